@@ -1,0 +1,241 @@
+/*
+ * abrk.h - C ABI of libabrk.so, the MI355X-native batched operational-space-control engine.
+ *
+ * This is the drop-in boundary for ONE hot path of abr/abr_control: the per-timestep
+ * evaluation of an arm's kinematics/dynamics and the control laws built on it.  Every
+ * entry point below names the reference interface (file:line under /root/reference)
+ * it replaces.  The reference evaluates one joint state per call through SymPy-generated
+ * Cython functions; this library evaluates a batch of B independent joint states per
+ * call with hand-written HIP kernels for gfx950.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, caller-owned buffers, no allocation inside
+ *     the compute calls.  Arrays are row-major [B, ...] exactly like the reference's
+ *     per-call outputs stacked along a leading batch axis.
+ *   - dtype selects the arithmetic AND the element type of every array argument:
+ *     ABRK_F64 (double) or ABRK_F32 (float).
+ *   - Every array pointer may be a device pointer (zero-copy) or a host pointer (the
+ *     library stages it through device scratch on the given stream and copies results
+ *     back before returning).  Detection is by hipPointerGetAttributes.
+ *   - `device` is a HIP device ordinal; `stream` is a hipStream_t (NULL = default
+ *     stream of that device).  Calls with device pointers are asynchronous on `stream`;
+ *     calls that had to stage host memory synchronise the stream before returning.
+ *   - Return value: 0 on success, negative ABRK_E* code on failure; abrk_last_error()
+ *     returns a thread-local message.  There is NO CPU fallback: without a usable HIP
+ *     device every compute call fails with ABRK_ENODEV.
+ *   - Re-entrant per (device, stream): concurrent calls must use distinct streams.
+ *
+ * Frames are addressed by integer id: link_i -> 2*i, joint_i -> 2*i+1, "EE" ->
+ * 2*n_joints+1 (the reference addresses them by the strings "link{i}", "joint{i}",
+ * "EE": e.g. abr_control/arms/ur5/config.py:301-339).
+ */
+#ifndef ABRK_H
+#define ABRK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABRK_VERSION 100
+#define ABRK_MAX_JOINTS 7
+#define ABRK_MAX_NULL 4
+
+enum { ABRK_F64 = 0, ABRK_F32 = 1 };
+
+enum {
+  ABRK_OK = 0,
+  ABRK_EINVAL = -1,   /* bad argument (shape, id, dtype, unsupported combination)      */
+  ABRK_ENODEV = -2,   /* no HIP device / HIP runtime error                              */
+  ABRK_ENOMEM = -3,   /* device allocation failed                                       */
+  ABRK_ENOARM = -4,   /* unknown arm id / name                                          */
+  ABRK_EFRAME = -5    /* invalid frame id ("Invalid transformation name", ur5/config.py:337) */
+};
+
+/* ---------------------------------------------------------------------------------
+ * Arm description = the constant table a reference `Config.__init__` + `_calc_T`
+ * encode symbolically (abr_control/arms/ur5/config.py:35-339, jaco2/config.py:35-356,
+ * twojoint/config.py:30-181, threejoint/config.py:32-223, onejoint/config.py:30-133).
+ *
+ *   T(link0)     = A0
+ *   T(joint_i)   = T(link_i) * AJ[i]
+ *   T(link_i+1)  = T(joint_i) * Rz(q_i) * B[i]          (all joints revolute about local z)
+ *   T(EE)        = T(link_n) * E   if has_ee else T(link_n)
+ *
+ * Each static transform is a 3x4 row-major affine [R | t] (bottom row 0 0 0 1 implied);
+ * R need not be exactly orthogonal (Jaco2's 8-digit constants are not) - the kernels
+ * differentiate the affine chain exactly.
+ * mdiag[l] = diagonal of the reference's 6x6 `_M_LINKS[l]` (m,m,m,Ixx,Iyy,Izz), applied
+ * in the WORLD frame exactly as base_config.py:628 does.  Only links l < n_links_dyn
+ * (= the reference's N_LINKS) enter M, g and C (base_config.py:449,626).
+ * --------------------------------------------------------------------------------- */
+typedef struct abrk_arm_desc {
+  int32_t n_joints;
+  int32_t n_links_dyn;
+  int32_t has_ee;
+  int32_t reserved;
+  double A0[12];
+  double AJ[ABRK_MAX_JOINTS][12];
+  double B[ABRK_MAX_JOINTS][12];
+  double E[12];
+  double mdiag[ABRK_MAX_JOINTS + 1][6];
+  char name[32];
+} abrk_arm_desc;
+
+/* Built-in arms ("ur5", "jaco2", "twojoint", "threejoint", "onejoint"): compile-time
+ * specialised kernels.  Returns an arm id >= 0 or ABRK_ENOARM.                        */
+int abrk_arm_builtin(const char* name);
+/* Register a user arm (runtime table; generic kernels).  Returns arm id >= 0.
+ * Replaces writing a BaseConfig subclass + first-use SymPy/Cython code generation
+ * (base_config.py:125-146).                                                            */
+int abrk_arm_create(const abrk_arm_desc* desc);
+int abrk_arm_get_desc(int arm_id, abrk_arm_desc* out);
+int abrk_arm_destroy(int arm_id);
+
+/* ---------------------------------------------------------------------------------
+ * Dynamics: replaces the generated `autofunc_c(q0..,[dq0..],[x,y,z])` calls behind
+ * BaseConfig.Tx/J/M/g/C/dJ/R/T/T_inv (base_config.py:210-415).  One launch evaluates
+ * every requested quantity for all B states; FK is shared between them.
+ *   want-mask bit      output (row-major per state)                reference wrapper
+ *   ABRK_WANT_TX       Tx  [B,3]      position of x in `frame`     base_config.py:371
+ *   ABRK_WANT_J        J   [B,6,n]    Jacobian of that point       base_config.py:249
+ *   ABRK_WANT_M        M   [B,n,n]    joint-space inertia          base_config.py:272
+ *   ABRK_WANT_G        g   [B,n]      gravity torque               base_config.py:210
+ *   ABRK_WANT_C        C   [B,n,n]    Christoffel Coriolis matrix  base_config.py:320
+ *   ABRK_WANT_DJ       dJ  [B,6,n]    time derivative of J         base_config.py:225
+ *   ABRK_WANT_R        R   [B,3,3]    rotation of `frame`          base_config.py:287
+ *   ABRK_WANT_T        T   [B,4,4]    transform of `frame`         base_config.py:338
+ *   ABRK_WANT_TINV     Ti  [B,4,4]    inverse transform            base_config.py:394
+ *   ABRK_WANT_QUAT     quat[B,4]      (w,x,y,z) of `frame`         base_config.py:304
+ * Outputs keep full `dtype` precision; the reference's float32 rounding of
+ * J/M/g/C/dJ/R (base_config.py:223,247,270,285,301,336) is applied by the Python layer.
+ * q: [B,n]; dq: [B,n] (needed for C/dJ, else may be NULL); x_off: [3] host values or NULL.
+ * --------------------------------------------------------------------------------- */
+enum {
+  ABRK_WANT_TX = 1u << 0,
+  ABRK_WANT_J = 1u << 1,
+  ABRK_WANT_M = 1u << 2,
+  ABRK_WANT_G = 1u << 3,
+  ABRK_WANT_C = 1u << 4,
+  ABRK_WANT_DJ = 1u << 5,
+  ABRK_WANT_R = 1u << 6,
+  ABRK_WANT_T = 1u << 7,
+  ABRK_WANT_TINV = 1u << 8,
+  ABRK_WANT_QUAT = 1u << 9
+};
+
+typedef struct abrk_dyn_out {
+  void* Tx;
+  void* J;
+  void* M;
+  void* g;
+  void* C;
+  void* dJ;
+  void* R;
+  void* T;
+  void* Tinv;
+  void* quat;
+} abrk_dyn_out;
+
+int abrk_dynamics_batch(int arm_id, int dtype, int64_t B, const void* q, const void* dq,
+                        int frame, const double* x_off, uint32_t want,
+                        const abrk_dyn_out* out, int device, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Secondary (null-space / joint-space) controllers: Damping.generate
+ * (controllers/damping.py:21-32), RestingConfig.generate (resting_config.py:18-42) and
+ * Joint.generate (joint.py:104-131, angle states only).
+ * --------------------------------------------------------------------------------- */
+enum { ABRK_NULL_DAMPING = 1, ABRK_NULL_RESTING = 2 };
+
+typedef struct abrk_null_ctrl {
+  int32_t kind;
+  int32_t rest_mask[ABRK_MAX_JOINTS]; /* RestingConfig.rest_indices                  */
+  double kp;                          /* Joint kp (resting)                          */
+  double kv;                          /* Damping kv / Joint kv                       */
+  double rest_angles[ABRK_MAX_JOINTS];
+} abrk_null_ctrl;
+
+/* OSC constructor arguments (controllers/osc.py:53-118), passed through unchanged; the
+ * derived constants (task_space_gains, lamb, sat_gain_*, scale_*) are formed inside
+ * with the reference's expressions.                                                    */
+typedef struct abrk_osc_params {
+  double kp, ko, kv, ki;
+  int32_t use_vmax;
+  int32_t use_g;
+  int32_t use_C;
+  int32_t orientation_algorithm;
+  double vmax[2];
+  int32_t ctrlr_dof[6];
+  int32_t ref_frame;            /* frame id of generate(ref_frame=...), osc.py:218       */
+  int32_t n_null;
+  double xyz_offset[3];         /* generate(xyz_offset=...), zeros == None               */
+  abrk_null_ctrl null_ctrl[ABRK_MAX_NULL];
+} abrk_osc_params;
+
+/* OSC.generate (controllers/osc.py:217-320) for B independent states.
+ *   q, dq [B,n]; target [B,6]; target_velocity [B,6] or NULL (== zeros, osc.py:239);
+ *   integrated_error [B,6] in/out state, required iff ki != 0 (osc.py:81,262-264);
+ *   u_null_ext [B,n] or NULL: extra secondary control signal already evaluated by the
+ *     caller (any Python null controller), projected into the null space with the same
+ *     filter as osc.py:315-318;
+ *   u [B,n] out; training_signal [B,n] out or NULL (osc.py:297).                      */
+int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_params* params, int64_t B,
+                            const void* q, const void* dq, const void* target,
+                            const void* target_velocity, void* integrated_error,
+                            const void* u_null_ext, void* u, void* training_signal,
+                            int device, void* stream);
+
+/* Sliding.generate (controllers/sliding.py:34-99), cartesian=True or False.
+ *   target [B,3] (cartesian) or [B,n]; target_velocity / target_acc same shape or NULL
+ *   (== 0); u [B,n] out; s [B,n] out or NULL (Sliding.s, sliding.py:89).              */
+typedef struct abrk_sliding_params {
+  double kd, lamb;
+  int32_t cartesian;
+  int32_t ref_frame;
+  double offset[3];
+} abrk_sliding_params;
+
+int abrk_sliding_generate_batch(int arm_id, int dtype, const abrk_sliding_params* params,
+                                int64_t B, const void* q, const void* dq, const void* target,
+                                const void* target_velocity, const void* target_acc, void* u,
+                                void* s, int device, void* stream);
+
+/* Joint.generate (controllers/joint.py:104-131) / Damping / RestingConfig standalone.
+ *   ctrl.kind == ABRK_NULL_DAMPING: u = M (-kv dq)            (damping.py:31-32)
+ *   ctrl.kind == ABRK_NULL_RESTING: RestingConfig.generate     (resting_config.py:33-42)
+ *   ctrl.kind == 0: Joint.generate with target [B,n], target_velocity [B,n] or NULL,
+ *                   account_for_gravity as given.                                       */
+int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_ctrl* ctrl,
+                              int account_for_gravity, int64_t B, const void* q,
+                              const void* dq, const void* target, const void* target_velocity,
+                              void* u, int device, void* stream);
+
+/* ---------------------------------------------------------------------------------
+ * Device plumbing (the host side is Python + ctypes; no PyTorch involved).
+ * --------------------------------------------------------------------------------- */
+int abrk_device_count(void);
+int abrk_device_name(int device, char* buf, size_t len);
+void* abrk_malloc(int device, size_t bytes);               /* NULL on failure */
+int abrk_free(int device, void* p);
+int abrk_memcpy_h2d(int device, void* dst, const void* src, size_t bytes, void* stream);
+int abrk_memcpy_d2h(int device, void* dst, const void* src, size_t bytes, void* stream);
+int abrk_memset(int device, void* dst, int value, size_t bytes, void* stream);
+void* abrk_stream_create(int device);
+int abrk_stream_destroy(int device, void* stream);
+int abrk_stream_sync(int device, void* stream);
+int abrk_device_sync(int device);
+void* abrk_event_create(int device);
+int abrk_event_destroy(int device, void* ev);
+int abrk_event_record(int device, void* ev, void* stream);
+int abrk_event_elapsed_ms(int device, void* start, void* stop, float* ms); /* syncs stop */
+
+const char* abrk_last_error(void);
+int abrk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABRK_H */

@@ -1,0 +1,313 @@
+"""Worker for gen_golden.py: one arm (or the known-answer grids) per process.
+
+TEST INFRASTRUCTURE.  Imports the reference (scratch copy on PYTHONPATH) and records
+its outputs; never imported by the package, never shipped to the GPU path.
+"""
+import importlib
+import sys
+
+import numpy as np
+
+what, OUT = sys.argv[1], sys.argv[2]
+
+
+# ----------------------------------------------------------------------------------------
+class RawConfig:
+    """robot_config whose wrappers skip the float32 cast = Oracle-D.
+
+    Mirrors abr_control/arms/base_config.py:210-336 wrapper by wrapper, calling the very
+    same generated functions (rc._M, rc._J[...], ...) but keeping their fp64 output.
+    """
+
+    def __init__(self, rc):
+        self.rc = rc
+        self.N_JOINTS = rc.N_JOINTS
+        self.N_LINKS = rc.N_LINKS
+        self.x_zeros = np.zeros(3)
+
+    def _fn(self, name, x):
+        x = self.x_zeros if x is None else x
+        return x, (name + "[0,0,0]" if np.allclose(x, 0) else name)
+
+    def g(self, q):
+        self.rc.g(q)
+        return np.array(self.rc._g(*tuple(q)), dtype="float64").flatten()
+
+    def dJ(self, name, q, dq, x=None):
+        self.rc.dJ(name, q, dq, x)
+        x, fn = self._fn(name, x)
+        return np.array(self.rc._dJ[fn](*(tuple(q) + tuple(dq) + tuple(x))), dtype="float64")
+
+    def J(self, name, q, x=None):
+        self.rc.J(name, q, x)
+        x, fn = self._fn(name, x)
+        return np.array(self.rc._J[fn](*(tuple(q) + tuple(x))), dtype="float64")
+
+    def M(self, q):
+        self.rc.M(q)
+        return np.array(self.rc._M(*tuple(q)), dtype="float64")
+
+    def R(self, name, q):
+        self.rc.R(name, q)
+        return np.array(self.rc._R[name](*tuple(q)), dtype="float64")
+
+    def quaternion(self, name, q):
+        from abr_control.utils import transformations
+
+        R = self.R(name, q)
+        return transformations.unit_vector(transformations.quaternion_from_matrix(matrix=R))
+
+    def C(self, q, dq):
+        self.rc.C(q, dq)
+        return np.array(self.rc._C(*(tuple(q) + tuple(dq))), dtype="float64")
+
+    def Tx(self, name, q, x=None):
+        return self.rc.Tx(name, q, x)
+
+
+def frames_of(rc):
+    fr = []
+    for i in range(rc.N_JOINTS + 1):
+        fr.append(f"link{i}")
+        if i < rc.N_JOINTS:
+            fr.append(f"joint{i}")
+    fr.append("EE")
+    return fr
+
+
+def draw(rng, B, n, nt=6):
+    """The reference benchmark's input distribution (examples/timing_plots.py:18-20)."""
+    q = rng.uniform(0, 2 * np.pi, (B, n))
+    dq = rng.uniform(0, 5, (B, n))
+    tgt = rng.uniform(-1, 1, (B, nt))
+    return q, dq, tgt
+
+
+def mx_diag(raw, q, dof, ref_frame="EE", x=None):
+    """det and singular values of Mx_inv (fp64) - lets tests find threshold-band states."""
+    J = raw.J(ref_frame, q, x)[np.asarray(dof, dtype=bool)]
+    M = raw.M(q)
+    A = J @ np.linalg.inv(M) @ J.T
+    s = np.linalg.svd(A, compute_uv=False)
+    return np.linalg.det(A), s
+
+
+# ----------------------------------------------------------------------------------------
+def gen_arm(arm):
+    mod = importlib.import_module(f"abr_control.arms.{arm}")
+    from abr_control.controllers import OSC, Damping, Joint, RestingConfig, Sliding
+
+    rc = mod.Config(use_cython=True)
+    raw = RawConfig(rc)
+    n = rc.N_JOINTS
+    out = {}
+
+    # ---------------- dynamics: raw fp64 outputs of the generated functions ------------
+    rng = np.random.RandomState(0)
+    Nd = 48
+    q, dq, _ = draw(rng, Nd, n)
+    q[0] = 0.0
+    q[1] = np.asarray(rc.START_ANGLES, dtype=float)
+    q[2] = -q[2]  # negative angles too
+    q[3] = q[3] * 20.0 - 50.0  # well outside [0, 2pi)
+    dq[4] = -dq[4]
+    out["dyn_q"], out["dyn_dq"] = q, dq
+    frames = frames_of(rc)
+    out["frames"] = np.array(frames)
+    xoff = np.array([0.11, -0.23, 0.37])
+    out["xoff"] = xoff
+    for f in frames:
+        out[f"Tx_{f}"] = np.array([rc.Tx(f, q[i]) for i in range(Nd)])
+        out[f"J_{f}"] = np.array([raw.J(f, q[i]) for i in range(Nd)])
+    # every frame's rotation / full transform where cheap (small arms), EE for all
+    rframes = frames if n <= 3 else ["EE"]
+    for f in rframes:
+        out[f"R_{f}"] = np.array([raw.R(f, q[i]) for i in range(Nd)])
+        out[f"dJ_{f}"] = np.array([raw.dJ(f, q[i], dq[i]) for i in range(Nd)])
+    out["T_EE"] = np.array([np.array(rc.T("EE", q[i]), dtype=float) for i in range(Nd)])
+    out["M"] = np.array([raw.M(q[i]) for i in range(Nd)])
+    out["g"] = np.array([raw.g(q[i]) for i in range(Nd)])
+    out["C"] = np.array([raw.C(q[i], dq[i]) for i in range(Nd)])
+    out["quat_EE"] = np.array([raw.quaternion("EE", q[i]) for i in range(Nd)])
+    # point offset inside the EE frame (exercises the x != 0 generated variants)
+    out["Tx_EE_x"] = np.array([rc.Tx("EE", q[i], x=xoff) for i in range(Nd)])
+    out["J_EE_x"] = np.array([raw.J("EE", q[i], x=xoff) for i in range(Nd)])
+    if n <= 3 or arm == "ur5":
+        out["dJ_EE_x"] = np.array([raw.dJ("EE", q[i], dq[i], x=xoff) for i in range(Nd)])
+    if n <= 3:
+        out["Tinv_EE"] = np.array([np.array(rc.T_inv("EE", q[i]), dtype=float) for i in range(Nd)])
+    print("  dynamics done; function types:", type(rc._M).__name__, type(rc._C).__name__, flush=True)
+
+    # ---------------- controllers: Oracle-S and Oracle-D per case -----------------------
+    xyz = [True, True, True, False, False, False]
+    six = [True] * 6
+
+    def run_osc(key, B, seed, kwargs, null=None, gen_kwargs=None, steps=1, tv=False, with_diag=True):
+        """null: list of (cls, kwargs); builds separate controller objects for S and D."""
+        rng = np.random.RandomState(seed)
+        q, dq, tgt = draw(rng, B, n)
+        tvel = rng.uniform(-0.5, 0.5, (B, 6)) if tv else None
+        gen_kwargs = gen_kwargs or {}
+        res = {}
+        for label, cfg in (("S", rc), ("D", raw)):
+            nulls = None
+            if null:
+                nulls = [cls(cfg, **kw) for cls, kw in null]
+            us = np.zeros((steps, B, n))
+            ts = np.zeros((steps, B, n))
+            for b in range(B):
+                ctrlr = OSC(cfg, null_controllers=nulls, **kwargs)  # fresh state per row
+                for s in range(steps):
+                    extra = dict(gen_kwargs)
+                    if tvel is not None:
+                        extra["target_velocity"] = tvel[b]
+                    # multi-step cases: same (q,dq,target) each step -> only the
+                    # integrated_error state evolves (osc.py:262-264)
+                    us[s, b] = ctrlr.generate(q[b], dq[b], tgt[b], **extra)
+                    ts[s, b] = ctrlr.training_signal
+            res[label] = (us, ts)
+        out[f"{key}_q"], out[f"{key}_dq"], out[f"{key}_target"] = q, dq, tgt
+        if tvel is not None:
+            out[f"{key}_tvel"] = tvel
+        for label in ("S", "D"):
+            us, ts = res[label]
+            out[f"{key}_u{label}"] = us if steps > 1 else us[0]
+            out[f"{key}_ts{label}"] = ts if steps > 1 else ts[0]
+        if with_diag:
+            dof = kwargs.get("ctrlr_dof", xyz)
+            dets = np.zeros(B)
+            svs = np.zeros((B, int(np.sum(dof))))
+            for b in range(B):
+                dets[b], svs[b] = mx_diag(
+                    raw, q[b], dof, gen_kwargs.get("ref_frame", "EE"), gen_kwargs.get("xyz_offset")
+                )
+            out[f"{key}_det"], out[f"{key}_sv"] = dets, svs
+        d = np.max(np.abs(res["S"][0] - res["D"][0]), axis=-1) / np.max(np.abs(res["D"][0]), axis=-1)
+        print(f"  {key}: B={B} S-vs-D rel median={np.median(d):.2e} p99={np.percentile(d, 99):.2e}", flush=True)
+
+    def run_simple(key, B, seed, make, nt, call):
+        rng = np.random.RandomState(seed)
+        q, dq, tgt = draw(rng, B, n, nt)
+        out[f"{key}_q"], out[f"{key}_dq"], out[f"{key}_target"] = q, dq, tgt
+        for label, cfg in (("S", rc), ("D", raw)):
+            c = make(cfg)
+            out[f"{key}_u{label}"] = np.array([call(c, q[b], dq[b], tgt[b]) for b in range(B)])
+        print(f"  {key}: B={B}", flush=True)
+
+    if arm == "twojoint":
+        xy = [True, True, False, False, False, False]
+        # BASELINE config 1: twojoint OSC position control (row 0 is the "batch=1" case)
+        run_osc("cfg1", 256, 0, dict(kp=10, kv=3, ctrlr_dof=xy))
+        run_osc("osc_xy_vmax", 128, 2, dict(kp=20, kv=5, ctrlr_dof=xy, vmax=[0.5, 0.5]))
+        run_osc("osc_xy_C", 128, 3, dict(kp=10, kv=3, ctrlr_dof=xy, use_C=True))
+        run_simple("sliding", 256, 4, lambda c: Sliding(c), 3,
+                   lambda c, q, dq, t: c.generate(q, dq, t))
+    elif arm == "threejoint":
+        # BASELINE config 5: threejoint Sliding(), defaults kd=160, lamb=30, cartesian
+        run_simple("cfg5", 2048, 0, lambda c: Sliding(c), 3,
+                   lambda c, q, dq, t: c.generate(q, dq, t))
+        run_simple("sliding_tv", 128, 5, lambda c: Sliding(c, kd=20.0, lamb=5.0), 3,
+                   lambda c, q, dq, t: c.generate(q, dq, t, target_velocity=t[::-1] * 0.3,
+                                                  target_acc=t * 0.1))
+        run_osc("osc_xy", 256, 1, dict(kp=50, kv=None, ctrlr_dof=[True, True, False, False, False, False]))
+        # planar arm: position xy + orientation about z (examples' 3-dof task)
+        for alg in (0, 1):
+            run_osc(f"osc_xyg_alg{alg}", 128, 6 + alg,
+                    dict(kp=50, ko=20, kv=8, ctrlr_dof=[True, True, False, False, False, True],
+                         orientation_algorithm=alg))
+        run_simple("joint", 128, 9, lambda c: Joint(c, kp=20, kv=4), 3,
+                   lambda c, q, dq, t: c.generate(q, dq, t))
+    elif arm == "ur5":
+        # BASELINE config 2: UR5 OSC, batch 4096, xyz, use_g
+        run_osc("cfg2", 4096, 0, dict(kp=200, ctrlr_dof=xyz))
+        # BASELINE config 4 (sample): UR5 OSC + gravity + Coriolis
+        run_osc("cfg4", 2048, 1, dict(kp=200, ctrlr_dof=xyz, use_g=True, use_C=True))
+        # the reference benchmark's own UR5 setting (examples/timing_plots.py:36)
+        for alg in (0, 1):
+            run_osc(f"osc6_alg{alg}", 512, 10 + alg,
+                    dict(kp=200, ko=150, kv=25, ctrlr_dof=six, orientation_algorithm=alg))
+        run_osc("osc_xyz_vmax_ki", 64, 12, dict(kp=100, kv=15, ki=0.2, ctrlr_dof=xyz, vmax=[0.5, 1.0]), steps=5)
+        run_osc("osc6_vmax", 128, 13, dict(kp=100, ko=80, kv=15, ctrlr_dof=six, vmax=[0.5, 1.0]))
+        run_osc("osc_xyz_tvel", 256, 14, dict(kp=200, ctrlr_dof=xyz), tv=True)
+        run_osc("osc_nog", 128, 15, dict(kp=30, kv=7, ctrlr_dof=xyz, use_g=False))
+        run_osc("osc_offset", 128, 16, dict(kp=200, ctrlr_dof=xyz),
+                gen_kwargs=dict(xyz_offset=np.array([0.11, -0.23, 0.37])))
+        run_osc("osc_link5", 128, 17, dict(kp=200, ctrlr_dof=xyz), gen_kwargs=dict(ref_frame="link5"))
+        run_osc("osc_abg", 128, 18, dict(kp=100, ko=60, kv=12,
+                                          ctrlr_dof=[False, False, False, True, True, True]))
+        run_osc("osc_xz_b", 128, 19, dict(kp=100, ko=60, kv=12,
+                                           ctrlr_dof=[True, False, True, False, True, False]))
+        run_osc("osc_null2", 256, 20, dict(kp=200, ctrlr_dof=xyz),
+                null=[(Damping, dict(kv=10)),
+                      (RestingConfig, dict(rest_angles=[None, 0.8, -1.6, None, 1.5, None], kp=40, kv=8))])
+        run_simple("joint", 256, 21, lambda c: Joint(c, kp=50, kv=9), 6,
+                   lambda c, q, dq, t: c.generate(q, dq, t * 3.0))
+        run_simple("joint_tv_nog", 128, 22, lambda c: Joint(c, kp=50, account_for_gravity=False), 6,
+                   lambda c, q, dq, t: c.generate(q, dq, t * 3.0, target_velocity=t[::-1]))
+        run_simple("sliding", 256, 23, lambda c: Sliding(c), 3,
+                   lambda c, q, dq, t: c.generate(q, dq, t))
+    elif arm == "jaco2":
+        # BASELINE config 3 (sample of the 16384): Jaco2 OSC + null-space Damping
+        run_osc("cfg3", 2048, 0, dict(kp=200, ctrlr_dof=xyz), null=[(Damping, dict(kv=10))])
+        # the reference benchmark's Jaco2 setting (examples/timing_plots.py:37)
+        run_osc("osc5", 512, 30, dict(kp=200, ctrlr_dof=[True] * 5 + [False]))
+        run_osc("osc6_alg1", 256, 31, dict(kp=200, ko=150, kv=25, ctrlr_dof=six, orientation_algorithm=1))
+        run_osc("osc_rest", 256, 32, dict(kp=200, ctrlr_dof=xyz),
+                null=[(RestingConfig, dict(rest_angles=[None, 3.14, 1.57, None, None, 3.04], kp=30, kv=6))])
+        run_simple("damping", 128, 33, lambda c: Damping(c, kv=10), 6,
+                   lambda c, q, dq, t: c.generate(q, dq))
+
+    np.savez_compressed(f"{OUT}/{arm}.npz", **out)
+    print(f"  wrote {OUT}/{arm}.npz ({len(out)} arrays)", flush=True)
+
+
+# ----------------------------------------------------------------------------------------
+def gen_known():
+    """Closed-form twojoint answers the reference's own tests pin its functions against
+    (abr_control/arms/tests/dummy_base_arm.py; grids as in test_base_config.py:40-180,
+    coarser for the 4-D (q,dq) grids to keep the fixture small), plus the doctest
+    constants of utils/transformations.py and the exact values of test_osc.py:12-59."""
+    from abr_control.arms.tests.dummy_base_arm import TwoJoint
+    from abr_control.utils import transformations as tf
+
+    ta = TwoJoint()
+    out = {}
+    qv = np.linspace(0, 2 * np.pi, 25)
+    Q = np.array([[a, b] for a in qv for b in qv])
+    out["q_grid"] = Q
+    for f in ("link0", "joint0", "link1", "joint1", "link2", "EE"):
+        out[f"R_{f}"] = np.array([getattr(ta, f"R_{f}")(q) for q in Q], dtype=float)
+        out[f"Tx_{f}"] = np.array([getattr(ta, f"Tx_{f}")(q) for q in Q], dtype=float)
+        out[f"Tinv_{f}"] = np.array([getattr(ta, f"T_inv_{f}")(q) for q in Q], dtype=float)
+        out[f"J_{f}"] = np.array([getattr(ta, f"J_{f}")(q) for q in Q], dtype=float)
+    out["M"] = np.array([ta.M(q) for q in Q], dtype=float)
+    out["g"] = np.array([ta.g(q) for q in Q], dtype=float)
+    v = np.linspace(0, 2 * np.pi, 7)
+    QD = np.array([[a, b, c, d] for a in v for b in v for c in v for d in v])
+    out["qdq_grid"] = QD
+    for f in ("link0", "joint0", "link1", "joint1", "link2", "EE"):
+        out[f"dJ_{f}"] = np.array([getattr(ta, f"dJ_{f}")(x[:2], x[2:]) for x in QD], dtype=float)
+    out["C"] = np.array([ta.C(x[:2], x[2:]) for x in QD], dtype=float)
+
+    # transformations.py known answers (run the reference's functions on seeded inputs)
+    rng = np.random.RandomState(0)
+    ang = rng.uniform(-2 * np.pi, 2 * np.pi, (64, 3))
+    out["tf_angles"] = ang
+    out["tf_quat_from_euler_rxyz"] = np.array([tf.quaternion_from_euler(*a, axes="rxyz") for a in ang])
+    out["tf_euler_matrix_rxyz"] = np.array([tf.euler_matrix(*a, axes="rxyz")[:3, :3] for a in ang])
+    out["tf_quat_from_matrix"] = np.array(
+        [tf.quaternion_from_matrix(tf.euler_matrix(*a, axes="rxyz")) for a in ang])
+    qa = rng.normal(size=(64, 4))
+    qb = rng.normal(size=(64, 4))
+    out["tf_qa"], out["tf_qb"] = qa, qb
+    out["tf_quat_mul"] = np.array([tf.quaternion_multiply(a, b) for a, b in zip(qa, qb)])
+    out["tf_quat_conj"] = np.array([tf.quaternion_conjugate(a) for a in qa])
+    out["tf_unit"] = np.array([tf.unit_vector(a) for a in qa])
+    np.savez_compressed(f"{OUT}/known_answers.npz", **out)
+    print(f"  wrote {OUT}/known_answers.npz", flush=True)
+
+
+if what == "known":
+    gen_known()
+else:
+    gen_arm(what)

@@ -1,0 +1,169 @@
+"""ctypes front-end of oracle/libabrk_oracle.so (the plain-C restatement of the reference's
+hot path).  TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg - never by the abr_control_amd package."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from abr_control_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libabrk_oracle.so")
+_lib = None
+_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "abrk_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B" if force else "-s"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _c(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Oracle:
+    """Per-arm oracle.  All methods take ONE state (like the reference) unless named *_batch."""
+
+    def __init__(self, table):
+        self.table = table
+        self.desc = _abi.desc_from_table(table)
+        self.n = self.desc.n_joints
+        self._d = C.byref(self.desc)
+        self.L = lib()
+
+    def fid(self, name):
+        return _abi.frame_id(name, self.n)
+
+    def _x(self, x):
+        return _c(np.zeros(3) if x is None else x)
+
+    def T(self, name, q):
+        out = np.zeros((4, 4))
+        assert self.L.abrk_oracle_T(self._d, self.fid(name), _p(_c(q)), _p(out)) == 0
+        return out
+
+    def Tx(self, name, q, x=None):
+        out = np.zeros(3)
+        assert self.L.abrk_oracle_Tx(self._d, self.fid(name), _p(_c(q)), _p(self._x(x)), _p(out)) == 0
+        return out
+
+    def J(self, name, q, x=None):
+        out = np.zeros((6, self.n))
+        assert self.L.abrk_oracle_J(self._d, self.fid(name), _p(_c(q)), _p(self._x(x)), _p(out)) == 0
+        return out
+
+    def dJ(self, name, q, dq, x=None):
+        out = np.zeros((6, self.n))
+        assert self.L.abrk_oracle_dJ(self._d, self.fid(name), _p(_c(q)), _p(_c(dq)), _p(self._x(x)), _p(out)) == 0
+        return out
+
+    def M(self, q):
+        out = np.zeros((self.n, self.n))
+        self.L.abrk_oracle_M(self._d, _p(_c(q)), _p(out))
+        return out
+
+    def g(self, q):
+        out = np.zeros(self.n)
+        self.L.abrk_oracle_g(self._d, _p(_c(q)), _p(out))
+        return out
+
+    def C(self, q, dq):
+        out = np.zeros((self.n, self.n))
+        self.L.abrk_oracle_C(self._d, _p(_c(q)), _p(_c(dq)), _p(out))
+        return out
+
+    def R(self, name, q):
+        out = np.zeros((3, 3))
+        assert self.L.abrk_oracle_R(self._d, self.fid(name), _p(_c(q)), _p(out)) == 0
+        return out
+
+    def T_inv(self, name, q):
+        out = np.zeros((4, 4))
+        assert self.L.abrk_oracle_Tinv(self._d, self.fid(name), _p(_c(q)), _p(out)) == 0
+        return out
+
+    def quaternion(self, name, q):
+        out = np.zeros(4)
+        assert self.L.abrk_oracle_quaternion(self._d, self.fid(name), _p(_c(q)), _p(out)) == 0
+        return out
+
+    # ---- controllers, batched drivers (row loop in C) ----
+    def osc_batch(self, params, q, dq, target, target_velocity=None, integrated_error=None,
+                  u_null_ext=None, want_training=False):
+        q, dq, target = _c(q), _c(dq), _c(target)
+        B = q.shape[0]
+        tv, une = _c(target_velocity), _c(u_null_ext)
+        u = np.zeros((B, self.n))
+        ts = np.zeros((B, self.n)) if want_training else None
+        rc = self.L.abrk_oracle_osc_generate_batch(
+            self._d, C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target), _p(tv),
+            _p(integrated_error), _p(une), _p(u), _p(ts))
+        assert rc == 0, rc
+        return (u, ts) if want_training else u
+
+    def sliding_batch(self, params, q, dq, target, target_velocity=None, target_acc=None):
+        q, dq, target = _c(q), _c(dq), _c(target)
+        B = q.shape[0]
+        u = np.zeros((B, self.n))
+        s = np.zeros((B, self.n))
+        rc = self.L.abrk_oracle_sliding_generate_batch(
+            self._d, C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
+            _p(_c(target_velocity)), _p(_c(target_acc)), _p(u), _p(s))
+        assert rc == 0, rc
+        return u, s
+
+    def joint_batch(self, ctrl, account_for_gravity, q, dq, target=None, target_velocity=None):
+        q, dq = _c(q), _c(dq)
+        B = q.shape[0]
+        target, tv = _c(target), _c(target_velocity)
+        u = np.zeros((B, self.n))
+        for b in range(B):
+            rc = self.L.abrk_oracle_joint_generate(
+                self._d, C.byref(ctrl), int(account_for_gravity), _p(q[b]), _p(dq[b]),
+                None if target is None else _p(target[b]),
+                None if tv is None else _p(tv[b]), _p(u[b]))
+            assert rc == 0
+        return u
+
+
+def quat_from_matrix(R):
+    out = np.zeros(4)
+    lib().abrk_oracle_quat_from_matrix(_p(_c(R)), _p(out))
+    return out
+
+
+def quat_from_euler_rxyz(a, b, c):
+    out = np.zeros(4)
+    lib().abrk_oracle_quat_from_euler_rxyz(C.c_double(a), C.c_double(b), C.c_double(c), _p(out))
+    return out
+
+
+def euler_matrix_rxyz(a, b, c):
+    out = np.zeros((3, 3))
+    lib().abrk_oracle_euler_matrix_rxyz(C.c_double(a), C.c_double(b), C.c_double(c), _p(out))
+    return out
+
+
+def quat_mul(q1, q0):
+    out = np.zeros(4)
+    lib().abrk_oracle_quat_mul(_p(_c(q1)), _p(_c(q0)), _p(out))
+    return out
