@@ -1,0 +1,171 @@
+"""ctypes binding of libabrk.so (include/abrk.h).  No PyTorch, no fallback: if the shared
+library is missing this module raises on first use, and every compute call raises when
+there is no HIP device (ABRK_ENODEV)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libabrk.so")
+_lib = None
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+
+
+class AbrkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libabrk: {_abi.ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+def lib():
+    """The loaded libabrk.so (built by `__graft_entry__.build()` / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found - build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C abr_control_amd/csrc). "
+                "abr_control_amd has no CPU fallback."
+            )
+        L = C.CDLL(LIB_PATH)
+        L.abrk_last_error.restype = C.c_char_p
+        L.abrk_arm_builtin.argtypes = [C.c_char_p]
+        L.abrk_arm_create.argtypes = [C.POINTER(_abi.ArmDesc)]
+        L.abrk_arm_get_desc.argtypes = [C.c_int, C.POINTER(_abi.ArmDesc)]
+        L.abrk_arm_destroy.argtypes = [C.c_int]
+        L.abrk_dynamics_batch.argtypes = [
+            C.c_int, C.c_int, _i64, _vp, _vp, C.c_int, C.POINTER(C.c_double), C.c_uint32,
+            C.POINTER(_abi.DynOut), C.c_int, _vp]
+        L.abrk_osc_generate_batch.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+            C.c_int, _vp]
+        L.abrk_sliding_generate_batch.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.SlidingParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+            C.c_int, _vp]
+        L.abrk_joint_generate_batch.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.NullCtrl), C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
+        L.abrk_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
+        L.abrk_malloc.restype = _vp
+        L.abrk_malloc.argtypes = [C.c_int, C.c_size_t]
+        L.abrk_free.argtypes = [C.c_int, _vp]
+        L.abrk_memcpy_h2d.argtypes = [C.c_int, _vp, _vp, C.c_size_t, _vp]
+        L.abrk_memcpy_d2h.argtypes = [C.c_int, _vp, _vp, C.c_size_t, _vp]
+        L.abrk_memset.argtypes = [C.c_int, _vp, C.c_int, C.c_size_t, _vp]
+        L.abrk_stream_create.restype = _vp
+        L.abrk_stream_create.argtypes = [C.c_int]
+        L.abrk_stream_destroy.argtypes = [C.c_int, _vp]
+        L.abrk_stream_sync.argtypes = [C.c_int, _vp]
+        L.abrk_device_sync.argtypes = [C.c_int]
+        L.abrk_event_create.restype = _vp
+        L.abrk_event_create.argtypes = [C.c_int]
+        L.abrk_event_destroy.argtypes = [C.c_int, _vp]
+        L.abrk_event_record.argtypes = [C.c_int, _vp, _vp]
+        L.abrk_event_elapsed_ms.argtypes = [C.c_int, _vp, _vp, C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise AbrkError(rc, lib().abrk_last_error().decode())
+    return rc
+
+
+def device_count():
+    return lib().abrk_device_count()
+
+
+def device_name(device=0):
+    buf = C.create_string_buffer(256)
+    check(lib().abrk_device_name(device, buf, 256))
+    return buf.value.decode()
+
+
+NP_DTYPE = {_abi.F64: np.float64, _abi.F32: np.float32}
+
+
+class DeviceArray:
+    """A caller-owned device buffer (hipMalloc through the C ABI): shape + dtype + pointer.
+    Passing DeviceArrays to the batched calls keeps them zero-copy and asynchronous."""
+
+    def __init__(self, shape, dtype=np.float64, device=0):
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.device = device
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = lib().abrk_malloc(device, self.nbytes)
+        if not self.ptr:
+            raise AbrkError(-3, lib().abrk_last_error().decode())
+
+    @classmethod
+    def from_numpy(cls, a, device=0, stream=None):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype, device)
+        check(lib().abrk_memcpy_h2d(device, d.ptr, a.ctypes.data, a.nbytes, stream))
+        return d
+
+    def numpy(self, stream=None):
+        out = np.empty(self.shape, self.dtype)
+        check(lib().abrk_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes, stream))
+        return out
+
+    def zero_(self, stream=None):
+        check(lib().abrk_memset(self.device, self.ptr, 0, self.nbytes, stream))
+        return self
+
+    def free(self):
+        if self.ptr:
+            lib().abrk_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    def __init__(self, device=0):
+        self.device = device
+        self.ptr = lib().abrk_stream_create(device)
+        if not self.ptr:
+            raise AbrkError(-2, lib().abrk_last_error().decode())
+
+    def sync(self):
+        check(lib().abrk_stream_sync(self.device, self.ptr))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().abrk_stream_destroy(self.device, self.ptr)
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self, device=0):
+        self.device = device
+        self.ptr = lib().abrk_event_create(device)
+        if not self.ptr:
+            raise AbrkError(-2, lib().abrk_last_error().decode())
+
+    def record(self, stream=None):
+        check(lib().abrk_event_record(self.device, self.ptr, stream.ptr if stream else None))
+
+    def elapsed_ms_since(self, start):
+        ms = C.c_float()
+        check(lib().abrk_event_elapsed_ms(self.device, start.ptr, self.ptr, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().abrk_event_destroy(self.device, self.ptr)
+        except Exception:
+            pass

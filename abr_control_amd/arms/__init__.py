@@ -1,0 +1,8 @@
+"""Arm configs with the reference's `robot_config` API (abr_control/arms)."""
+from . import jaco2, onejoint, threejoint, twojoint, ur5  # noqa: F401
+from .base_config import BatchedConfig  # noqa: F401
+
+
+def from_table(table, **kwargs):
+    """robot_config for a user arm table (tools/extract_arm_table.py) - generic kernels."""
+    return BatchedConfig(table, builtin=None, **kwargs)

@@ -1,0 +1,5 @@
+// Generic kernels for user arms with 3 joint(s) (table passed at launch), both dtypes.
+#include "abrk_rt.h"
+namespace abrk {
+ABRK_RT_DEFINE(3)
+}  // namespace abrk

@@ -1,0 +1,690 @@
+// abrk_ctrl.h - per-row control laws on top of abrk_device.h: OSC.generate
+// (abr_control/controllers/osc.py:217-320), Sliding.generate (sliding.py:34-99),
+// Joint / Damping / RestingConfig (joint.py:104-131, damping.py:21-32,
+// resting_config.py:18-42) and the small fixed-size dense algebra they need, all unrolled
+// into registers (no LAPACK on a GPU lane: inv -> Cholesky, pinv -> Jacobi).
+#pragma once
+#include "abrk_device.h"
+
+namespace abrk {
+
+// ---------------------------------------------------------------- device-side parameter blocks
+// (filled on the host from abrk_osc_params etc., in the kernel's arithmetic type)
+template <class T>
+struct NullP {
+  int kind;
+  int mask[7];
+  T kp, kv;
+  T rest[7];
+};
+
+template <class T>
+struct OscP {
+  T kp, ko, kv, ki;
+  T vmax0, vmax1;
+  T off[3];
+  int use_vmax, use_g, alg;
+  int dof[6];
+  int pos_on, ori_on;
+  int ref_frame, m_joints, has_off;
+  int n_null;
+  NullP<T> nul[4];
+};
+
+template <class T>
+struct SlidingP {
+  T kd, lamb;
+  T off[3];
+  int cartesian, ref_frame, m_joints, has_off;
+};
+
+template <class T>
+struct JointP {
+  NullP<T> c;  // kind 0: Joint; 1: Damping; 2: RestingConfig
+  int account_for_gravity;
+};
+
+// ---------------------------------------------------------------- small dense algebra
+template <class T>
+ABRK_INL T rcp(T x) {
+  return T(1) / x;
+}
+
+// Cholesky of a symmetric K x K matrix in lower-triangular packed storage.
+// L overwrites a copy; il[j] = 1/L_jj.  ok=false if a pivot is not positive.
+template <int K, class T>
+ABRK_INL bool chol(const T (&S)[K * (K + 1) / 2], T (&L)[K * (K + 1) / 2], T (&il)[K]) {
+  bool ok = true;
+  sfor<K>([&](auto j) ABRK_LAMBDA {
+    T dgn = S[tri(j(), j())];
+    sfor<j()>([&](auto k) ABRK_LAMBDA { dgn -= L[tri(j(), k())] * L[tri(j(), k())]; });
+    bool pos = dgn > T(0);
+    ok = ok && pos;
+    T sq = Rm<T>::sqrt(pos ? dgn : T(1));
+    T inv = pos ? rcp(sq) : T(0);
+    L[tri(j(), j())] = sq;
+    il[j()] = inv;
+    sfor<K - 1 - j()>([&](auto ii) ABRK_LAMBDA {
+      constexpr int i = j() + 1 + ii();
+      T acc = S[tri(i, j())];
+      sfor<j()>([&](auto k) ABRK_LAMBDA { acc -= L[tri(i, k())] * L[tri(j(), k())]; });
+      L[tri(i, j())] = acc * inv;
+    });
+  });
+  return ok;
+}
+// x = L^-1 b
+template <int K, class T>
+ABRK_INL void chol_fwd(const T (&L)[K * (K + 1) / 2], const T (&il)[K], const T (&b)[K], T (&x)[K]) {
+  sfor<K>([&](auto i) ABRK_LAMBDA {
+    T acc = b[i()];
+    sfor<i()>([&](auto k) ABRK_LAMBDA { acc -= L[tri(i(), k())] * x[k()]; });
+    x[i()] = acc * il[i()];
+  });
+}
+// x = L^-T b
+template <int K, class T>
+ABRK_INL void chol_bwd(const T (&L)[K * (K + 1) / 2], const T (&il)[K], const T (&b)[K], T (&x)[K]) {
+  sfor<K>([&](auto ir) ABRK_LAMBDA {
+    constexpr int i = K - 1 - ir();
+    T acc = b[i];
+    sfor<K - 1 - i>([&](auto kk) ABRK_LAMBDA {
+      constexpr int k = i + 1 + kk();
+      acc -= L[tri(k, i)] * x[k];
+    });
+    x[i] = acc * il[i];
+  });
+}
+// symmetric matvec from packed lower triangle
+template <int K, class T>
+ABRK_INL void symv(const T (&S)[K * (K + 1) / 2], const T (&v)[K], T (&o)[K]) {
+  sfor<K>([&](auto i) ABRK_LAMBDA {
+    T acc = T(0);
+    sfor<K>([&](auto j) ABRK_LAMBDA { acc += S[tri(i(), j())] * v[j()]; });
+    o[i()] = acc;
+  });
+}
+// inverse of an SPD matrix from its Cholesky factor: Sinv = L^-T L^-1 (packed)
+template <int K, class T>
+ABRK_INL void chol_inverse(const T (&L)[K * (K + 1) / 2], const T (&il)[K], T (&Sinv)[K * (K + 1) / 2]) {
+  T Li[K * (K + 1) / 2];  // L^-1, lower
+  sfor<K>([&](auto j) ABRK_LAMBDA {
+    Li[tri(j(), j())] = il[j()];
+    sfor<K - 1 - j()>([&](auto ii) ABRK_LAMBDA {
+      constexpr int i = j() + 1 + ii();
+      T acc = T(0);
+      sfor<i - j()>([&](auto kk) ABRK_LAMBDA {
+        constexpr int k = j() + kk();
+        acc -= L[tri(i, k)] * Li[tri(k, j())];
+      });
+      Li[tri(i, j())] = acc * il[i];
+    });
+  });
+  sfor<K>([&](auto i) ABRK_LAMBDA {
+    sfor<i() + 1>([&](auto j) ABRK_LAMBDA {
+      T acc = T(0);
+      sfor<K - i()>([&](auto kk) ABRK_LAMBDA {
+        constexpr int k = i() + kk();
+        acc += Li[tri(k, i())] * Li[tri(k, j())];
+      });
+      Sinv[tri(i(), j())] = acc;
+    });
+  });
+}
+
+// Cyclic two-sided Jacobi eigen-decomposition of a symmetric K x K matrix (packed lower
+// in, destroyed).  V columns = eigenvectors, lam = eigenvalues.  Stands in for the SVD
+// inside numpy.linalg.pinv(Mx_inv) (osc.py:145) - for a symmetric matrix |eigenvalues|
+// are the singular values.
+template <int K, class T>
+ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
+  sfor<K>([&](auto i) ABRK_LAMBDA { sfor<K>([&](auto j) ABRK_LAMBDA { V[i()][j()] = (i() == j()) ? T(1) : T(0); }); });
+  for (int sweep = 0; sweep < 30; sweep++) {
+    T off = T(0), dg = T(0);
+    sfor<K>([&](auto p) ABRK_LAMBDA {
+      dg += S[tri(p(), p())] * S[tri(p(), p())];
+      sfor<p()>([&](auto q) ABRK_LAMBDA { off += S[tri(p(), q())] * S[tri(p(), q())]; });
+    });
+    if (!(off > Rm<T>::eps() * Rm<T>::eps() * T(1e-4) * dg)) break;
+    sfor<K>([&](auto qq) ABRK_LAMBDA {
+      sfor<qq()>([&](auto pp) ABRK_LAMBDA {
+        constexpr int p = pp(), q = qq();  // p < q
+        T apq = S[tri(q, p)];
+        if (apq != T(0)) {
+          T theta = (S[tri(q, q)] - S[tri(p, p)]) / (T(2) * apq);
+          T t = (theta >= T(0) ? T(1) : T(-1)) / (Rm<T>::fabs(theta) + Rm<T>::sqrt(theta * theta + T(1)));
+          T c = rcp(Rm<T>::sqrt(t * t + T(1)));
+          T s = t * c;
+          sfor<K>([&](auto k) ABRK_LAMBDA {
+            if constexpr (k() != p && k() != q) {
+              T skp = S[tri(k(), p)], skq = S[tri(k(), q)];
+              S[tri(k(), p)] = c * skp - s * skq;
+              S[tri(k(), q)] = s * skp + c * skq;
+            }
+          });
+          S[tri(p, p)] -= t * apq;
+          S[tri(q, q)] += t * apq;
+          S[tri(q, p)] = T(0);
+          sfor<K>([&](auto k) ABRK_LAMBDA {
+            T vkp = V[k()][p], vkq = V[k()][q];
+            V[k()][p] = c * vkp - s * vkq;
+            V[k()][q] = s * vkp + c * vkq;
+          });
+        }
+      });
+    });
+  }
+  sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = S[tri(i(), i())]; });
+}
+
+// One-sided (Hestenes) Jacobi: orthogonalise the 3 columns G[:,0..2] (length N each),
+// accumulating the rotations in V (3x3).  Afterwards G = U diag(sig), so for J = G^T:
+//   pinv(J)[i][r] = sum_{sig_j > cutoff} G[i][j] V[r][j] / sig_j^2        (sliding.py:72)
+template <int N, class T>
+ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P)[N][3] /* P[i][r] */) {
+  T G[N][3];
+  T V[3][3];
+  sfor<N>([&](auto i) ABRK_LAMBDA { sfor<3>([&](auto r) ABRK_LAMBDA { G[i()][r()] = J[i()][r()]; }); });
+  sfor<3>([&](auto a) ABRK_LAMBDA { sfor<3>([&](auto b) ABRK_LAMBDA { V[a()][b()] = (a() == b()) ? T(1) : T(0); }); });
+  for (int sweep = 0; sweep < 30; sweep++) {
+    T worst = T(0);
+    sfor<3>([&](auto qq) ABRK_LAMBDA {
+      sfor<qq()>([&](auto pp) ABRK_LAMBDA {
+        constexpr int p = pp(), q = qq();
+        T alpha = T(0), beta = T(0), gamma = T(0);
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          alpha += G[i()][p] * G[i()][p];
+          beta += G[i()][q] * G[i()][q];
+          gamma += G[i()][p] * G[i()][q];
+        });
+        T lim = Rm<T>::sqrt(alpha * beta);
+        if (Rm<T>::fabs(gamma) > Rm<T>::eps() * lim && Rm<T>::fabs(gamma) > Rm<T>::tiny()) {
+          worst = Rm<T>::fmax(worst, Rm<T>::fabs(gamma) / lim);
+          T zeta = (beta - alpha) / (T(2) * gamma);
+          T t = (zeta >= T(0) ? T(1) : T(-1)) / (Rm<T>::fabs(zeta) + Rm<T>::sqrt(T(1) + zeta * zeta));
+          T c = rcp(Rm<T>::sqrt(T(1) + t * t));
+          T s = c * t;
+          sfor<N>([&](auto i) ABRK_LAMBDA {
+            T gp = G[i()][p], gq = G[i()][q];
+            G[i()][p] = c * gp - s * gq;
+            G[i()][q] = s * gp + c * gq;
+          });
+          sfor<3>([&](auto a) ABRK_LAMBDA {
+            T vp = V[a()][p], vq = V[a()][q];
+            V[a()][p] = c * vp - s * vq;
+            V[a()][q] = s * vp + c * vq;
+          });
+        }
+      });
+    });
+    if (!(worst > T(0))) break;
+  }
+  T sig2[3], smax2 = T(0);
+  sfor<3>([&](auto j) ABRK_LAMBDA {
+    T acc = T(0);
+    sfor<N>([&](auto i) ABRK_LAMBDA { acc += G[i()][j()] * G[i()][j()]; });
+    sig2[j()] = acc;
+    smax2 = Rm<T>::fmax(smax2, acc);
+  });
+  T w[3];
+  T cut = rcond * Rm<T>::sqrt(smax2);
+  sfor<3>([&](auto j) ABRK_LAMBDA { w[j()] = (Rm<T>::sqrt(sig2[j()]) > cut) ? rcp(sig2[j()]) : T(0); });
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      T acc = T(0);
+      sfor<3>([&](auto j) ABRK_LAMBDA { acc += G[i()][j()] * V[r()][j()] * w[j()]; });
+      P[i()][r()] = acc;
+    });
+  });
+}
+
+// ---------------------------------------------------------------- quaternions (utils/transformations.py)
+// quaternion_from_matrix(isprecise=False) (transformations.py:1192-1271): dominant
+// eigenvector of the symmetric 4x4 K/3 built from R.  For a (near-)rotation K/3 has
+// eigenvalues {1, -1/3, -1/3, -1/3}, so B = K/3 + I/3 is rank one up to the
+// non-orthogonality of R and three power steps from its heaviest column converge to
+// rounding (error ratio^3 with ratio ~ |R^T R - I|).  Returns unit (w,x,y,z), w >= 0
+// (sign rule transformations.py:1269; unit_vector base_config.py:315).
+template <class T>
+ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
+  const T m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7],
+          m22 = R[8];
+  const T th = T(1) / T(3);
+  T Bm[4][4];
+  Bm[0][0] = (m00 - m11 - m22) * th + th;
+  Bm[1][1] = (m11 - m00 - m22) * th + th;
+  Bm[2][2] = (m22 - m00 - m11) * th + th;
+  Bm[3][3] = (m00 + m11 + m22) * th + th;
+  Bm[1][0] = Bm[0][1] = (m01 + m10) * th;
+  Bm[2][0] = Bm[0][2] = (m02 + m20) * th;
+  Bm[2][1] = Bm[1][2] = (m12 + m21) * th;
+  Bm[3][0] = Bm[0][3] = (m21 - m12) * th;
+  Bm[3][1] = Bm[1][3] = (m02 - m20) * th;
+  Bm[3][2] = Bm[2][3] = (m10 - m01) * th;
+  // heaviest diagonal -> start vector = that column
+  int best = 0;
+  T bd = Bm[0][0];
+  sfor<3>([&](auto jj) ABRK_LAMBDA {
+    constexpr int j = jj() + 1;
+    bool gt = Bm[j][j] > bd;
+    best = gt ? j : best;
+    bd = gt ? Bm[j][j] : bd;
+  });
+  T v[4];
+  sfor<4>([&](auto i) ABRK_LAMBDA {
+    v[i()] = best == 0 ? Bm[i()][0] : best == 1 ? Bm[i()][1] : best == 2 ? Bm[i()][2] : Bm[i()][3];
+  });
+  sfor<3>([&](auto it) ABRK_LAMBDA {
+    T nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    T inv = rcp(Rm<T>::sqrt(nn));
+    T w[4];
+    sfor<4>([&](auto i) ABRK_LAMBDA {
+      w[i()] = (Bm[i()][0] * v[0] + Bm[i()][1] * v[1] + Bm[i()][2] * v[2] + Bm[i()][3] * v[3]) * inv;
+    });
+    sfor<4>([&](auto i) ABRK_LAMBDA { v[i()] = w[i()]; });
+  });
+  T nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  T inv = rcp(Rm<T>::sqrt(nn));
+  T sg = (v[3] < T(0)) ? -inv : inv;
+  qo[0] = v[3] * sg;
+  qo[1] = v[0] * sg;
+  qo[2] = v[1] * sg;
+  qo[3] = v[2] * sg;
+}
+
+// quaternion_from_euler(ai, aj, ak, 'rxyz') (transformations.py:1096-1150), then unit_vector
+template <class T>
+ABRK_INL void quat_from_euler_rxyz(T ai, T aj, T ak, T (&q)[4]) {
+  // axes 'rxyz' -> (firstaxis, parity, repetition, frame) = (2, 1, 0, 1): i=3, j=2, k=1
+  T t = ai;
+  ai = ak;
+  ak = t;
+  aj = -aj;
+  T si, ci, sj, cj, sk, ck;
+  Rm<T>::sincos(ai / T(2), si, ci);
+  Rm<T>::sincos(aj / T(2), sj, cj);
+  Rm<T>::sincos(ak / T(2), sk, ck);
+  T cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  q[0] = cj * cc + sj * ss;
+  q[3] = cj * sc - sj * cs;
+  q[2] = -(cj * ss + sj * cc);
+  q[1] = cj * cs - sj * sc;
+  T inv = rcp(Rm<T>::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+  sfor<4>([&](auto i) ABRK_LAMBDA { q[i()] *= inv; });
+}
+
+// euler_matrix(ai, aj, ak, 'rxyz')[:3,:3] (transformations.py:973-1032)
+template <class T>
+ABRK_INL void euler_matrix_rxyz(T ai, T aj, T ak, T (&M)[9]) {
+  // (2,1,0,1): i=2, j=1, k=0; swap ai/ak; negate all
+  T t = ai;
+  ai = -ak;
+  ak = -t;
+  aj = -aj;
+  T si, ci, sj, cj, sk, ck;
+  Rm<T>::sincos(ai, si, ci);
+  Rm<T>::sincos(aj, sj, cj);
+  Rm<T>::sincos(ak, sk, ck);
+  T cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  constexpr int i = 2, j = 1, k = 0;
+  M[i * 3 + i] = cj * ck;
+  M[i * 3 + j] = sj * sc - cs;
+  M[i * 3 + k] = sj * cc + ss;
+  M[j * 3 + i] = cj * sk;
+  M[j * 3 + j] = sj * ss + cc;
+  M[j * 3 + k] = sj * cs - sc;
+  M[k * 3 + i] = -sj;
+  M[k * 3 + j] = cj * si;
+  M[k * 3 + k] = cj * ci;
+}
+
+// quaternion_multiply(q1, q0) (transformations.py:1274-1290)
+template <class T>
+ABRK_INL void quat_mul(const T (&q1)[4], const T (&q0)[4], T (&r)[4]) {
+  T w0 = q0[0], x0 = q0[1], y0 = q0[2], z0 = q0[3];
+  T w1 = q1[0], x1 = q1[1], y1 = q1[2], z1 = q1[3];
+  r[0] = -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0;
+  r[1] = x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0;
+  r[2] = -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0;
+  r[3] = x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0;
+}
+
+// _calc_orientation_forces (osc.py:149-196)
+template <class T>
+ABRK_INL void orientation_forces(int alg, const T (&Re)[9], const T (&abg)[3], T (&uo)[3]) {
+  if (alg == 0) {
+    T qd[4], qe[4], qec[4], qr[4];
+    quat_from_euler_rxyz(abg[0], abg[1], abg[2], qd);
+    quat_from_R(Re, qe);
+    qec[0] = qe[0];
+    qec[1] = -qe[1];
+    qec[2] = -qe[2];
+    qec[3] = -qe[3];
+    quat_mul(qd, qec, qr);
+    T sg = qr[0] > T(0) ? T(1) : (qr[0] < T(0) ? T(-1) : T(0));
+    sfor<3>([&](auto r) ABRK_LAMBDA { uo[r()] = -qr[1 + r()] * sg; });
+  } else {
+    T Rd[9], Red[9], qed[4];
+    euler_matrix_rxyz(abg[0], abg[1], abg[2], Rd);
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      sfor<3>([&](auto c) ABRK_LAMBDA {
+        Red[r() * 3 + c()] = Re[0 * 3 + r()] * Rd[0 * 3 + c()] + Re[1 * 3 + r()] * Rd[1 * 3 + c()] +
+                             Re[2 * 3 + r()] * Rd[2 * 3 + c()];
+      });
+    });
+    quat_from_R(Red, qed);
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      uo[r()] = -(Re[r() * 3 + 0] * qed[1] + Re[r() * 3 + 1] * qed[2] + Re[r() * 3 + 2] * qed[3]);
+    });
+  }
+}
+
+// Python float modulo: result takes the sign of the (positive) divisor
+template <class T>
+ABRK_INL T pymod_pos(T a, T b) {
+  T r = Rm<T>::fmod(a, b);
+  return (r < T(0)) ? r + b : r;
+}
+
+// joint-space command of a secondary controller: u_null = M v   (damping.py:31-32,
+// resting_config.py:25-42 + joint.py:42-46,118-123)
+template <int N, class T>
+ABRK_INL void null_command(const NullP<T>& c, const T (&q)[N], const T (&dq)[N], T (&v)[N]) {
+  const T pi = T(3.141592653589793238462643383279502884);
+  if (c.kind == 1) {
+    sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] += -c.kv * dq[i()]; });
+  } else {
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      T qt = c.mask[i()] ? pymod_pos(c.rest[i()] - q[i()] + pi, pi * T(2)) - pi : T(0);
+      v[i()] += c.kp * qt + c.kv * (T(0) - dq[i()]);
+    });
+  }
+}
+
+// ---------------------------------------------------------------- OSC.generate, one row
+// KM = 3 (FAST: task rows are exactly x,y,z of the EE) or 6 (all six task rows, unselected
+// rows masked: their Jacobian row is zeroed and Mx_inv gets a unit diagonal there, which
+// leaves det, the inverse and the singular values of the selected block unchanged).
+template <class A, class T, int KM, bool USE_C>
+ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
+                      bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
+                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N]) {
+  constexpr int N = A::N;
+  constexpr bool FAST = (KM == 3);
+  Joints<A, T> jt;
+  Dyn<A, T, USE_C ? CMODE_VEC : CMODE_NONE> d;
+  T XR[9], xo[3];
+  T p[3], RF[9];
+  int m = N;
+  if constexpr (FAST) {
+    NoCap nc;
+    kin_dyn(arm, q, dq, jt, d, XR, xo, nc);
+    if (P.has_off) {
+      T oe[3];
+      mulBE<A, T>(arm, XR, xo, RF, oe);
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        p[r()] = oe[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
+      });
+    } else {
+      mulBE_pt<A, T>(arm, XR, xo, p);
+    }
+  } else {
+    FrameCap<T> cap;
+    cap.frame = P.ref_frame;
+    sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = T(0); });
+    sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = T(0); });
+    kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
+    sfor<9>([&](auto e) ABRK_LAMBDA { RF[e()] = cap.R[e()]; });
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      p[r()] = cap.o[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
+    });
+    m = P.m_joints;
+  }
+  // task Jacobian, rows masked (osc.py:242-244)
+  T Jv[N][3], Jw[N][3];
+  jacobian(jt, p, m, Jv, Jw);
+  T Jr[N][KM];
+  bool sel[KM];
+  sfor<KM>([&](auto r) ABRK_LAMBDA {
+    sel[r()] = FAST ? true : (P.dof[r()] != 0);
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      T val = (r() < 3) ? Jv[i()][r() % 3] : Jw[i()][r() % 3];
+      Jr[i()][r()] = sel[r()] ? val : T(0);
+    });
+  });
+
+  // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T through the Cholesky factor of M
+  T L[N * (N + 1) / 2], il[N];
+  chol<N>(d.Ms, L, il);
+  T Y[N][KM];
+  sfor<KM>([&](auto r) ABRK_LAMBDA {
+    T b[N], x[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { b[i()] = Jr[i()][r()]; });
+    chol_fwd<N>(L, il, b, x);
+    sfor<N>([&](auto i) ABRK_LAMBDA { Y[i()][r()] = x[i()]; });
+  });
+  T Am[KM * (KM + 1) / 2];
+  T trace = T(0);
+  sfor<KM>([&](auto r) ABRK_LAMBDA {
+    sfor<r() + 1>([&](auto c) ABRK_LAMBDA {
+      T acc = T(0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { acc += Y[i()][r()] * Y[i()][c()]; });
+      Am[tri(r(), c())] = acc;
+    });
+    trace += sel[r()] ? Am[tri(r(), r())] : T(0);
+    if (!sel[r()]) Am[tri(r(), r())] = T(1);
+  });
+  T LA[KM * (KM + 1) / 2], ila[KM], Mx[KM * (KM + 1) / 2];
+  bool okA = chol<KM>(Am, LA, ila);
+  T det = T(1);
+  sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
+  chol_inverse<KM>(LA, ila, Mx);
+  const T thr = T(1e-3), rcond = T(1e-3) * T(0.1);
+  if (!(okA && det >= thr)) {
+    // pinv branch (osc.py:142-145).  pinv == inv unless some singular value is below
+    // rcond*max; det >= rcond*trace^K proves none is (lam_min >= det/lam_max^(K-1)).
+    T bound = rcond;
+    sfor<KM>([&](auto r) ABRK_LAMBDA { bound *= sel[r()] ? trace : T(1); });
+    if (!(okA && det > bound)) {
+      T S[KM * (KM + 1) / 2], V[KM][KM], lam[KM];
+      sfor<KM*(KM + 1) / 2>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
+      jacobi_eig<KM>(S, V, lam);
+      T smax = T(0);
+      sfor<KM>([&](auto r) ABRK_LAMBDA {
+        // a masked row r is an isolated unit diagonal: Jacobi never rotates it, so eigenpair r
+        // stays (1, e_r) and belongs to no controlled DOF - drop it
+        bool mine = sel[r()];
+        lam[r()] = mine ? lam[r()] : T(0);
+        smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()]));
+      });
+      T cut = rcond * smax;
+      T wv[KM];
+      sfor<KM>([&](auto r) ABRK_LAMBDA { wv[r()] = (Rm<T>::fabs(lam[r()]) > cut) ? rcp(lam[r()]) : T(0); });
+      sfor<KM>([&](auto a) ABRK_LAMBDA {
+        sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
+          T acc = T(0);
+          sfor<KM>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
+          Mx[tri(a(), b())] = acc;
+        });
+      });
+    }
+  }
+
+  // desired task-space forces (osc.py:250-259)
+  T ut[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  if (FAST || P.pos_on) sfor<3>([&](auto r) ABRK_LAMBDA { ut[r()] = p[r()] - tgt[r()]; });
+  if constexpr (!FAST) {
+    if (P.ori_on) {
+      T abg[3] = {tgt[3], tgt[4], tgt[5]}, uo[3];
+      orientation_forces(P.alg, RF, abg, uo);
+      sfor<3>([&](auto r) ABRK_LAMBDA { ut[3 + r()] = uo[r()]; });
+    }
+  }
+  // integral term (osc.py:262-264)
+  if (have_ierr) {
+    sfor<6>([&](auto r) ABRK_LAMBDA {
+      ierr[r()] += ut[r()];
+      ut[r()] += P.ki * ierr[r()];
+    });
+  }
+  // gains / velocity limiting (osc.py:266-272, 198-215; constants osc.py:89-115)
+  if (P.use_vmax) {
+    T sat_xyz = P.vmax0 / P.kp * P.kv, sat_abg = P.vmax1 / P.ko * P.kv;
+    T nx = Rm<T>::sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
+    T na = Rm<T>::sqrt(ut[3] * ut[3] + ut[4] * ut[4] + ut[5] * ut[5]);
+    T sx = (nx > sat_xyz) ? sat_xyz / nx : T(1);
+    T sa = (na > sat_abg) ? sat_abg / na : T(1);
+    T lx = P.kp / P.kv, la = P.ko / P.kv;
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      ut[r()] = P.kv * sx * lx * ut[r()];
+      ut[3 + r()] = P.kv * sa * la * ut[3 + r()];
+    });
+  } else {
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      ut[r()] *= P.kp;
+      ut[3 + r()] *= P.ko;
+    });
+  }
+  // velocity compensation (osc.py:274-282)
+  bool tv_zero = true;
+  if (tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
+  T Mdq[N];
+  symv<N>(d.Ms, dq, Mdq);
+  if (tv_zero) {
+    sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(-1) * P.kv * Mdq[i()]; });
+  } else {
+    sfor<6>([&](auto r) ABRK_LAMBDA {
+      T dx = T(0);
+      if constexpr (r() < KM) {
+        sfor<N>([&](auto i) ABRK_LAMBDA { dx += Jr[i()][r()] * dq[i()]; });
+      }
+      ut[r()] += P.kv * (dx - tvin[r()]);
+    });
+    sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(0); });
+  }
+  // u -= J^T (Mx u_task[ctrlr_dof]) (osc.py:285-288)
+  T uts[KM], f[KM];
+  sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
+  symv<KM>(Mx, uts, f);
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    T acc = T(0);
+    sfor<KM>([&](auto r) ABRK_LAMBDA { acc += Jr[i()][r()] * f[r()]; });
+    u[i()] -= acc;
+  });
+  if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= d.cv[i()]; });  // osc.py:291-292
+  sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297
+  if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += T(9.81) * d.gz[i()]; }); // osc.py:300-301
+
+  // secondary controllers through the null-space filter I - J^T Jbar^T (osc.py:310-318).
+  // With u_null = M v the filtered signal is M v - J^T Mx (J v) (Jbar^T M = Mx J).
+  if (P.n_null > 0 || have_ext) {
+    T v[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = T(0); });
+    for (int c = 0; c < P.n_null; c++) null_command<N>(P.nul[c], q, dq, v);
+    T un[N];
+    symv<N>(d.Ms, v, un);
+    if (have_ext) {
+      // caller-evaluated u_null: v_ext = M^-1 u_ext
+      T y[N], w[N];
+      chol_fwd<N>(L, il, une, y);
+      chol_bwd<N>(L, il, y, w);
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        v[i()] += w[i()];
+        un[i()] += une[i()];
+      });
+    }
+    T jv[KM], f2[KM];
+    sfor<KM>([&](auto r) ABRK_LAMBDA {
+      T acc = T(0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { acc += Jr[i()][r()] * v[i()]; });
+      jv[r()] = acc;
+    });
+    symv<KM>(Mx, jv, f2);
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      T acc = T(0);
+      sfor<KM>([&](auto r) ABRK_LAMBDA { acc += Jr[i()][r()] * f2[r()]; });
+      u[i()] += un[i()] - acc;
+    });
+  }
+}
+
+// ---------------------------------------------------------------- Sliding.generate, one row (sliding.py:34-99)
+template <class A, class T>
+ABRK_INL void sliding_row(const A& arm, const SlidingP<T>& P, const T (&q)[A::N], const T (&dq)[A::N],
+                          const T (&tgt)[A::N > 3 ? A::N : 3], const T (&tv)[A::N > 3 ? A::N : 3],
+                          const T (&ta)[A::N > 3 ? A::N : 3], T (&u)[A::N], T (&s)[A::N]) {
+  constexpr int N = A::N;
+  Joints<A, T> jt;
+  Dyn<A, T, CMODE_MAT> d;
+  T XR[9], xo[3];
+  FrameCap<T> cap;
+  cap.frame = P.ref_frame;
+  sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = T(0); });
+  sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = T(0); });
+  kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
+  T dq_ref[N], ddq_ref[N];
+  if (P.cartesian) {
+    T p[3];
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      p[r()] = cap.o[r()] + cap.R[r() * 3] * P.off[0] + cap.R[r() * 3 + 1] * P.off[1] + cap.R[r() * 3 + 2] * P.off[2];
+    });
+    T Jv[N][3], Jw[N][3], dJv[N][3], dJw[N][3], Ji[N][3];
+    jacobian(jt, p, P.m_joints, Jv, Jw);
+    jacobian_dot(jt, dq, Jv, P.m_joints, dJv, dJw);
+    pinv_3xN<N>(Jv, T(1e-15), Ji);
+    T dx[3], a[3], w[3];
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      T acc = T(0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { acc += Jv[i()][r()] * dq[i()]; });
+      dx[r()] = acc;
+      a[r()] = tv[r()] + P.lamb * (tgt[r()] - p[r()]);
+    });
+    sfor<N>([&](auto i) ABRK_LAMBDA { dq_ref[i()] = Ji[i()][0] * a[0] + Ji[i()][1] * a[1] + Ji[i()][2] * a[2]; });
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      T acc = T(0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { acc += dJv[i()][r()] * dq_ref[i()]; });
+      w[r()] = ta[r()] + P.lamb * (tv[r()] - dx[r()]) - acc;
+    });
+    sfor<N>([&](auto i) ABRK_LAMBDA { ddq_ref[i()] = Ji[i()][0] * w[0] + Ji[i()][1] * w[1] + Ji[i()][2] * w[2]; });
+  } else {
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      dq_ref[i()] = tv[i()] - P.lamb * (q[i()] - tgt[i()]);
+      ddq_ref[i()] = ta[i()] - P.lamb * (dq[i()] - tv[i()]);
+    });
+  }
+  T a1[N];
+  symv<N>(d.Ms, ddq_ref, a1);
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    s[i()] = dq[i()] - dq_ref[i()];
+    T a2 = T(0);
+    sfor<N>([&](auto j) ABRK_LAMBDA { a2 += d.Cm[i() * N + j()] * dq_ref[j()]; });
+    u[i()] = a1[i()] + a2 + T(-9.81) * d.gz[i()] - P.kd * s[i()];
+  });
+}
+
+// ---------------------------------------------------------------- Joint / Damping / RestingConfig, one row
+template <class A, class T>
+ABRK_INL void joint_row(const A& arm, const JointP<T>& P, const T (&q)[A::N], const T (&dq)[A::N],
+                        const T (&tgt)[A::N], const T (&tv)[A::N], T (&u)[A::N]) {
+  constexpr int N = A::N;
+  const T pi = T(3.141592653589793238462643383279502884);
+  Joints<A, T> jt;
+  Dyn<A, T, CMODE_NONE> d;
+  T XR[9], xo[3];
+  NoCap nc;
+  kin_dyn(arm, q, dq, jt, d, XR, xo, nc);
+  T v[N];
+  sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = T(0); });
+  if (P.c.kind != 0) {
+    null_command<N>(P.c, q, dq, v);
+  } else {
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      T qt = pymod_pos(tgt[i()] - q[i()] + pi, pi * T(2)) - pi;
+      v[i()] = P.c.kp * qt + P.c.kv * (tv[i()] - dq[i()]);
+    });
+  }
+  symv<N>(d.Ms, v, u);
+  if (P.c.kind == 0 && P.account_for_gravity) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += T(9.81) * d.gz[i()]; });
+}
+
+}  // namespace abrk

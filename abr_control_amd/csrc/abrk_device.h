@@ -1,0 +1,639 @@
+// abrk_device.h - per-row device arithmetic of the batched arm engine (gfx950 / CDNA4).
+//
+// One lane evaluates one arm instance ("row" of the batch) entirely in registers: the
+// work per row is a short serial chain (forward kinematics over <= 7 joints) followed by
+// small fixed-size dense algebra, so rows map to lanes and a 64-wide wavefront advances
+// 64 independent arms in lock-step with no cross-lane traffic and no divergence on the
+// main path.  All loops are unrolled at compile time (`sfor`) so every small array lives
+// in VGPRs, and for the built-in arms every static frame transform is a compile-time
+// constant whose 0 / +-1 entries are folded away (`cfma`).
+//
+// What is computed follows abr_control/arms/base_config.py (reference file:line cited at
+// each function) but NOT how: the reference differentiates symbolic expressions; here the
+// affine joint chain is differentiated in closed form:
+//   for a point p rigidly attached after joints 0..m-1, with P_i / o_i the linear part /
+//   origin of T(joint_i) and  W_i = P_i Zhat P_i^-1  (= [z_i]x when P_i is orthogonal):
+//       dp/dq_i            = W_i (p - o_i)                      (i < m)
+//       d2p/dq_i dq_k      = W_min(i,k) W_max(i,k) (p - o_max)  (i,k < m)
+//       dz_i/dq_k          = W_k z_i                            (k < i),  z_i = P_i e_z
+//   exact for ANY affine static transforms (Jaco2's constants are not orthogonal).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "abrk_arms_builtin.h"
+
+#ifndef ABRK_HD
+#define ABRK_HD __device__
+#endif
+#define ABRK_INL ABRK_HD __forceinline__
+#define ABRK_LAMBDA __attribute__((always_inline))
+
+namespace abrk {
+
+// ---------------------------------------------------------------- compile-time loops
+template <int I>
+using ic = std::integral_constant<int, I>;
+
+template <class F, int... Is>
+ABRK_INL void sfor_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(ic<Is>{}), ...);
+}
+// sfor<N>(f): f(ic<0>), ..., f(ic<N-1>) - indices are constant expressions inside f
+template <int N, class F>
+ABRK_INL void sfor(F&& f) {
+  sfor_impl(f, std::make_integer_sequence<int, (N > 0 ? N : 0)>{});
+}
+
+// ---------------------------------------------------------------- scalar math per type
+template <class T>
+struct Rm;
+template <>
+struct Rm<double> {
+  static ABRK_INL void sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+  static ABRK_INL double sqrt(double x) { return ::sqrt(x); }
+  static ABRK_INL double fabs(double x) { return ::fabs(x); }
+  static ABRK_INL double fma(double a, double b, double c) { return ::fma(a, b, c); }
+  static ABRK_INL double fmod(double a, double b) { return ::fmod(a, b); }
+  static ABRK_INL double fmax(double a, double b) { return ::fmax(a, b); }
+  static constexpr double eps() { return 2.220446049250313e-16; }
+  static constexpr double tiny() { return 1e-300; }
+};
+template <>
+struct Rm<float> {
+  static ABRK_INL void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+  static ABRK_INL float sqrt(float x) { return ::sqrtf(x); }
+  static ABRK_INL float fabs(float x) { return ::fabsf(x); }
+  static ABRK_INL float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
+  static ABRK_INL float fmod(float a, float b) { return ::fmodf(a, b); }
+  static ABRK_INL float fmax(float a, float b) { return ::fmaxf(a, b); }
+  static constexpr float eps() { return 1.1920929e-07f; }
+  static constexpr float tiny() { return 1e-37f; }
+};
+
+// ---------------------------------------------------------------- 3-vectors
+template <class T>
+ABRK_INL void cross3(const T (&a)[3], const T (&b)[3], T (&o)[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1];
+  o[1] = a[2] * b[0] - a[0] * b[2];
+  o[2] = a[0] * b[1] - a[1] * b[0];
+}
+template <class T>
+ABRK_INL T dot3(const T (&a)[3], const T (&b)[3]) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+template <class T>
+ABRK_INL void matvec3(const T (&M)[9], const T (&v)[3], T (&o)[3]) {
+  o[0] = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  o[1] = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  o[2] = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+}
+
+// ---------------------------------------------------------------- arm policies
+// constexpr 3x4 affine product element: (X*Y)[e], e = r*4+c
+constexpr double aff_mul(const double* X, const double* Y, int e) {
+  int r = e / 4, c = e % 4;
+  double s = 0.0;
+  for (int k = 0; k < 3; k++) s += X[r * 4 + k] * Y[k * 4 + c];
+  if (c == 3) s += X[r * 4 + 3];
+  return s;
+}
+constexpr bool aff_is_orthogonal(const double* X) {
+  for (int a = 0; a < 3; a++)
+    for (int b = 0; b < 3; b++) {
+      double s = 0.0;
+      for (int k = 0; k < 3; k++) s += X[k * 4 + a] * X[k * 4 + b];
+      if (s != (a == b ? 1.0 : 0.0)) return false;
+    }
+  return true;
+}
+
+// Built-in arm: every constant is a constant expression.  Derived static transforms:
+//   J0   = A0 * AJ[0]                joint_0 frame (independent of q)
+//   S[i] = B[i] * AJ[i+1]            joint_i (after Rz(q_i)) -> joint_{i+1}
+//   B[i]                             joint_i (after Rz(q_i)) -> link_{i+1}  (COM frame)
+//   BE   = B[N-1] * E                joint_{N-1} (after Rz) -> EE
+template <class Tab>
+struct StaticArm {
+  static constexpr int N = Tab::N;
+  static constexpr int NL = Tab::NL;
+  static constexpr bool kStatic = true;
+  static constexpr bool kHasEE = Tab::kHasEE;
+  static constexpr double J0(int e) { return aff_mul(Tab::A0, Tab::AJ[0], e); }
+  static constexpr double S(int i, int e) { return aff_mul(Tab::B[i], Tab::AJ[i + 1 < N ? i + 1 : i], e); }
+  static constexpr double Bm(int i, int e) { return Tab::B[i][e]; }
+  static constexpr double BE(int e) { return kHasEE ? aff_mul(Tab::B[N - 1], Tab::E, e) : Tab::B[N - 1][e]; }
+  static constexpr double A0m(int e) { return Tab::A0[e]; }
+  static constexpr double MD(int l, int r) { return Tab::MD[l][r]; }
+  // angular inertia seen by joint pair with max index m: sum of links l > m (l < NL)
+  static constexpr double Isuf(int m, int r) {
+    double s = 0.0;
+    for (int l = m + 1; l < NL && l <= N; l++) s += Tab::MD[l][3 + r];
+    return s;
+  }
+  static constexpr bool compute_ortho() {
+    if (!aff_is_orthogonal(Tab::A0)) return false;
+    for (int i = 0; i < N; i++)
+      if (!aff_is_orthogonal(Tab::AJ[i]) || !aff_is_orthogonal(Tab::B[i])) return false;
+    return true;
+  }
+  static constexpr bool kOrtho = compute_ortho();
+};
+
+// User arm: same derived tables, filled on the host (abrk_host.cpp) in the kernel's
+// arithmetic type and passed by value as a kernel argument (scalar loads, SGPR operands).
+template <int NJ, class T>
+struct RtArm {
+  static constexpr int N = NJ;
+  static constexpr bool kStatic = false;
+  static constexpr bool kOrtho = false;  // always differentiate the general affine chain
+  int NL;
+  T J0v[12];
+  T Sv[NJ][12];
+  T Bv[NJ][12];
+  T BEv[12];
+  T A0v[12];
+  T MDv[NJ + 1][6];
+  T Isufv[NJ + 1][3];
+};
+
+// Accessors: value of a table element as type T (constant expression for static arms).
+#define ABRK_ACC(NAME, STATIC_EXPR, RT_EXPR)                                 \
+  template <class A, class T, int... Ix>                                     \
+  struct NAME {                                                              \
+    static ABRK_INL T get(const A& a) {                                      \
+      if constexpr (A::kStatic) {                                            \
+        constexpr double v = STATIC_EXPR;                                    \
+        return T(v);                                                         \
+      } else {                                                               \
+        return RT_EXPR;                                                      \
+      }                                                                      \
+    }                                                                        \
+    static constexpr double cv() {                                           \
+      if constexpr (A::kStatic) return STATIC_EXPR;                          \
+      else return 0.5; /* "not a foldable constant" */                       \
+    }                                                                        \
+  };
+
+template <int... Ix>
+struct idx_pack {
+  static constexpr int v[sizeof...(Ix) > 0 ? sizeof...(Ix) : 1] = {Ix...};
+};
+
+ABRK_ACC(AccJ0, A::J0(idx_pack<Ix...>::v[0]), a.J0v[idx_pack<Ix...>::v[0]])
+ABRK_ACC(AccS, A::S(idx_pack<Ix...>::v[0], idx_pack<Ix...>::v[1]), a.Sv[idx_pack<Ix...>::v[0]][idx_pack<Ix...>::v[1]])
+ABRK_ACC(AccB, A::Bm(idx_pack<Ix...>::v[0], idx_pack<Ix...>::v[1]), a.Bv[idx_pack<Ix...>::v[0]][idx_pack<Ix...>::v[1]])
+ABRK_ACC(AccBE, A::BE(idx_pack<Ix...>::v[0]), a.BEv[idx_pack<Ix...>::v[0]])
+ABRK_ACC(AccA0, A::A0m(idx_pack<Ix...>::v[0]), a.A0v[idx_pack<Ix...>::v[0]])
+ABRK_ACC(AccMD, A::MD(idx_pack<Ix...>::v[0], idx_pack<Ix...>::v[1]), a.MDv[idx_pack<Ix...>::v[0]][idx_pack<Ix...>::v[1]])
+ABRK_ACC(AccIsuf, A::Isuf(idx_pack<Ix...>::v[0], idx_pack<Ix...>::v[1]), a.Isufv[idx_pack<Ix...>::v[0]][idx_pack<Ix...>::v[1]])
+
+// acc + coef*x with compile-time folding of coef in {0, 1, -1}.  Start accumulators at
+// -0.0 (additive identity that LLVM folds exactly under strict IEEE).
+template <class Acc, class A, class T>
+ABRK_INL T cfma(const A& a, T x, T acc) {
+  if constexpr (A::kStatic) {
+    constexpr double c = Acc::cv();
+    if constexpr (c == 0.0)
+      return acc;
+    else if constexpr (c == 1.0)
+      return acc + x;
+    else if constexpr (c == -1.0)
+      return acc - x;
+    else
+      return Rm<T>::fma(T(c), x, acc);
+  } else {
+    return Rm<T>::fma(Acc::get(a), x, acc);
+  }
+}
+// acc + coef (pure constant add, skipped when 0)
+template <class Acc, class A, class T>
+ABRK_INL T cadd(const A& a, T acc) {
+  if constexpr (A::kStatic) {
+    constexpr double c = Acc::cv();
+    if constexpr (c == 0.0)
+      return acc;
+    else
+      return acc + T(c);
+  } else {
+    return acc + Acc::get(a);
+  }
+}
+
+// (R, o) * static affine C  ->  (R2, o2);   C's elements come from accessor template AccT<A,T,...,e>
+#define ABRK_FRAME_MUL(FN, ACC)                                                              \
+  template <class A, class T, int... Pre>                                                    \
+  ABRK_INL void FN(const A& a, const T (&R)[9], const T (&o)[3], T (&R2)[9], T (&o2)[3]) {   \
+    sfor<3>([&](auto r) ABRK_LAMBDA {                                                        \
+      sfor<3>([&](auto c) ABRK_LAMBDA {                                                      \
+        T acc = T(-0.0);                                                                     \
+        sfor<3>([&](auto k) ABRK_LAMBDA {                                                    \
+          acc = cfma<ACC<A, T, Pre..., k() * 4 + c()>>(a, R[r() * 3 + k()], acc);            \
+        });                                                                                  \
+        R2[r() * 3 + c()] = acc;                                                             \
+      });                                                                                    \
+      T acc = o[r()];                                                                        \
+      sfor<3>([&](auto k) ABRK_LAMBDA {                                                      \
+        acc = cfma<ACC<A, T, Pre..., k() * 4 + 3>>(a, R[r() * 3 + k()], acc);                \
+      });                                                                                    \
+      o2[r()] = acc;                                                                         \
+    });                                                                                      \
+  }                                                                                          \
+  /* translation only: o2 = o + R * C_t */                                                   \
+  template <class A, class T, int... Pre>                                                    \
+  ABRK_INL void FN##_pt(const A& a, const T (&R)[9], const T (&o)[3], T (&o2)[3]) {          \
+    sfor<3>([&](auto r) ABRK_LAMBDA {                                                        \
+      T acc = o[r()];                                                                        \
+      sfor<3>([&](auto k) ABRK_LAMBDA {                                                      \
+        acc = cfma<ACC<A, T, Pre..., k() * 4 + 3>>(a, R[r() * 3 + k()], acc);                \
+      });                                                                                    \
+      o2[r()] = acc;                                                                         \
+    });                                                                                      \
+  }                                                                                          \
+  /* rotation only: R2 = R * C_R */                                                          \
+  template <class A, class T, int... Pre>                                                    \
+  ABRK_INL void FN##_rot(const A& a, const T (&R)[9], T (&R2)[9]) {                          \
+    sfor<3>([&](auto r) ABRK_LAMBDA {                                                        \
+      sfor<3>([&](auto c) ABRK_LAMBDA {                                                      \
+        T acc = T(-0.0);                                                                     \
+        sfor<3>([&](auto k) ABRK_LAMBDA {                                                    \
+          acc = cfma<ACC<A, T, Pre..., k() * 4 + c()>>(a, R[r() * 3 + k()], acc);            \
+        });                                                                                  \
+        R2[r() * 3 + c()] = acc;                                                             \
+      });                                                                                    \
+    });                                                                                      \
+  }
+
+ABRK_FRAME_MUL(mulS, AccS)
+ABRK_FRAME_MUL(mulB, AccB)
+ABRK_FRAME_MUL(mulBE, AccBE)
+
+// ---------------------------------------------------------------- per-row joint state
+template <class A, class T>
+struct Joints {
+  static constexpr int N = A::N;
+  T z[N][3];                      // z_i = P_i e_z            (J_orientation[i], base_config.py:565-580)
+  T o[N][3];                      // origin of T(joint_i)
+  T W[A::kOrtho ? 1 : N][9];      // W_i = P_i Zhat P_i^-1    (general affine chain only)
+};
+
+// out = W_I v
+template <int I, class A, class T>
+ABRK_INL void wapply(const Joints<A, T>& jt, const T (&v)[3], T (&out)[3]) {
+  if constexpr (A::kOrtho)
+    cross3(jt.z[I], v, out);
+  else
+    matvec3(jt.W[I], v, out);
+}
+
+// Optional capture of an arbitrary frame (runtime id, uniform across the wavefront).
+template <class T>
+struct FrameCap {
+  int frame;   // link_i -> 2i, joint_i -> 2i+1, EE -> 2N+1
+  T R[9];
+  T o[3];
+};
+struct NoCap {};
+
+// Forward kinematics over the joint chain (arms/*/config.py `_calc_T`, e.g.
+// ur5/config.py:301-339).  For i = 0..N-1: records joint_i (z, o, W), rotates by q_i,
+// calls on_link(ic<i+1>, p) with the COM position of link_{i+1}.  Leaves in (XR, xo) the
+// rotation of joint_{N-1} after its Rz and its origin - the EE hangs off that.
+template <class A, class T, class Cap, class LinkFn>
+ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (&XR)[9], T (&xo)[3],
+                         Cap& cap, LinkFn&& on_link) {
+  constexpr int N = A::N;
+  T Rj[9], oj[3];
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    sfor<3>([&](auto c) ABRK_LAMBDA { Rj[r() * 3 + c()] = AccJ0<A, T, r() * 4 + c()>::get(arm); });
+    oj[r()] = AccJ0<A, T, r() * 4 + 3>::get(arm);
+  });
+  if constexpr (!std::is_same<Cap, NoCap>::value) {
+    if (cap.frame == 0) {  // link0 = A0
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        sfor<3>([&](auto c) ABRK_LAMBDA { cap.R[r() * 3 + c()] = AccA0<A, T, r() * 4 + c()>::get(arm); });
+        cap.o[r()] = AccA0<A, T, r() * 4 + 3>::get(arm);
+      });
+    }
+  }
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    constexpr int I = i();
+    // ---- record joint_I
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      jt.z[I][r()] = Rj[r() * 3 + 2];
+      jt.o[I][r()] = oj[r()];
+    });
+    if constexpr (!A::kOrtho) {
+      // rows 0,1 of P^-1 via the dual basis: r0 = (c1 x c2)/det, r1 = (c2 x c0)/det
+      T c0[3] = {Rj[0], Rj[3], Rj[6]}, c1[3] = {Rj[1], Rj[4], Rj[7]}, c2[3] = {Rj[2], Rj[5], Rj[8]};
+      T r0[3], r1[3];
+      cross3(c1, c2, r0);
+      cross3(c2, c0, r1);
+      T idet = T(1) / dot3(c0, r0);
+      sfor<3>([&](auto a) ABRK_LAMBDA {
+        sfor<3>([&](auto b) ABRK_LAMBDA {
+          jt.W[I][a() * 3 + b()] = (c1[a()] * r0[b()] - c0[a()] * r1[b()]) * idet;
+        });
+      });
+    }
+    if constexpr (!std::is_same<Cap, NoCap>::value) {
+      if (cap.frame == 2 * I + 1) {
+        sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = Rj[e()]; });
+        sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = oj[r()]; });
+      }
+    }
+    // ---- rotate about local z by q_I:  X = joint_I * Rz(q_I)
+    T s, c;
+    Rm<T>::sincos(q[I], s, c);
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      T a0 = Rj[r() * 3 + 0], a1 = Rj[r() * 3 + 1];
+      XR[r() * 3 + 0] = c * a0 + s * a1;
+      XR[r() * 3 + 1] = c * a1 - s * a0;
+      XR[r() * 3 + 2] = Rj[r() * 3 + 2];
+    });
+    sfor<3>([&](auto r) ABRK_LAMBDA { xo[r()] = oj[r()]; });
+    // ---- COM of link_{I+1}
+    T p[3];
+    mulB_pt<A, T, I>(arm, XR, xo, p);
+    if constexpr (!std::is_same<Cap, NoCap>::value) {
+      if (cap.frame == 2 * (I + 1)) {
+        mulB_rot<A, T, I>(arm, XR, cap.R);
+        sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = p[r()]; });
+      }
+    }
+    on_link(ic<I + 1>{}, p);
+    // ---- next joint frame
+    if constexpr (I + 1 < N) {
+      T R2[9], o2[3];
+      mulS<A, T, I>(arm, XR, xo, R2, o2);
+      sfor<9>([&](auto e) ABRK_LAMBDA { Rj[e()] = R2[e()]; });
+      sfor<3>([&](auto r) ABRK_LAMBDA { oj[r()] = o2[r()]; });
+    }
+  });
+  if constexpr (!std::is_same<Cap, NoCap>::value) {
+    if (cap.frame == 2 * N + 1) mulBE<A, T>(arm, XR, xo, cap.R, cap.o);
+  }
+}
+
+// ---------------------------------------------------------------- dynamics accumulation
+// Lower-triangular index of a symmetric N x N matrix
+constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+enum { CMODE_NONE = 0, CMODE_VEC = 1, CMODE_MAT = 2 };
+
+template <class A, class T, int CMODE>
+struct Dyn {
+  static constexpr int N = A::N;
+  T Ms[N * (N + 1) / 2];                  // M, lower triangle            (base_config.py:594-645)
+  T gz[N];                                // sum_l m_l,z * dp_l,z/dq_i    (g = -9.81 gz, base_config.py:417-468)
+  T Cm[CMODE == CMODE_MAT ? N * N : 1];   // Christoffel matrix           (base_config.py:678-727)
+  T cv[CMODE == CMODE_VEC ? N : 1];       // C(q,dq) dq
+  T om[CMODE != CMODE_NONE ? N : 1][3];   // omega_j = sum_{k<j} dq_k z_k  (orthogonal chains)
+};
+
+// does link L carry linear / any mass?  (static arms: compile time; user arms: assume yes)
+template <class A, int L>
+constexpr bool link_has_linear_mass() {
+  if constexpr (A::kStatic)
+    return A::MD(L, 0) != 0.0 || A::MD(L, 1) != 0.0 || A::MD(L, 2) != 0.0;
+  else
+    return true;
+}
+
+// Omega_J v = sum_{k<J} dq_k W_k v
+template <int J, class A, class T, int CM>
+ABRK_INL void omega_apply(const Joints<A, T>& jt, const Dyn<A, T, CM>& d, const T (&dq)[A::N], const T (&v)[3],
+                          T (&out)[3]) {
+  if constexpr (J == 0) {
+    out[0] = out[1] = out[2] = T(0);
+  } else if constexpr (A::kOrtho) {
+    cross3(d.om[J], v, out);
+  } else {
+    T acc[3] = {T(0), T(0), T(0)};
+    sfor<J>([&](auto k) ABRK_LAMBDA {
+      T t[3];
+      wapply<k()>(jt, v, t);
+      sfor<3>([&](auto r) ABRK_LAMBDA { acc[r()] += dq[k()] * t[r()]; });
+    });
+    sfor<3>([&](auto r) ABRK_LAMBDA { out[r()] = acc[r()]; });
+  }
+}
+
+// Contribution of link L (COM at p, moved by joints 0..L-1) to M, g and C.
+//   e_i = dp/dq_i = W_i (p - o_i);   M_ij += sum_r m_r e_i[r] e_j[r];   gz_i += m_z e_i[2]
+//   linear Coriolis:  C_lin = sum_l E_l^T D_l Edot_l  with
+//       Edot[:,j] = d/dt e_j = W_j (sum_{k>=j} e_k dq_k) + Omega_j e_j
+//   (the Christoffel combination 1/2(M_kj,i + M_ki,j - M_ij,k) dq_i collapses to this
+//    because d2p/dq_i dq_k is symmetric - see DESIGN.md)
+template <int L, class A, class T, int CM>
+ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq)[A::N], const T (&p)[3],
+                              Dyn<A, T, CM>& d) {
+  constexpr int NJ = (L < A::N ? L : A::N);
+  bool live = true;
+  if constexpr (!A::kStatic) live = (L < arm.NL);
+  if constexpr (A::kStatic) {
+    if constexpr (!(L < A::NL) || !link_has_linear_mass<A, L>()) return;
+  }
+  if (!live) return;
+  T e[NJ][3];
+  sfor<NJ>([&](auto i) ABRK_LAMBDA {
+    T dlt[3] = {p[0] - jt.o[i()][0], p[1] - jt.o[i()][1], p[2] - jt.o[i()][2]};
+    wapply<i()>(jt, dlt, e[i()]);
+  });
+  T m0 = AccMD<A, T, L, 0>::get(arm), m1 = AccMD<A, T, L, 1>::get(arm), m2 = AccMD<A, T, L, 2>::get(arm);
+  T me[NJ][3];  // D_l e_i
+  sfor<NJ>([&](auto i) ABRK_LAMBDA {
+    me[i()][0] = m0 * e[i()][0];
+    me[i()][1] = m1 * e[i()][1];
+    me[i()][2] = m2 * e[i()][2];
+    d.gz[i()] += me[i()][2];
+    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] += dot3(me[i()], e[j()]); });
+  });
+  if constexpr (CM != CMODE_NONE) {
+    T s[3] = {T(0), T(0), T(0)};
+    T a[3] = {T(0), T(0), T(0)};  // COM bias acceleration  Edot dq
+    T ed[NJ][3];
+    sfor<NJ>([&](auto jr) ABRK_LAMBDA {
+      constexpr int j = NJ - 1 - jr();
+      sfor<3>([&](auto r) ABRK_LAMBDA { s[r()] += e[j][r()] * dq[j]; });
+      T t1[3], t2[3];
+      wapply<j>(jt, s, t1);
+      omega_apply<j>(jt, d, dq, e[j], t2);
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        ed[j][r()] = t1[r()] + t2[r()];
+        a[r()] += dq[j] * ed[j][r()];
+      });
+    });
+    if constexpr (CM == CMODE_VEC) {
+      sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] += dot3(me[k()], a); });
+    } else {
+      sfor<NJ>([&](auto k) ABRK_LAMBDA {
+        sfor<NJ>([&](auto j) ABRK_LAMBDA { d.Cm[k() * A::N + j()] += dot3(me[k()], ed[j()]); });
+      });
+    }
+  }
+}
+
+template <class A, class T, int CM>
+ABRK_INL void dyn_init(Dyn<A, T, CM>& d) {
+  constexpr int N = A::N;
+  sfor<N*(N + 1) / 2>([&](auto e) ABRK_LAMBDA { d.Ms[e()] = T(0); });
+  sfor<N>([&](auto i) ABRK_LAMBDA { d.gz[i()] = T(0); });
+  if constexpr (CM == CMODE_MAT) sfor<N * N>([&](auto e) ABRK_LAMBDA { d.Cm[e()] = T(0); });
+  if constexpr (CM == CMODE_VEC) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(0); });
+}
+
+// weighted dot  sum_r Isuf(m,r) a[r] b[r]
+template <int Mx, class A, class T>
+ABRK_INL T idot(const A& arm, const T (&a)[3], const T (&b)[3]) {
+  T acc = T(-0.0);
+  sfor<3>([&](auto r) ABRK_LAMBDA { acc = cfma<AccIsuf<A, T, Mx, r()>>(arm, a[r()] * b[r()], acc); });
+  return acc;
+}
+
+// Angular (world-frame inertia diagonal, base_config.py:628 quirk) parts of M and C, added
+// once every z_i is known:  M^w_ij = z_i^T Ibar_max(i,j) z_j,  Ibar_m = sum_{l>m} diag(I_l).
+template <class A, class T, int CM>
+ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
+  constexpr int N = A::N;
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] += idot<i()>(arm, jt.z[i()], jt.z[j()]); });
+  });
+  if constexpr (CM == CMODE_VEC) {
+    // c^w_k = zdot_k.y_k + z_k.y'_k - sum_{i>k} dq_i (W_k z_i).y_i
+    //   y_k  = sum_i Ibar_max(k,i) o (z_i dq_i),   y'_k = sum_i Ibar_max(k,i) o (zdot_i dq_i)
+    T zd[N][3];
+    sfor<N>([&](auto k) ABRK_LAMBDA { omega_apply<k()>(jt, d, dq, jt.z[k()], zd[k()]); });
+    T y[N][3], yp[N][3];
+    sfor<N>([&](auto k) ABRK_LAMBDA {
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        T ay = T(-0.0), ayp = T(-0.0);
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          constexpr int m = (k() > i() ? k() : i());
+          ay = cfma<AccIsuf<A, T, m, r()>>(arm, jt.z[i()][r()] * dq[i()], ay);
+          ayp = cfma<AccIsuf<A, T, m, r()>>(arm, zd[i()][r()] * dq[i()], ayp);
+        });
+        y[k()][r()] = ay;
+        yp[k()][r()] = ayp;
+      });
+    });
+    sfor<N>([&](auto k) ABRK_LAMBDA {
+      T acc = dot3(zd[k()], y[k()]) + dot3(jt.z[k()], yp[k()]);
+      sfor<N - 1 - k()>([&](auto ii) ABRK_LAMBDA {
+        constexpr int i = k() + 1 + ii();
+        T x[3];
+        wapply<k()>(jt, jt.z[i], x);
+        acc -= dq[i] * dot3(x, y[i]);
+      });
+      d.cv[k()] += acc;
+    });
+  }
+  if constexpr (CM == CMODE_MAT) {
+    // Christoffel symbols of M^w with dz_a/dq_c = [c<a] W_c z_a:
+    //   dM_ab/dq_c = [c<a] (W_c z_a)^T Ibar z_b + [c<b] z_a^T Ibar (W_c z_b),  Ibar = Ibar_max(a,b)
+    T X[N][N][3];  // X[c][a] = W_c z_a  (c < a)
+    sfor<N>([&](auto c) ABRK_LAMBDA {
+      sfor<N - 1 - c()>([&](auto aa) ABRK_LAMBDA {
+        constexpr int a = c() + 1 + aa();
+        wapply<c()>(jt, jt.z[a], X[c()][a]);
+      });
+    });
+    auto dM = [&](auto a, auto b, auto c) ABRK_LAMBDA -> T {
+      constexpr int m = (a() > b() ? a() : b());
+      T acc = T(0);
+      if constexpr (c() < a()) acc += idot<m>(arm, X[c()][a()], jt.z[b()]);
+      if constexpr (c() < b()) acc += idot<m>(arm, jt.z[a()], X[c()][b()]);
+      return acc;
+    };
+    sfor<N>([&](auto k) ABRK_LAMBDA {
+      sfor<N>([&](auto j) ABRK_LAMBDA {
+        T acc = T(0);
+        sfor<N>([&](auto i) ABRK_LAMBDA { acc += (dM(k, j, i) + dM(k, i, j) - dM(i, j, k)) * dq[i()]; });
+        d.Cm[k() * N + j()] += T(0.5) * acc;
+      });
+    });
+  }
+}
+
+// omega prefix sums (orthogonal chains): om[j] = sum_{k<j} dq_k z_k; must be current before
+// link_accumulate<L> uses joints < L, so it is advanced inside the link visitor.
+template <int L, class A, class T, int CM>
+ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
+  if constexpr (CM != CMODE_NONE && A::kOrtho && L - 1 < A::N) {
+    constexpr int j = L - 1;  // joint that was just recorded
+    if constexpr (j == 0) {
+      d.om[0][0] = d.om[0][1] = d.om[0][2] = T(0);
+    }
+    if constexpr (j + 1 < A::N) {
+      sfor<3>([&](auto r) ABRK_LAMBDA { d.om[j + 1][r()] = d.om[j][r()] + dq[j] * jt.z[j][r()]; });
+    }
+  }
+}
+
+// FK + M, g (+C).  Returns joint state for Jacobians; (XR, xo) = last rotated joint frame.
+template <class A, class T, int CM, class Cap>
+ABRK_INL void kin_dyn(const A& arm, const T (&q)[A::N], const T (&dq)[A::N], Joints<A, T>& jt, Dyn<A, T, CM>& d,
+                      T (&XR)[9], T (&xo)[3], Cap& cap) {
+  dyn_init(d);
+  fk_forward(arm, q, jt, XR, xo, cap, [&](auto L, const T(&p)[3]) ABRK_LAMBDA {
+    omega_advance<L()>(jt, dq, d);
+    link_accumulate<L()>(arm, jt, dq, p, d);
+  });
+  angular_finish(arm, jt, dq, d);
+}
+
+// Jacobian of point p attached after joints 0..m-1 (m runtime, uniform):
+//   Jv[:,i] = W_i (p - o_i), Jw[:,i] = z_i  for i < m, else 0        (base_config.py:522-592)
+template <class A, class T>
+ABRK_INL void jacobian(const Joints<A, T>& jt, const T (&p)[3], int m, T (&Jv)[A::N][3], T (&Jw)[A::N][3]) {
+  sfor<A::N>([&](auto i) ABRK_LAMBDA {
+    T dlt[3] = {p[0] - jt.o[i()][0], p[1] - jt.o[i()][1], p[2] - jt.o[i()][2]};
+    T e[3];
+    wapply<i()>(jt, dlt, e);
+    bool on = i() < m;
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      Jv[i()][r()] = on ? e[r()] : T(0);
+      Jw[i()][r()] = on ? jt.z[i()][r()] : T(0);
+    });
+  });
+}
+
+// dJ/dt of the same point (base_config.py:470-520):
+//   dJv[:,i] = W_i (sum_{k>=i} Jv_k dq_k) + Omega_i Jv_i ;  dJw[:,i] = Omega_i z_i     (i < m)
+template <class A, class T>
+ABRK_INL void jacobian_dot(const Joints<A, T>& jt, const T (&dq)[A::N], const T (&Jv)[A::N][3], int m,
+                           T (&dJv)[A::N][3], T (&dJw)[A::N][3]) {
+  constexpr int N = A::N;
+  Dyn<A, T, CMODE_VEC> tmp;  // only .om is used
+  if constexpr (A::kOrtho) {
+    tmp.om[0][0] = tmp.om[0][1] = tmp.om[0][2] = T(0);
+    sfor<N - 1>([&](auto j) ABRK_LAMBDA {
+      sfor<3>([&](auto r) ABRK_LAMBDA { tmp.om[j() + 1][r()] = tmp.om[j()][r()] + dq[j()] * jt.z[j()][r()]; });
+    });
+  }
+  T s[3] = {T(0), T(0), T(0)};
+  sfor<N>([&](auto jr) ABRK_LAMBDA {
+    constexpr int j = N - 1 - jr();
+    sfor<3>([&](auto r) ABRK_LAMBDA { s[r()] += Jv[j][r()] * dq[j]; });  // Jv is already 0 for j >= m
+    T t1[3], t2[3], t3[3];
+    wapply<j>(jt, s, t1);
+    omega_apply<j>(jt, tmp, dq, Jv[j], t2);
+    omega_apply<j>(jt, tmp, dq, jt.z[j], t3);
+    bool on = j < m;
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      dJv[j][r()] = on ? t1[r()] + t2[r()] : T(0);
+      dJw[j][r()] = on ? t3[r()] : T(0);
+    });
+  });
+}
+
+// number of joints a frame depends on == the reference's `end_point` (base_config.py:565-572)
+ABRK_INL int frame_joints(int frame, int N) {
+  if (frame == 2 * N + 1) return N;
+  int e = frame >> 1;
+  return e < N ? e : N;
+}
+
+}  // namespace abrk

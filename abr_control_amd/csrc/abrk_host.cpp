@@ -1,0 +1,569 @@
+// abrk_host.cpp - the C ABI of libabrk.so (include/abrk.h): arm registry, parameter
+// conversion, host<->device staging and kernel dispatch.  No arithmetic of the hot path
+// happens here and there is no CPU fallback: without a HIP device every compute entry
+// point fails with ABRK_ENODEV.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/abrk.h"
+#include "abrk_kernels.h"
+#include "abrk_params.h"
+
+namespace abrk {
+const ArmOps* ops_ur5();
+const ArmOps* ops_jaco2();
+const ArmOps* ops_twojoint();
+const ArmOps* ops_threejoint();
+const ArmOps* ops_onejoint();
+const ArmOps* ops_rt(int n_joints);
+size_t rt_table_size(int n_joints, int dtype);
+void rt_table_fill(int n_joints, int dtype, const abrk_arm_desc* d, void* dst);
+}  // namespace abrk
+
+using namespace abrk;
+
+// ------------------------------------------------------------------------------- errors
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(expr)                                                                       \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (void)hipGetLastError();                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? ABRK_ENOMEM : ABRK_ENODEV, "%s: %s", #expr,  \
+                  hipGetErrorString(e_));                                                  \
+    }                                                                                      \
+  } while (0)
+
+extern "C" const char* abrk_last_error(void) { return g_err.c_str(); }
+extern "C" int abrk_version(void) { return ABRK_VERSION; }
+
+// ------------------------------------------------------------------------------- arm registry
+namespace {
+struct ArmEntry {
+  bool live = false;
+  bool builtin = false;
+  abrk_arm_desc desc;
+  const ArmOps* ops = nullptr;
+  std::vector<unsigned char> rt64, rt32;  // RtArm<N,double> / RtArm<N,float> images (user arms)
+};
+std::mutex g_mu;
+std::vector<ArmEntry> g_arms;
+
+template <class Tab>
+void desc_from_tab(abrk_arm_desc* d) {
+  memset(d, 0, sizeof *d);
+  d->n_joints = Tab::N;
+  d->n_links_dyn = Tab::NL;
+  d->has_ee = Tab::kHasEE ? 1 : 0;
+  const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  memcpy(d->A0, Tab::A0, sizeof d->A0);
+  for (int i = 0; i < ABRK_MAX_JOINTS; i++) {
+    memcpy(d->AJ[i], i < Tab::N ? Tab::AJ[i] : ident, sizeof ident);
+    memcpy(d->B[i], i < Tab::N ? Tab::B[i] : ident, sizeof ident);
+  }
+  memcpy(d->E, Tab::E, sizeof d->E);
+  for (int l = 0; l <= Tab::N; l++) memcpy(d->mdiag[l], Tab::MD[l], 6 * sizeof(double));
+  snprintf(d->name, sizeof d->name, "%s", Tab::kName);
+}
+
+void init_builtins() {
+  if (!g_arms.empty()) return;
+  g_arms.reserve(4096);  // entries are handed out by address: never reallocate
+  g_arms.resize(5);
+  desc_from_tab<Tab_ur5>(&g_arms[0].desc);
+  g_arms[0].ops = ops_ur5();
+  desc_from_tab<Tab_jaco2>(&g_arms[1].desc);
+  g_arms[1].ops = ops_jaco2();
+  desc_from_tab<Tab_twojoint>(&g_arms[2].desc);
+  g_arms[2].ops = ops_twojoint();
+  desc_from_tab<Tab_threejoint>(&g_arms[3].desc);
+  g_arms[3].ops = ops_threejoint();
+  desc_from_tab<Tab_onejoint>(&g_arms[4].desc);
+  g_arms[4].ops = ops_onejoint();
+  for (auto& a : g_arms) a.live = a.builtin = true;
+}
+
+// returns a COPY-safe pointer valid while the registry lock is not needed (entries are
+// never moved after creation: vector of stable size is avoided by reserving)
+ArmEntry* get_arm(int id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  init_builtins();
+  if (id < 0 || id >= (int)g_arms.size() || !g_arms[id].live) return nullptr;
+  return &g_arms[id];
+}
+}  // namespace
+
+extern "C" int abrk_arm_builtin(const char* name) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  init_builtins();
+  if (!name) return fail(ABRK_EINVAL, "abrk_arm_builtin: NULL name");
+  for (int i = 0; i < 5; i++)
+    if (!strcmp(name, g_arms[i].desc.name)) return i;
+  return fail(ABRK_ENOARM, "unknown built-in arm '%s'", name);
+}
+
+extern "C" int abrk_arm_create(const abrk_arm_desc* d) {
+  if (!d) return fail(ABRK_EINVAL, "abrk_arm_create: NULL desc");
+  if (d->n_joints < 1 || d->n_joints > ABRK_MAX_JOINTS)
+    return fail(ABRK_EINVAL, "n_joints=%d outside 1..%d", d->n_joints, ABRK_MAX_JOINTS);
+  if (d->n_links_dyn < 0 || d->n_links_dyn > d->n_joints + 1)
+    return fail(ABRK_EINVAL, "n_links_dyn=%d outside 0..n_joints+1", d->n_links_dyn);
+  std::lock_guard<std::mutex> lk(g_mu);
+  init_builtins();
+  if (g_arms.size() >= 4096) return fail(ABRK_ENOMEM, "too many arms");
+  ArmEntry e;
+  e.live = true;
+  e.desc = *d;
+  e.desc.name[sizeof e.desc.name - 1] = 0;
+  e.ops = ops_rt(d->n_joints);
+  e.rt64.resize(rt_table_size(d->n_joints, ABRK_F64));
+  e.rt32.resize(rt_table_size(d->n_joints, ABRK_F32));
+  rt_table_fill(d->n_joints, ABRK_F64, d, e.rt64.data());
+  rt_table_fill(d->n_joints, ABRK_F32, d, e.rt32.data());
+  g_arms.push_back(std::move(e));
+  return (int)g_arms.size() - 1;
+}
+
+extern "C" int abrk_arm_get_desc(int arm_id, abrk_arm_desc* out) {
+  ArmEntry* a = get_arm(arm_id);
+  if (!a || !out) return fail(ABRK_ENOARM, "unknown arm id %d", arm_id);
+  *out = a->desc;
+  return 0;
+}
+
+extern "C" int abrk_arm_destroy(int arm_id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  init_builtins();
+  if (arm_id < 5 || arm_id >= (int)g_arms.size() || !g_arms[arm_id].live)
+    return fail(ABRK_ENOARM, "arm id %d is not a user arm", arm_id);
+  g_arms[arm_id].live = false;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- device plumbing
+static int use_device(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(ABRK_ENODEV, "no HIP device available (%s); libabrk has no CPU fallback",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  }
+  if (device < 0 || device >= n) return fail(ABRK_EINVAL, "device %d outside 0..%d", device, n - 1);
+  HIPCHK(hipSetDevice(device));
+  return 0;
+}
+
+extern "C" int abrk_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+extern "C" int abrk_device_name(int device, char* buf, size_t len) {
+  if (int rc = use_device(device)) return rc;
+  hipDeviceProp_t p;
+  HIPCHK(hipGetDeviceProperties(&p, device));
+  snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  return 0;
+}
+extern "C" void* abrk_malloc(int device, size_t bytes) {
+  if (use_device(device)) return nullptr;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    fail(ABRK_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return nullptr;
+  }
+  return p;
+}
+extern "C" int abrk_free(int device, void* p) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipFree(p));
+  return 0;
+}
+extern "C" int abrk_memcpy_h2d(int device, void* dst, const void* src, size_t bytes, void* stream) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int abrk_memcpy_d2h(int device, void* dst, const void* src, size_t bytes, void* stream) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int abrk_memset(int device, void* dst, int value, size_t bytes, void* stream) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipMemsetAsync(dst, value, bytes, (hipStream_t)stream));
+  return 0;
+}
+extern "C" void* abrk_stream_create(int device) {
+  if (use_device(device)) return nullptr;
+  hipStream_t s;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    fail(ABRK_ENODEV, "hipStreamCreate failed");
+    return nullptr;
+  }
+  return s;
+}
+extern "C" int abrk_stream_destroy(int device, void* stream) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+extern "C" int abrk_stream_sync(int device, void* stream) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+extern "C" int abrk_device_sync(int device) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipDeviceSynchronize());
+  return 0;
+}
+extern "C" void* abrk_event_create(int device) {
+  if (use_device(device)) return nullptr;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) {
+    (void)hipGetLastError();
+    fail(ABRK_ENODEV, "hipEventCreate failed");
+    return nullptr;
+  }
+  return e;
+}
+extern "C" int abrk_event_destroy(int device, void* ev) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipEventDestroy((hipEvent_t)ev));
+  return 0;
+}
+extern "C" int abrk_event_record(int device, void* ev, void* stream) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int abrk_event_elapsed_ms(int device, void* start, void* stop, float* ms) {
+  if (int rc = use_device(device)) return rc;
+  HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+  HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------- staging
+namespace {
+// Per-thread device scratch arena for host-pointer arguments (grown on demand, reused).
+struct Arena {
+  int device = -1;
+  char* base = nullptr;
+  size_t cap = 0, used = 0;
+};
+thread_local Arena t_arena;
+
+bool is_device_ptr(const void* p) {
+  hipPointerAttribute_t at;
+  hipError_t e = hipPointerGetAttributes(&at, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // plain malloc'ed host memory is "invalid value" to HIP
+    return false;
+  }
+  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+struct Stager {
+  int device;
+  hipStream_t stream;
+  struct Item {
+    void* host;
+    void* dev;
+    size_t bytes;
+    bool out, in;
+  };
+  std::vector<Item> items;
+  size_t need = 0;
+  bool staged = false;
+
+  // first pass: register; second pass (after reserve()) resolve
+  void* add(const void* p, size_t bytes, bool in, bool out) {
+    if (!p) return nullptr;
+    if (is_device_ptr(p)) return const_cast<void*>(p);
+    items.push_back({const_cast<void*>(p), nullptr, bytes, out, in});
+    need += (bytes + 255) & ~size_t(255);
+    return (void*)(uintptr_t)(items.size());  // placeholder index+1, resolved by fix()
+  }
+  int reserve() {
+    if (items.empty()) return 0;
+    staged = true;
+    Arena& a = t_arena;
+    if (a.device != device || a.cap < need) {
+      if (a.base) {
+        (void)hipSetDevice(a.device);
+        (void)hipFree(a.base);
+        (void)hipSetDevice(device);
+      }
+      a.base = nullptr;
+      a.cap = 0;
+      size_t cap = need < (1u << 20) ? (1u << 20) : need + need / 4;
+      hipError_t e = hipMalloc((void**)&a.base, cap);
+      if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ABRK_ENOMEM, "staging hipMalloc(%zu): %s", cap, hipGetErrorString(e));
+      }
+      a.cap = cap;
+      a.device = device;
+    }
+    size_t off = 0;
+    for (auto& it : items) {
+      it.dev = a.base + off;
+      off += (it.bytes + 255) & ~size_t(255);
+      if (it.in) {
+        hipError_t e = hipMemcpyAsync(it.dev, it.host, it.bytes, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return fail(ABRK_ENODEV, "H2D staging: %s", hipGetErrorString(e));
+      }
+    }
+    return 0;
+  }
+  // map a value returned by add() to the real device pointer
+  template <class P>
+  P fix(P p, const void* orig) const {
+    if (!orig) return nullptr;
+    for (size_t i = 0; i < items.size(); i++)
+      if (items[i].host == orig && (uintptr_t)p == i + 1) return (P)items[i].dev;
+    return p;
+  }
+  int finish() {
+    if (!staged) return 0;
+    for (auto& it : items)
+      if (it.out) {
+        hipError_t e = hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return fail(ABRK_ENODEV, "D2H staging: %s", hipGetErrorString(e));
+      }
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(ABRK_ENODEV, "stream sync: %s", hipGetErrorString(e));
+    return 0;
+  }
+};
+
+size_t esz(int dtype) { return dtype == ABRK_F64 ? 8 : 4; }
+
+int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
+  *a = get_arm(arm_id);
+  if (!*a) return fail(ABRK_ENOARM, "unknown arm id %d", arm_id);
+  if (dtype != ABRK_F64 && dtype != ABRK_F32) return fail(ABRK_EINVAL, "dtype %d is not ABRK_F64/ABRK_F32", dtype);
+  if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
+  return 0;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------- dynamics
+extern "C" int abrk_dynamics_batch(int arm_id, int dtype, int64_t B, const void* q, const void* dq, int frame,
+                                   const double* x_off, uint32_t want, const abrk_dyn_out* out, int device,
+                                   void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (frame < 0 || frame > 2 * n + 1) return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", frame);
+  if (!out || !want) return fail(ABRK_EINVAL, "nothing requested");
+  if (want >> 10) return fail(ABRK_EINVAL, "unknown want bits 0x%x", want);
+  if (!q) return fail(ABRK_EINVAL, "q is NULL");
+  if ((want & (ABRK_WANT_C | ABRK_WANT_DJ)) && !dq) return fail(ABRK_EINVAL, "C / dJ need dq");
+  void* const* outs = reinterpret_cast<void* const*>(out);
+  const size_t per[10] = {3, (size_t)6 * n, (size_t)n * n, (size_t)n, (size_t)n * n, (size_t)6 * n, 9, 16, 16, 4};
+  for (int i = 0; i < 10; i++)
+    if ((want >> i & 1) && !outs[i]) return fail(ABRK_EINVAL, "output %d requested but its pointer is NULL", i);
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  DynArgs da;
+  memset(&da, 0, sizeof da);
+  const void* q_ = st.add(q, B * n * s, true, false);
+  const void* dq_ = (want & (ABRK_WANT_C | ABRK_WANT_DJ)) ? st.add(dq, B * n * s, true, false) : nullptr;
+  void* o_[10];
+  for (int i = 0; i < 10; i++) o_[i] = (want >> i & 1) ? st.add(outs[i], B * per[i] * s, false, true) : nullptr;
+  if (int rc = st.reserve()) return rc;
+  da.q = st.fix(q_, q);
+  da.dq = dq_ ? st.fix(dq_, dq) : nullptr;
+  for (int i = 0; i < 10; i++) da.out[i] = (want >> i & 1) ? st.fix(o_[i], outs[i]) : nullptr;
+  da.frame = frame;
+  da.m = frame_m(frame, n);
+  for (int r = 0; r < 3; r++) da.off[r] = x_off ? x_off[r] : 0.0;
+  da.want = want;
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->dyn(dtype, la, da));
+  return st.finish();
+}
+
+// ------------------------------------------------------------------------------- OSC
+extern "C" int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                                       const void* dq, const void* target, const void* target_velocity,
+                                       void* integrated_error, const void* u_null_ext, void* u,
+                                       void* training_signal, int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (P->ref_frame < 0 || P->ref_frame > 2 * n + 1)
+    return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", P->ref_frame);
+  if (P->n_null < 0 || P->n_null > ABRK_MAX_NULL) return fail(ABRK_EINVAL, "n_null=%d outside 0..%d", P->n_null, ABRK_MAX_NULL);
+  for (int c = 0; c < P->n_null; c++)
+    if (P->null_ctrl[c].kind != ABRK_NULL_DAMPING && P->null_ctrl[c].kind != ABRK_NULL_RESTING)
+      return fail(ABRK_EINVAL, "null controller %d has unknown kind %d", c, P->null_ctrl[c].kind);
+  if (P->orientation_algorithm != 0 && P->orientation_algorithm != 1)
+    return fail(ABRK_EINVAL, "Invalid algorithm number %d for calculating orientation error", P->orientation_algorithm);
+  int k = 0;
+  for (int r = 0; r < 6; r++) k += P->ctrlr_dof[r] ? 1 : 0;
+  if (k == 0) return fail(ABRK_EINVAL, "ctrlr_dof selects no task-space dimension");
+  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
+  if (P->ki != 0 && !integrated_error) return fail(ABRK_EINVAL, "ki != 0 needs the integrated_error state array");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  void* ie = (P->ki != 0) ? integrated_error : nullptr;
+  const void* q_ = st.add(q, B * n * s, true, false);
+  const void* dq_ = st.add(dq, B * n * s, true, false);
+  const void* t_ = st.add(target, B * 6 * s, true, false);
+  const void* tv_ = st.add(target_velocity, B * 6 * s, true, false);
+  void* ie_ = st.add(ie, B * 6 * s, true, true);
+  const void* une_ = st.add(u_null_ext, B * n * s, true, false);
+  void* u_ = st.add(u, B * n * s, false, true);
+  void* ts_ = st.add(training_signal, B * n * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  OscArgs oa;
+  oa.q = st.fix(q_, q);
+  oa.dq = st.fix(dq_, dq);
+  oa.target = st.fix(t_, target);
+  oa.tv = st.fix(tv_, target_velocity);
+  oa.ierr = st.fix(ie_, ie);
+  oa.une = st.fix(une_, u_null_ext);
+  oa.u = st.fix(u_, u);
+  oa.ts = st.fix(ts_, training_signal);
+  oa.use_C = P->use_C ? 1 : 0;
+  oa.fast = osc_is_fast(*P, n, u_null_ext != nullptr);
+  OscP<double> p64;
+  OscP<float> p32;
+  if (dtype == ABRK_F64) {
+    p64 = make_oscp<double>(*P, n);
+    oa.P = &p64;
+  } else {
+    p32 = make_oscp<float>(*P, n);
+    oa.P = &p32;
+  }
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->osc(dtype, la, oa));
+  return st.finish();
+}
+
+// ------------------------------------------------------------------------------- Sliding
+extern "C" int abrk_sliding_generate_batch(int arm_id, int dtype, const abrk_sliding_params* P, int64_t B,
+                                           const void* q, const void* dq, const void* target,
+                                           const void* target_velocity, const void* target_acc, void* u, void* s_out,
+                                           int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (P->ref_frame < 0 || P->ref_frame > 2 * n + 1)
+    return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", P->ref_frame);
+  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  const int nt = P->cartesian ? 3 : n;
+  Stager st{device, (hipStream_t)stream};
+  const void* q_ = st.add(q, B * n * s, true, false);
+  const void* dq_ = st.add(dq, B * n * s, true, false);
+  const void* t_ = st.add(target, B * nt * s, true, false);
+  const void* tv_ = st.add(target_velocity, B * nt * s, true, false);
+  const void* ta_ = st.add(target_acc, B * nt * s, true, false);
+  void* u_ = st.add(u, B * n * s, false, true);
+  void* s_ = st.add(s_out, B * n * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  SlidingArgs sa;
+  sa.q = st.fix(q_, q);
+  sa.dq = st.fix(dq_, dq);
+  sa.target = st.fix(t_, target);
+  sa.tv = st.fix(tv_, target_velocity);
+  sa.ta = st.fix(ta_, target_acc);
+  sa.u = st.fix(u_, u);
+  sa.s = st.fix(s_, s_out);
+  SlidingP<double> p64;
+  SlidingP<float> p32;
+  if (dtype == ABRK_F64) {
+    p64 = make_slidingp<double>(*P, n);
+    sa.P = &p64;
+  } else {
+    p32 = make_slidingp<float>(*P, n);
+    sa.P = &p32;
+  }
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->sliding(dtype, la, sa));
+  return st.finish();
+}
+
+// ------------------------------------------------------------------------------- Joint / Damping / RestingConfig
+extern "C" int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_ctrl* ctrl, int account_for_gravity,
+                                         int64_t B, const void* q, const void* dq, const void* target,
+                                         const void* target_velocity, void* u, int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!ctrl) return fail(ABRK_EINVAL, "ctrl is NULL");
+  if (ctrl->kind < 0 || ctrl->kind > 2) return fail(ABRK_EINVAL, "unknown controller kind %d", ctrl->kind);
+  if (!q || !dq || !u) return fail(ABRK_EINVAL, "q, dq and u are required");
+  if (ctrl->kind == 0 && !target) return fail(ABRK_EINVAL, "Joint.generate needs target");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* q_ = st.add(q, B * n * s, true, false);
+  const void* dq_ = st.add(dq, B * n * s, true, false);
+  const void* t_ = st.add(target, B * n * s, true, false);
+  const void* tv_ = st.add(target_velocity, B * n * s, true, false);
+  void* u_ = st.add(u, B * n * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  JointArgs ja;
+  ja.q = st.fix(q_, q);
+  ja.dq = st.fix(dq_, dq);
+  ja.target = st.fix(t_, target);
+  ja.tv = st.fix(tv_, target_velocity);
+  ja.u = st.fix(u_, u);
+  JointP<double> p64;
+  JointP<float> p32;
+  if (dtype == ABRK_F64) {
+    p64 = make_jointp<double>(*ctrl, account_for_gravity);
+    ja.P = &p64;
+  } else {
+    p32 = make_jointp<float>(*ctrl, account_for_gravity);
+    ja.P = &p32;
+  }
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->joint(dtype, la, ja));
+  return st.finish();
+}

@@ -1,0 +1,159 @@
+// abrk_kernels.h - __global__ kernels (one lane = one arm instance) and the per-arm
+// launch table.  Each arm translation unit (abrk_arm_<name>.hip, abrk_arm_rt<N>.hip)
+// instantiates these for its arm policy and both arithmetic types.
+#pragma once
+#include "abrk_rows.h"
+
+namespace abrk {
+
+constexpr int kBlock = 64;  // one wavefront per workgroup: rows are independent, no LDS sharing
+
+#define ABRK_ROW_INDEX                                     \
+  long b = (long)blockIdx.x * kBlock + threadIdx.x;        \
+  if (b >= B) return;
+
+template <class A, class T, bool WITH_DQ>
+__global__ void __launch_bounds__(kBlock)
+dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, const T* __restrict__ qg,
+           const T* __restrict__ dqg, DynOutP<T> out) {
+  ABRK_ROW_INDEX
+  dyn_body<A, T, WITH_DQ>(b, arm, frame, m, ox, oy, oz, want, B, qg, dqg, out);
+}
+
+template <class A, class T, int KM, bool USE_C>
+__global__ void __launch_bounds__(kBlock)
+osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+           const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
+           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
+  ABRK_ROW_INDEX
+  osc_body<A, T, KM, USE_C>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg);
+}
+
+template <class A, class T>
+__global__ void __launch_bounds__(kBlock)
+sliding_kernel(A arm, SlidingP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+               const T* __restrict__ tg, const T* __restrict__ tvg, const T* __restrict__ tag,
+               T* __restrict__ ug, T* __restrict__ sg) {
+  ABRK_ROW_INDEX
+  sliding_body<A, T>(b, arm, P, B, qg, dqg, tg, tvg, tag, ug, sg);
+}
+
+template <class A, class T>
+__global__ void __launch_bounds__(kBlock)
+joint_kernel(A arm, JointP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+             const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ug) {
+  ABRK_ROW_INDEX
+  joint_body<A, T>(b, arm, P, B, qg, dqg, tg, tvg, ug);
+}
+
+// ---------------------------------------------------------------- launch table
+// Type-erased launchers the host ABI (abrk_host.cpp) calls; pointers are device pointers.
+struct LaunchArgs {
+  const void* arm_rt;   // RtArm<N,T> table for user arms (matching dtype), else nullptr
+  long B;
+  hipStream_t stream;
+};
+struct DynArgs {
+  int frame, m;
+  double off[3];
+  unsigned want;
+  const void *q, *dq;
+  void* out[10];
+};
+struct OscArgs {
+  const void* P;  // OscP<T>
+  int fast, use_C;
+  const void *q, *dq, *target, *tv, *une;
+  void *ierr, *u, *ts;
+};
+struct SlidingArgs {
+  const void* P;  // SlidingP<T>
+  const void *q, *dq, *target, *tv, *ta;
+  void *u, *s;
+};
+struct JointArgs {
+  const void* P;  // JointP<T>
+  const void *q, *dq, *target, *tv;
+  void* u;
+};
+struct ArmOps {
+  int n_joints;
+  hipError_t (*dyn)(int dtype, const LaunchArgs&, const DynArgs&);
+  hipError_t (*osc)(int dtype, const LaunchArgs&, const OscArgs&);
+  hipError_t (*sliding)(int dtype, const LaunchArgs&, const SlidingArgs&);
+  hipError_t (*joint)(int dtype, const LaunchArgs&, const JointArgs&);
+};
+
+inline dim3 grid_for(long B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
+
+template <class A, class T>
+struct Launch {
+  static A arm_of(const LaunchArgs& la) {
+    if constexpr (A::kStatic) return A{};
+    else return *static_cast<const A*>(la.arm_rt);
+  }
+  static hipError_t dyn(const LaunchArgs& la, const DynArgs& a) {
+    DynOutP<T> o;
+    T** po = reinterpret_cast<T**>(&o);
+    for (int i = 0; i < 10; i++) po[i] = static_cast<T*>(a.out[i]);
+    A arm = arm_of(la);
+    if (a.want & (W_C | W_DJ))
+      hipLaunchKernelGGL((dyn_kernel<A, T, true>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm, a.frame, a.m,
+                         T(a.off[0]), T(a.off[1]), T(a.off[2]), a.want, la.B, (const T*)a.q, (const T*)a.dq, o);
+    else
+      hipLaunchKernelGGL((dyn_kernel<A, T, false>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm, a.frame, a.m,
+                         T(a.off[0]), T(a.off[1]), T(a.off[2]), a.want, la.B, (const T*)a.q, (const T*)a.dq, o);
+    return hipGetLastError();
+  }
+  template <int KM, bool UC>
+  static void osc_launch(const LaunchArgs& la, const OscArgs& a) {
+    hipLaunchKernelGGL((osc_kernel<A, T, KM, UC>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
+                       *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
+                       (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts);
+  }
+  static hipError_t osc(const LaunchArgs& la, const OscArgs& a) {
+    if (a.fast) {
+      if (a.use_C) osc_launch<3, true>(la, a);
+      else osc_launch<3, false>(la, a);
+    } else {
+      if (a.use_C) osc_launch<6, true>(la, a);
+      else osc_launch<6, false>(la, a);
+    }
+    return hipGetLastError();
+  }
+  static hipError_t sliding(const LaunchArgs& la, const SlidingArgs& a) {
+    hipLaunchKernelGGL((sliding_kernel<A, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
+                       *static_cast<const SlidingP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq,
+                       (const T*)a.target, (const T*)a.tv, (const T*)a.ta, (T*)a.u, (T*)a.s);
+    return hipGetLastError();
+  }
+  static hipError_t joint(const LaunchArgs& la, const JointArgs& a) {
+    hipLaunchKernelGGL((joint_kernel<A, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
+                       *static_cast<const JointP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
+                       (const T*)a.tv, (T*)a.u);
+    return hipGetLastError();
+  }
+};
+
+// ops for an arm policy available in both arithmetic types (AD = double flavour, AF = float)
+template <class AD, class AF>
+struct OpsFor {
+  static hipError_t dyn(int dt, const LaunchArgs& la, const DynArgs& a) {
+    return dt == 0 ? Launch<AD, double>::dyn(la, a) : Launch<AF, float>::dyn(la, a);
+  }
+  static hipError_t osc(int dt, const LaunchArgs& la, const OscArgs& a) {
+    return dt == 0 ? Launch<AD, double>::osc(la, a) : Launch<AF, float>::osc(la, a);
+  }
+  static hipError_t sliding(int dt, const LaunchArgs& la, const SlidingArgs& a) {
+    return dt == 0 ? Launch<AD, double>::sliding(la, a) : Launch<AF, float>::sliding(la, a);
+  }
+  static hipError_t joint(int dt, const LaunchArgs& la, const JointArgs& a) {
+    return dt == 0 ? Launch<AD, double>::joint(la, a) : Launch<AF, float>::joint(la, a);
+  }
+  static const ArmOps* ops() {
+    static const ArmOps o = {AD::N, &dyn, &osc, &sliding, &joint};
+    return &o;
+  }
+};
+
+}  // namespace abrk

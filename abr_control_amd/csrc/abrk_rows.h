@@ -1,0 +1,181 @@
+// abrk_rows.h - the complete per-row programs (load a row, evaluate, store): what one GPU
+// lane executes.  Kept separate from the __global__ wrappers so that tests/hostsim can
+// compile the very same row code for the host and check the kernel arithmetic against the
+// oracle in a container without a GPU (test aid only - the product never runs it on a CPU).
+#pragma once
+#include "abrk_ctrl.h"
+
+namespace abrk {
+
+
+template <class T>
+struct DynOutP {
+  T *Tx, *J, *M, *g, *C, *dJ, *R, *Tm, *Tinv, *quat;
+};
+
+enum {
+  W_TX = 1u << 0, W_J = 1u << 1, W_M = 1u << 2, W_G = 1u << 3, W_C = 1u << 4,
+  W_DJ = 1u << 5, W_R = 1u << 6, W_T = 1u << 7, W_TINV = 1u << 8, W_QUAT = 1u << 9
+};
+
+template <int N, class T>
+ABRK_INL void load_row(const T* __restrict__ base, long b, T (&v)[N]) {
+  const T* p = base + b * N;
+  sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = p[i()]; });
+}
+template <int N, class T>
+ABRK_INL void store_row(T* __restrict__ base, long b, const T (&v)[N]) {
+  T* p = base + b * N;
+  sfor<N>([&](auto i) ABRK_LAMBDA { p[i()] = v[i()]; });
+}
+
+// ---- robot_config.{Tx,J,M,g,C,dJ,R,T,T_inv,quaternion} for B states (base_config.py:210-415)
+template <class A, class T, bool WITH_DQ>
+ABRK_INL void dyn_body(long b, const A& arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, const T* __restrict__ qg,
+           const T* __restrict__ dqg, const DynOutP<T>& out) {
+  constexpr int N = A::N;
+  T q[N], dq[N];
+  load_row<N>(qg, b, q);
+  if constexpr (WITH_DQ) load_row<N>(dqg, b, dq);
+  else sfor<N>([&](auto i) ABRK_LAMBDA { dq[i()] = T(0); });
+  Joints<A, T> jt;
+  Dyn<A, T, WITH_DQ ? CMODE_MAT : CMODE_NONE> d;
+  T XR[9], xo[3];
+  FrameCap<T> cap;
+  cap.frame = frame;
+  sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = T(0); });
+  sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = T(0); });
+  kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
+  T p[3];
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    p[r()] = cap.o[r()] + cap.R[r() * 3] * ox + cap.R[r() * 3 + 1] * oy + cap.R[r() * 3 + 2] * oz;
+  });
+  if (want & W_TX) store_row<3>(out.Tx, b, p);
+  if (want & (W_J | W_DJ)) {
+    T Jv[N][3], Jw[N][3];
+    jacobian(jt, p, m, Jv, Jw);
+    if (want & W_J) {
+      T* o = out.J + b * 6 * N;
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          o[r() * N + i()] = Jv[i()][r()];
+          o[(3 + r()) * N + i()] = Jw[i()][r()];
+        });
+      });
+    }
+    if constexpr (WITH_DQ) {
+      if (want & W_DJ) {
+        T dJv[N][3], dJw[N][3];
+        jacobian_dot(jt, dq, Jv, m, dJv, dJw);
+        T* o = out.dJ + b * 6 * N;
+        sfor<3>([&](auto r) ABRK_LAMBDA {
+          sfor<N>([&](auto i) ABRK_LAMBDA {
+            o[r() * N + i()] = dJv[i()][r()];
+            o[(3 + r()) * N + i()] = dJw[i()][r()];
+          });
+        });
+      }
+    }
+  }
+  if (want & W_M) {
+    T* o = out.M + b * N * N;
+    sfor<N>([&](auto i) ABRK_LAMBDA { sfor<N>([&](auto j) ABRK_LAMBDA { o[i() * N + j()] = d.Ms[tri(i(), j())]; }); });
+  }
+  if (want & W_G) {
+    T* o = out.g + b * N;
+    sfor<N>([&](auto i) ABRK_LAMBDA { o[i()] = T(-9.81) * d.gz[i()]; });
+  }
+  if constexpr (WITH_DQ) {
+    if (want & W_C) {
+      T* o = out.C + b * N * N;
+      sfor<N * N>([&](auto e) ABRK_LAMBDA { o[e()] = d.Cm[e()]; });
+    }
+  }
+  if (want & W_R) store_row<9>(out.R, b, cap.R);
+  if (want & W_T) {
+    T* o = out.Tm + b * 16;
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      sfor<3>([&](auto c) ABRK_LAMBDA { o[r() * 4 + c()] = cap.R[r() * 3 + c()]; });
+      o[r() * 4 + 3] = p[r()];   // T * [x,1] column: with x = 0 this is the frame origin
+      o[12 + r()] = T(0);
+    });
+    o[15] = T(1);
+  }
+  if (want & W_TINV) {  // base_config.py:791-837: [R^T | -R^T t]
+    T* o = out.Tinv + b * 16;
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      sfor<3>([&](auto c) ABRK_LAMBDA { o[r() * 4 + c()] = cap.R[c() * 3 + r()]; });
+      o[r() * 4 + 3] = -(cap.R[0 * 3 + r()] * cap.o[0] + cap.R[1 * 3 + r()] * cap.o[1] + cap.R[2 * 3 + r()] * cap.o[2]);
+      o[12 + r()] = T(0);
+    });
+    o[15] = T(1);
+  }
+  if (want & W_QUAT) {
+    T qq[4];
+    quat_from_R(cap.R, qq);
+    store_row<4>(out.quat, b, qq);
+  }
+}
+
+// ---- OSC.generate for B states (osc.py:217-320)
+template <class A, class T, int KM, bool USE_C>
+ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+           const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
+           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
+  constexpr int N = A::N;
+  T q[N], dq[N], tgt[6], tv[6], ierr[6], une[N], u[N], ts[N];
+  load_row<N>(qg, b, q);
+  load_row<N>(dqg, b, dq);
+  load_row<6>(tg, b, tgt);
+  const bool tv_given = tvg != nullptr, have_ierr = ierrg != nullptr, have_ext = uneg != nullptr;
+  if (tv_given) load_row<6>(tvg, b, tv);
+  else sfor<6>([&](auto r) ABRK_LAMBDA { tv[r()] = T(0); });
+  if (have_ierr) load_row<6>(ierrg, b, ierr);
+  else sfor<6>([&](auto r) ABRK_LAMBDA { ierr[r()] = T(0); });
+  if (have_ext) load_row<N>(uneg, b, une);
+  else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
+  osc_row<A, T, KM, USE_C>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts);
+  store_row<N>(ug, b, u);
+  if (tsg) store_row<N>(tsg, b, ts);
+  if (have_ierr) store_row<6>(ierrg, b, ierr);
+}
+
+// ---- Sliding.generate for B states (sliding.py:34-99)
+template <class A, class T>
+ABRK_INL void sliding_body(long b, const A& arm, const SlidingP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+               const T* __restrict__ tg, const T* __restrict__ tvg, const T* __restrict__ tag,
+               T* __restrict__ ug, T* __restrict__ sg) {
+  constexpr int N = A::N;
+  constexpr int NT = N > 3 ? N : 3;
+  T q[N], dq[N], tgt[NT], tv[NT], ta[NT], u[N], s[N];
+  load_row<N>(qg, b, q);
+  load_row<N>(dqg, b, dq);
+  const int nt = P.cartesian ? 3 : N;
+  sfor<NT>([&](auto i) ABRK_LAMBDA {
+    bool in = i() < nt;
+    tgt[i()] = in ? tg[b * nt + i()] : T(0);
+    tv[i()] = (in && tvg) ? tvg[b * nt + i()] : T(0);
+    ta[i()] = (in && tag) ? tag[b * nt + i()] : T(0);
+  });
+  sliding_row<A, T>(arm, P, q, dq, tgt, tv, ta, u, s);
+  store_row<N>(ug, b, u);
+  if (sg) store_row<N>(sg, b, s);
+}
+
+// ---- Joint / Damping / RestingConfig for B states
+template <class A, class T>
+ABRK_INL void joint_body(long b, const A& arm, const JointP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+             const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ug) {
+  constexpr int N = A::N;
+  T q[N], dq[N], tgt[N], tv[N], u[N];
+  load_row<N>(qg, b, q);
+  load_row<N>(dqg, b, dq);
+  if (tg) load_row<N>(tg, b, tgt);
+  else sfor<N>([&](auto i) ABRK_LAMBDA { tgt[i()] = T(0); });
+  if (tvg) load_row<N>(tvg, b, tv);
+  else sfor<N>([&](auto i) ABRK_LAMBDA { tv[i()] = T(0); });
+  joint_row<A, T>(arm, P, q, dq, tgt, tv, u);
+  store_row<N>(ug, b, u);
+}
+
+}  // namespace abrk

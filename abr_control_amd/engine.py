@@ -1,0 +1,176 @@
+"""Batched calls into libabrk.so.
+
+Every function takes either NumPy arrays (staged through device scratch by the library,
+results returned as NumPy) or `DeviceArray`s (zero-copy, asynchronous on `stream`, results
+returned as `DeviceArray`s).  Shapes are `[B, ...]`, row-major; dtype float64 or float32
+selects the arithmetic of the kernels.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import NP_DTYPE, AbrkError, DeviceArray, check, lib  # noqa: F401
+
+_OUT_SHAPES = {
+    "Tx": lambda n: (3,),
+    "J": lambda n: (6, n),
+    "M": lambda n: (n, n),
+    "g": lambda n: (n,),
+    "C": lambda n: (n, n),
+    "dJ": lambda n: (6, n),
+    "R": lambda n: (3, 3),
+    "T": lambda n: (4, 4),
+    "Tinv": lambda n: (4, 4),
+    "quat": lambda n: (4,),
+}
+_WANT_BITS = {
+    "Tx": _abi.WANT_TX, "J": _abi.WANT_J, "M": _abi.WANT_M, "g": _abi.WANT_G, "C": _abi.WANT_C,
+    "dJ": _abi.WANT_DJ, "R": _abi.WANT_R, "T": _abi.WANT_T, "Tinv": _abi.WANT_TINV, "quat": _abi.WANT_QUAT,
+}
+
+
+def _dtype_code(dtype):
+    dt = np.dtype(dtype)
+    if dt == np.float64:
+        return _abi.F64
+    if dt == np.float32:
+        return _abi.F32
+    raise TypeError(f"abr_control_amd computes in float64 or float32, not {dt}")
+
+
+class _Args:
+    """Marshals array arguments: keeps host copies alive, decides host/device mode."""
+
+    def __init__(self, dtype):
+        self.np_dtype = np.dtype(dtype)
+        self.code = _dtype_code(dtype)
+        self.keep = []
+        self.on_device = None
+
+    def _mode(self, dev):
+        if self.on_device is None:
+            self.on_device = dev
+        elif self.on_device != dev:
+            raise TypeError("mixing DeviceArray and NumPy arguments in one call is not supported")
+
+    def inp(self, a, shape, name):
+        if a is None:
+            return None
+        if isinstance(a, DeviceArray):
+            self._mode(True)
+            if a.dtype != self.np_dtype or a.shape != tuple(shape):
+                raise ValueError(f"{name}: expected {self.np_dtype}{tuple(shape)}, got {a.dtype}{a.shape}")
+            return a.ptr
+        self._mode(False)
+        h = np.ascontiguousarray(a, dtype=self.np_dtype)
+        if h.shape != tuple(shape):
+            raise ValueError(f"{name}: expected shape {tuple(shape)}, got {h.shape}")
+        self.keep.append(h)
+        return h.ctypes.data
+
+    def out(self, given, shape, device, name):
+        """-> (pointer, object to return)"""
+        if self.on_device:
+            if given is None:
+                given = DeviceArray(shape, self.np_dtype, device)
+            elif not isinstance(given, DeviceArray) or given.shape != tuple(shape) or given.dtype != self.np_dtype:
+                raise ValueError(f"{name}: output must be a DeviceArray {self.np_dtype}{tuple(shape)}")
+            return given.ptr, given
+        if given is None:
+            given = np.empty(shape, self.np_dtype)
+        elif (not isinstance(given, np.ndarray) or given.shape != tuple(shape) or given.dtype != self.np_dtype
+              or not given.flags.c_contiguous):
+            raise ValueError(f"{name}: output must be a C-contiguous ndarray {self.np_dtype}{tuple(shape)}")
+        return given.ctypes.data, given
+
+
+def _sp(stream):
+    return None if stream is None else getattr(stream, "ptr", stream)
+
+
+def dynamics(arm_id, n, q, dq=None, frame=None, x_off=None, want=("M",), dtype=np.float64, device=0,
+             stream=None, out=None):
+    """robot_config.{Tx,J,M,g,C,dJ,R,T,T_inv,quaternion} for a batch (one launch, shared FK).
+    Returns {name: array[B, ...]} for every name in `want`."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    frame = 2 * n + 1 if frame is None else frame
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq")
+    bits = 0
+    do = _abi.DynOut()
+    res = {}
+    for name in want:
+        bits |= _WANT_BITS[name]
+        ptr, obj = a.out(None if out is None else out.get(name), (B,) + _OUT_SHAPES[name](n), device, name)
+        setattr(do, name, ptr)
+        res[name] = obj
+    xo = None
+    if x_off is not None:
+        xo = (C.c_double * 3)(*[float(v) for v in x_off])
+    check(lib().abrk_dynamics_batch(arm_id, a.code, B, qp, dqp, frame, xo, bits, C.byref(do), device, _sp(stream)))
+    return res
+
+
+def osc_generate(arm_id, n, params, q, dq, target, target_velocity=None, integrated_error=None,
+                 u_null_ext=None, u=None, training_signal=False, dtype=np.float64, device=0, stream=None):
+    """OSC.generate for a batch.  `integrated_error` ([B,6]) is updated in place when ki != 0.
+    Returns u, or (u, training_signal) when training_signal is True / an output array."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq")
+    tp = a.inp(target, (B, 6), "target")
+    tvp = a.inp(target_velocity, (B, 6), "target_velocity")
+    unp = a.inp(u_null_ext, (B, n), "u_null_ext")
+    iep = None
+    if integrated_error is not None:
+        if isinstance(integrated_error, DeviceArray):
+            iep = a.inp(integrated_error, (B, 6), "integrated_error")
+        else:
+            if (not isinstance(integrated_error, np.ndarray) or integrated_error.dtype != a.np_dtype
+                    or integrated_error.shape != (B, 6) or not integrated_error.flags.c_contiguous):
+                raise ValueError("integrated_error must be a C-contiguous ndarray [B,6] of the call dtype")
+            a._mode(False)
+            iep = integrated_error.ctypes.data
+    up, uo = a.out(u, (B, n), device, "u")
+    tsp, tso = None, None
+    if training_signal is not False and training_signal is not None:
+        tsp, tso = a.out(None if training_signal is True else training_signal, (B, n), device, "training_signal")
+    check(lib().abrk_osc_generate_batch(arm_id, a.code, C.byref(params), B, qp, dqp, tp, tvp, iep, unp, up, tsp,
+                                        device, _sp(stream)))
+    return (uo, tso) if tso is not None else uo
+
+
+def sliding_generate(arm_id, n, params, q, dq, target, target_velocity=None, target_acc=None, u=None,
+                     want_s=False, dtype=np.float64, device=0, stream=None):
+    a = _Args(dtype)
+    B = q.shape[0]
+    nt = 3 if params.cartesian else n
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq")
+    tp = a.inp(target, (B, nt), "target")
+    tvp = a.inp(target_velocity, (B, nt), "target_velocity")
+    tap = a.inp(target_acc, (B, nt), "target_acc")
+    up, uo = a.out(u, (B, n), device, "u")
+    sp, so = (None, None)
+    if want_s:
+        sp, so = a.out(None, (B, n), device, "s")
+    check(lib().abrk_sliding_generate_batch(arm_id, a.code, C.byref(params), B, qp, dqp, tp, tvp, tap, up, sp,
+                                            device, _sp(stream)))
+    return (uo, so) if want_s else uo
+
+
+def joint_generate(arm_id, n, ctrl, account_for_gravity, q, dq, target=None, target_velocity=None, u=None,
+                   dtype=np.float64, device=0, stream=None):
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq")
+    tp = a.inp(target, (B, n), "target")
+    tvp = a.inp(target_velocity, (B, n), "target_velocity")
+    up, uo = a.out(u, (B, n), device, "u")
+    check(lib().abrk_joint_generate_batch(arm_id, a.code, C.byref(ctrl), int(bool(account_for_gravity)), B, qp, dqp,
+                                          tp, tvp, up, device, _sp(stream)))
+    return uo

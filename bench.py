@@ -1,0 +1,246 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched OSC.generate on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the fused OSC kernel over one batch of synthetic joint states that
+are already resident in HBM.  Default workload = BASELINE.json configs[1] (UR5 6-DOF OSC,
+batch 4096 per GPU, fp64, xyz control + gravity).  With N > 1 every rank evaluates its own
+shard (weak scaling, no collective on the data path); rank 0 prints ONE JSON line.
+
+Besides the contract fields the line carries
+  roofline        - dominant kernel on an HBM-sized batch (>> 256 MiB Infinity Cache),
+                    HIP-event timed on the launch stream: algorithmic bytes / launch time vs 8 TB/s,
+                    plus the FP64-VALU view (this kernel is above the FP64 ridge);
+  roofline_config - the same accounting for the config-sized (cache-resident, launch-bound) batch;
+  cpu_baseline    - the CPU oracle (plain C port of the reference path) on this box's host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TF = 78.6   # = 1/2 of the 157.3 TF fp32 vector peak
+
+WORKLOADS = {
+    # name: (arm, batch per GPU, dtype, kind, params kwargs, algorithmic flops per eval)
+    "cfg1": ("twojoint", 1, "f64", "osc", dict(kp=10, kv=3, ctrlr_dof=[1, 1, 0, 0, 0, 0]), 150),
+    "cfg2": ("ur5", 4096, "f64", "osc", dict(kp=200), 3500),
+    "cfg3": ("jaco2", 16384, "f64", "osc_damp", dict(kp=200), 4500),
+    "cfg4": ("ur5", (1 << 20) // 8, "f64", "osc", dict(kp=200, use_g=True, use_C=True), 10000),
+    "cfg5": ("threejoint", 65536, "f32", "sliding", dict(), 1200),
+}
+
+
+def algorithmic_bytes(n, esz, kind):
+    """SURVEY.md 8d, Mode U: read q, dq [n] + target, write u [n]"""
+    nt = 3 if kind == "sliding" else 6
+    return esz * (2 * n + nt) + esz * n
+
+
+def make_inputs(seed, B, n, nt, dt):
+    """the reference benchmark's input distribution (examples/timing_plots.py:18-20)"""
+    rng = np.random.RandomState(seed)
+    q = rng.uniform(0, 2 * np.pi, (B, n)).astype(dt)
+    dq = rng.uniform(0, 5, (B, n)).astype(dt)
+    t = rng.uniform(-1, 1, (B, nt)).astype(dt)
+    return q, dq, t
+
+
+class Runner:
+    """device-resident inputs + one launch per step()"""
+
+    def __init__(self, workload, B, device, stream):
+        import abr_control_amd as a
+        from abr_control_amd import _abi, engine
+        from abr_control_amd._lib import check, lib
+
+        arm, _, dts, kind, kw, self.flops = WORKLOADS[workload]
+        self.a, self.engine, self.kind = a, engine, kind
+        self.dt = np.float64 if dts == "f64" else np.float32
+        tab = _abi.load_table(arm)
+        self.n = tab["n_joints"]
+        self.nt = 3 if kind == "sliding" else 6
+        self.arm_id = check(lib().abrk_arm_builtin(arm.encode()))
+        self.B, self.device, self.stream = B, device, stream
+        q, dq, t = make_inputs(1, B, self.n, self.nt, self.dt)
+        self.host = (q, dq, t)
+        self.q = a.DeviceArray.from_numpy(q, device)
+        self.dq = a.DeviceArray.from_numpy(dq, device)
+        self.t = a.DeviceArray.from_numpy(t, device)
+        self.u = a.DeviceArray((B, self.n), self.dt, device)
+        if kind == "sliding":
+            self.params = _abi.make_sliding_params(self.n)
+        else:
+            nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
+            self.params = _abi.make_osc_params(self.n, null_controllers=nulls, **kw)
+        self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
+
+    def step(self):
+        if self.kind == "sliding":
+            self.engine.sliding_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
+                                         dtype=self.dt, device=self.device, stream=self.stream)
+        else:
+            self.engine.osc_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
+                                     dtype=self.dt, device=self.device, stream=self.stream)
+
+    def timed(self, steps, warmup, barrier=None):
+        """-> (wall seconds of the timed region, mean kernel ms per launch from HIP events)"""
+        a = self.a
+        for _ in range(warmup):
+            self.step()
+        self.stream.sync()
+        ev0, ev1 = a.Event(self.device), a.Event(self.device)
+        if barrier:
+            barrier()
+        self.stream.sync()
+        t0 = time.perf_counter()
+        ev0.record(self.stream)
+        for _ in range(steps):
+            self.step()
+        ev1.record(self.stream)
+        self.stream.sync()
+        if barrier:
+            barrier()
+        wall = time.perf_counter() - t0
+        return wall, ev1.elapsed_ms_since(ev0) / steps
+
+
+def roofline(runner, ms_per_launch, label):
+    evals_s = runner.B / (ms_per_launch * 1e-3)
+    gbs = evals_s * runner.bytes_per_eval / 1e9
+    tf = evals_s * runner.flops / 1e12
+    return {
+        "kernel": "osc_kernel" if runner.kind != "sliding" else "sliding_kernel",
+        "workload": label, "batch": runner.B, "bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+        "bytes_per_eval": runner.bytes_per_eval, "us_per_launch": round(ms_per_launch * 1e3, 3),
+        "evals_per_s": round(evals_s, 1),
+        "binding": "fp64_valu" if runner.dt == np.float64 else "fp32_valu",
+        "valu_tflops": round(tf, 3), "valu_peak_tflops": FP64_VALU_PEAK_TF if runner.dt == np.float64 else 157.3,
+        "valu_frac": round(tf / (FP64_VALU_PEAK_TF if runner.dt == np.float64 else 157.3), 5),
+    }
+
+
+def cpu_baseline(workload, budget_s=12.0):
+    """the oracle (plain-C port of the reference path) on one host core, bounded sample"""
+    from abr_control_amd import _abi
+    from oracle.oracle import Oracle
+
+    arm, _, _, kind, kw, _ = WORKLOADS[workload]
+    o = Oracle(_abi.load_table(arm))
+    nt = 3 if kind == "sliding" else 6
+    Bs = 2048
+    q, dq, t = make_inputs(1, Bs, o.n, nt, np.float64)
+    if kind == "sliding":
+        p = _abi.make_sliding_params(o.n)
+        fn = lambda: o.sliding_batch(p, q, dq, t)
+    else:
+        nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
+        p = _abi.make_osc_params(o.n, null_controllers=nulls, **kw)
+        fn = lambda: o.osc_batch(p, q, dq, t)
+    fn()
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        fn()
+        reps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(reps * Bs / dt, 1), "unit": "evals/s", "cores": 1, "kind": "port",
+            "host_cores_available": os.cpu_count(),
+            "sample": f"{reps} x {Bs} seeded rows of the same workload, oracle/abrk_oracle.c, 1 thread, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the workload's)")
+    ap.add_argument("--roofline-batch", type=int, default=8 << 20, help="rows of the HBM-sized roofline leg")
+    ap.add_argument("--roofline-steps", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-leg", action="store_true")
+    args = ap.parse_args()
+
+    from abr_control_amd.sharding import dist_env
+
+    rank, local_rank, world = dist_env()
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
+                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        # coordination only (barrier + max of timings): CPU tensors over gloo, no RCCL on the data path
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    import abr_control_amd as a
+
+    if a.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device: abr_control_amd has no CPU fallback")
+    device = local_rank % a.device_count()
+    stream = a.Stream(device)
+    arm, B0, dts, kind, kw, _ = WORKLOADS[args.workload]
+    B = args.batch or B0
+    run = Runner(args.workload, B, device, stream)
+
+    barrier = (lambda: dist.barrier()) if dist else None
+    wall, ms = run.timed(args.steps, args.warmup, barrier)
+    if dist:
+        tt = torch.tensor([wall], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt[0])
+    value = world * B * args.steps / wall
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "OSC control-signal evaluations/sec (batched UR5 6-DOF, fp64)" if args.workload == "cfg2"
+            else f"control-signal evaluations/sec ({args.workload})",
+            "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dts, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {arm} {kind} batch={B} per GPU, inputs resident in HBM, "
+                                   f"q~U(0,2pi) dq~U(0,5) target~U(-1,1) seed 1", "arm": arm, "batch_per_gpu": B,
+                       "global_batch": B * world, "params": {k: (v if not isinstance(v, list) else list(v))
+                                                              for k, v in kw.items()},
+                       "parallelism": f"batch-shard x{world}, no collective", "device": a.device_name(device)},
+            "roofline_config": roofline(run, ms, f"{args.workload} batch={B} (cache-resident, launch-bound)"),
+        }
+    # HBM-sized leg for the roofline (rank 0 only; every rank could, the figure is per GPU)
+    if rank == 0 and not args.no_roofline_leg:
+        del run
+        big = Runner(args.workload, args.roofline_batch, device, stream)
+        _, ms_big = big.timed(args.roofline_steps, 3)
+        out["roofline"] = roofline(big, ms_big, f"{args.workload} batch={args.roofline_batch} "
+                                                f"({args.roofline_batch * big.bytes_per_eval / 2**20:.0f} MiB algorithmic, "
+                                                f">> 256 MiB Infinity Cache)")
+        del big
+    elif rank == 0:
+        out["roofline"] = out["roofline_config"]
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

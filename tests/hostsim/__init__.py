@@ -1,0 +1,111 @@
+"""Python side of the hostsim TEST AID (tests/hostsim/hostsim.cpp): same call surface as
+abr_control_amd.engine, but runs the row programs on the CPU.  Never imported by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from abr_control_amd import _abi
+from abr_control_amd.engine import _OUT_SHAPES, _WANT_BITS, _dtype_code
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libabrk_hostsim.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, "hostsim.cpp")] + [
+        os.path.join(_HERE, "..", "..", "abr_control_amd", "csrc", f)
+        for f in ("abrk_device.h", "abrk_ctrl.h", "abrk_rows.h", "abrk_params.h", "abrk_rt.h", "abrk_arms_builtin.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared",
+                        "--cuda-host-only", "-o", _SO, srcs[0]], check=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _arm(arm):
+    """arm: built-in name (static kernels) or a table dict (runtime-table kernels)"""
+    if isinstance(arm, str):
+        return arm.encode(), None, _abi.load_table(arm)["n_joints"]
+    d = _abi.desc_from_table(arm)
+    return None, C.byref(d), d.n_joints
+
+
+def _in(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def dynamics(arm, q, dq=None, frame=None, x_off=None, want=("M",), dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q, dq = _in(q, dt), _in(dq, dt)
+    B = q.shape[0]
+    frame = 2 * n + 1 if frame is None else frame
+    do = _abi.DynOut()
+    res, bits = {}, 0
+    for w in want:
+        bits |= _WANT_BITS[w]
+        res[w] = np.full((B,) + _OUT_SHAPES[w](n), np.nan, dt)
+        setattr(do, w, res[w].ctypes.data)
+    xo = None if x_off is None else (C.c_double * 3)(*[float(v) for v in x_off])
+    rc = lib().hostsim_dynamics(name, desc, _dtype_code(dt), C.c_int64(B), _p(q), _p(dq), frame, xo,
+                                C.c_uint32(bits), C.byref(do))
+    assert rc == 0, rc
+    return res
+
+
+def osc_generate(arm, params, q, dq, target, target_velocity=None, integrated_error=None, u_null_ext=None,
+                 training_signal=False, dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q, dq, target = _in(q, dt), _in(dq, dt), _in(target, dt)
+    tv, une = _in(target_velocity, dt), _in(u_null_ext, dt)
+    B = q.shape[0]
+    u = np.full((B, n), np.nan, dt)
+    ts = np.full((B, n), np.nan, dt) if training_signal else None
+    if integrated_error is not None:
+        assert integrated_error.dtype == dt and integrated_error.flags.c_contiguous
+    rc = lib().hostsim_osc(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
+                           _p(tv), _p(integrated_error), _p(une), _p(u), _p(ts))
+    assert rc == 0, rc
+    return (u, ts) if training_signal else u
+
+
+def sliding_generate(arm, params, q, dq, target, target_velocity=None, target_acc=None, want_s=False,
+                     dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q, dq, target = _in(q, dt), _in(dq, dt), _in(target, dt)
+    tv, ta = _in(target_velocity, dt), _in(target_acc, dt)
+    B = q.shape[0]
+    u = np.full((B, n), np.nan, dt)
+    s = np.full((B, n), np.nan, dt)
+    rc = lib().hostsim_sliding(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
+                               _p(tv), _p(ta), _p(u), _p(s))
+    assert rc == 0, rc
+    return (u, s) if want_s else u
+
+
+def joint_generate(arm, ctrl, account_for_gravity, q, dq, target=None, target_velocity=None, dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q, dq, target, tv = _in(q, dt), _in(dq, dt), _in(target, dt), _in(target_velocity, dt)
+    B = q.shape[0]
+    u = np.full((B, n), np.nan, dt)
+    rc = lib().hostsim_joint(name, desc, _dtype_code(dt), C.byref(ctrl), int(bool(account_for_gravity)),
+                             C.c_int64(B), _p(q), _p(dq), _p(target), _p(tv), _p(u))
+    assert rc == 0, rc
+    return u

@@ -1,0 +1,137 @@
+// hostsim.cpp - TEST AID ONLY.  Compiles the row programs of abr_control_amd/csrc
+// (abrk_rows.h: exactly what one GPU lane executes) for the HOST so that the kernel
+// arithmetic can be checked against the oracle in a container without a GPU, before GPU
+// minutes are spent.  Nothing in abr_control_amd/ loads this library; the product path is
+// libabrk.so and fails loudly without a HIP device.
+#define ABRK_HD __host__ __device__
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "../../abr_control_amd/csrc/abrk_params.h"
+#include "../../abr_control_amd/csrc/abrk_rows.h"
+#include "../../abr_control_amd/csrc/abrk_rt.h"
+
+using namespace abrk;
+
+namespace {
+template <class A, class T>
+int run_dyn(const A& arm, int n, int64_t B, const void* q, const void* dq, int frame, const double* off,
+            unsigned want, void* const* outs) {
+  DynOutP<T> o;
+  T** po = reinterpret_cast<T**>(&o);
+  for (int i = 0; i < 10; i++) po[i] = static_cast<T*>(outs[i]);
+  int m = frame_m(frame, n);
+  T ox = T(off ? off[0] : 0), oy = T(off ? off[1] : 0), oz = T(off ? off[2] : 0);
+  for (long b = 0; b < B; b++) {
+    if (want & (W_C | W_DJ))
+      dyn_body<A, T, true>(b, arm, frame, m, ox, oy, oz, want, (long)B, (const T*)q, (const T*)dq, o);
+    else
+      dyn_body<A, T, false>(b, arm, frame, m, ox, oy, oz, want, (long)B, (const T*)q, (const T*)dq, o);
+  }
+  return 0;
+}
+template <class A, class T>
+int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void* q, const void* dq,
+            const void* tg, const void* tv, void* ie, const void* une, void* u, void* ts) {
+  OscP<T> p = make_oscp<T>(*P, n);
+  bool fast = osc_is_fast(*P, n, une != nullptr);
+  if (P->ki == 0) ie = nullptr;
+  for (long b = 0; b < B; b++) {
+#define CALL(KM, UC)                                                                                  \
+  osc_body<A, T, KM, UC>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, \
+                         (T*)ie, (const T*)une, (T*)u, (T*)ts)
+    if (fast) {
+      if (P->use_C) CALL(3, true); else CALL(3, false);
+    } else {
+      if (P->use_C) CALL(6, true); else CALL(6, false);
+    }
+#undef CALL
+  }
+  return 0;
+}
+template <class A, class T>
+int run_sliding(const A& arm, int n, const abrk_sliding_params* P, int64_t B, const void* q, const void* dq,
+                const void* tg, const void* tv, const void* ta, void* u, void* s) {
+  SlidingP<T> p = make_slidingp<T>(*P, n);
+  for (long b = 0; b < B; b++)
+    sliding_body<A, T>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, (const T*)ta,
+                       (T*)u, (T*)s);
+  return 0;
+}
+template <class A, class T>
+int run_joint(const A& arm, int n, const abrk_null_ctrl* c, int grav, int64_t B, const void* q, const void* dq,
+              const void* tg, const void* tv, void* u) {
+  JointP<T> p = make_jointp<T>(*c, grav);
+  for (long b = 0; b < B; b++)
+    joint_body<A, T>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, (T*)u);
+  return 0;
+}
+
+// dispatch over (arm kind, dtype): static built-in by name, or runtime table by joint count
+template <class F>
+int with_arm(const char* name, const abrk_arm_desc* d, int dtype, F&& f) {
+#define STATIC_CASE(NM)                                                                     \
+  if (name && !strcmp(name, #NM)) {                                                         \
+    StaticArm<Tab_##NM> a;                                                                  \
+    return dtype == 0 ? f(a, double(0), Tab_##NM::N) : f(a, float(0), Tab_##NM::N);         \
+  }
+  STATIC_CASE(ur5) STATIC_CASE(jaco2) STATIC_CASE(twojoint) STATIC_CASE(threejoint) STATIC_CASE(onejoint)
+#undef STATIC_CASE
+  if (!d) return -4;
+#define RT_CASE(NN)                                                           \
+  if (d->n_joints == NN) {                                                    \
+    if (dtype == 0) {                                                         \
+      RtArm<NN, double> a;                                                    \
+      rt_fill<NN, double>(d, &a);                                             \
+      return f(a, double(0), NN);                                             \
+    } else {                                                                  \
+      RtArm<NN, float> a;                                                     \
+      rt_fill<NN, float>(d, &a);                                              \
+      return f(a, float(0), NN);                                              \
+    }                                                                         \
+  }
+  RT_CASE(1) RT_CASE(2) RT_CASE(3) RT_CASE(4) RT_CASE(5) RT_CASE(6) RT_CASE(7)
+#undef RT_CASE
+  return -4;
+}
+}  // namespace
+
+extern "C" int hostsim_dynamics(const char* builtin, const abrk_arm_desc* d, int dtype, int64_t B, const void* q,
+                                const void* dq, int frame, const double* off, uint32_t want,
+                                const abrk_dyn_out* out) {
+  void* const* outs = reinterpret_cast<void* const*>(out);
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int n) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    return run_dyn<A, T>(a, n, B, q, dq, frame, off, want, outs);
+  });
+}
+extern "C" int hostsim_osc(const char* builtin, const abrk_arm_desc* d, int dtype, const abrk_osc_params* P,
+                           int64_t B, const void* q, const void* dq, const void* tg, const void* tv, void* ie,
+                           const void* une, void* u, void* ts) {
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int n) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    return run_osc<A, T>(a, n, P, B, q, dq, tg, tv, ie, une, u, ts);
+  });
+}
+extern "C" int hostsim_sliding(const char* builtin, const abrk_arm_desc* d, int dtype,
+                               const abrk_sliding_params* P, int64_t B, const void* q, const void* dq,
+                               const void* tg, const void* tv, const void* ta, void* u, void* s) {
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int n) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    return run_sliding<A, T>(a, n, P, B, q, dq, tg, tv, ta, u, s);
+  });
+}
+extern "C" int hostsim_joint(const char* builtin, const abrk_arm_desc* d, int dtype, const abrk_null_ctrl* c,
+                             int grav, int64_t B, const void* q, const void* dq, const void* tg, const void* tv,
+                             void* u) {
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int n) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    return run_joint<A, T>(a, n, c, grav, B, q, dq, tg, tv, u);
+  });
+}

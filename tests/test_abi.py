@@ -1,0 +1,159 @@
+"""Host-side checks that need no GPU: libabrk.so loads and exports every symbol
+include/abrk.h declares, the arm registry and tables are consistent, the Python surface
+mirrors the reference's, and compute calls FAIL LOUDLY without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from abr_control_amd import _abi
+from tests.conftest import REPO
+
+
+@pytest.fixture(scope="module")
+def L():
+    from abr_control_amd._lib import lib
+
+    return lib()
+
+
+def test_every_declared_symbol_is_exported(L):
+    hdr = open(os.path.join(REPO, "include", "abrk.h")).read()
+    names = sorted(set(re.findall(r"\b(abrk_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    for nm in names:
+        assert hasattr(L, nm), f"libabrk.so does not export {nm}"
+    assert L.abrk_version() == 100
+
+
+def test_struct_layouts_match_header():
+    """ctypes mirrors vs the C structs (sizes computed by compiling a probe with the real header)"""
+    src = r'''
+#include <stdio.h>
+#include "abrk.h"
+int main(){printf("%zu %zu %zu %zu %zu %zu\n", sizeof(abrk_arm_desc), sizeof(abrk_dyn_out),
+  sizeof(abrk_null_ctrl), sizeof(abrk_osc_params), sizeof(abrk_sliding_params), offsetof(abrk_osc_params, null_ctrl));return 0;}'''
+    exe = "/tmp/abrk_layout_probe"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(REPO, "include"), "-o", exe], input=src.encode(),
+                   check=True)
+    sizes = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
+    assert sizes == [C.sizeof(_abi.ArmDesc), C.sizeof(_abi.DynOut), C.sizeof(_abi.NullCtrl),
+                     C.sizeof(_abi.OSCParams), C.sizeof(_abi.SlidingParams), _abi.OSCParams.null_ctrl.offset]
+
+
+def test_builtin_arm_registry_matches_tables(L):
+    for name in _abi.BUILTIN_ARMS:
+        aid = L.abrk_arm_builtin(name.encode())
+        assert aid >= 0
+        d = _abi.ArmDesc()
+        assert L.abrk_arm_get_desc(aid, C.byref(d)) == 0
+        tab, got = _abi.load_table(name), _abi.table_from_desc(d)
+        assert got["n_joints"] == tab["n_joints"] and got["n_links_dyn"] == tab["n_links_dyn"]
+        assert got["has_ee"] == tab["has_ee"]
+        assert np.array_equal(np.array(got["A0"]), np.array(tab["A0"]))
+        assert np.array_equal(np.array(got["AJ"]), np.array(tab["AJ"]))
+        assert np.array_equal(np.array(got["B"]), np.array(tab["B"]))
+        n = tab["n_joints"]
+        assert np.array_equal(np.array(got["mdiag"]), np.array((tab["mdiag"] + [[0.0] * 6] * 8)[: n + 1]))
+    assert L.abrk_arm_builtin(b"nonexistent") == -4
+    assert b"nonexistent" in L.abrk_last_error()
+
+
+def test_generated_header_in_sync_with_tables():
+    rc = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_builtin_arms.py"), "--check"]).returncode
+    assert rc == 0, "abr_control_amd/csrc/abrk_arms_builtin.h is stale: run tools/gen_builtin_arms.py"
+
+
+def test_user_arm_create_and_validation(L):
+    tab = _abi.load_table("ur5")
+    d = _abi.desc_from_table(tab)
+    aid = L.abrk_arm_create(C.byref(d))
+    assert aid >= 5
+    back = _abi.ArmDesc()
+    assert L.abrk_arm_get_desc(aid, C.byref(back)) == 0 and back.n_joints == 6
+    assert L.abrk_arm_destroy(aid) == 0
+    assert L.abrk_arm_get_desc(aid, C.byref(back)) == -4
+    assert L.abrk_arm_destroy(0) == -4  # built-ins cannot be destroyed
+    d.n_joints = 9
+    assert L.abrk_arm_create(C.byref(d)) == -1
+
+
+def test_frame_ids_and_invalid_names():
+    assert _abi.frame_id("link0", 6) == 0 and _abi.frame_id("joint0", 6) == 1
+    assert _abi.frame_id("link6", 6) == 12 and _abi.frame_id("EE", 6) == 13
+    for bad in ("link7", "joint6", "ee", "hand", "link-1", 3):
+        with pytest.raises(Exception, match="Invalid transformation name"):
+            _abi.frame_id(bad, 6)
+
+
+def test_python_surface_mirrors_reference():
+    from abr_control_amd.arms import jaco2, onejoint, threejoint, twojoint, ur5
+    from abr_control_amd.controllers import OSC, Damping, Joint, RestingConfig, Sliding
+
+    rc = ur5.Config(use_cython=True)
+    assert (rc.N_JOINTS, rc.N_LINKS, rc.ROBOT_NAME) == (6, 7, "ur5")
+    assert rc.L.shape == (13, 3) and len(rc._M_LINKS) == 7 and rc.START_ANGLES.dtype == np.float32
+    assert jaco2.Config().L.shape == (14, 3) and jaco2.Config().N_JOINTS == 6
+    assert twojoint.Config().L.shape == (6, 3) and threejoint.Config().L.shape == (8, 3)
+    assert onejoint.Config().N_LINKS == 1
+    for m in ("g", "dJ", "J", "M", "R", "quaternion", "C", "T", "Tx", "T_inv"):
+        assert callable(getattr(rc, m))
+    with pytest.raises(TypeError):
+        ur5.Config(hand_attached=True)  # base_config.py:78 rejects unknown kwargs the same way
+    c = OSC(rc, kp=200)
+    assert c.ko == 200 and np.isclose(c.kv, np.sqrt(400)) and list(c.ctrlr_dof) == [1, 1, 1, 0, 0, 0]
+    c = OSC(rc, kp=10, ko=8, kv=4, vmax=[1, 1], ki=0.1)
+    assert np.isclose(c.sat_gain_xyz, 1 / 10 * 4) and np.isclose(c.sat_gain_abg, 1 / 8 * 4)
+    assert c.integrated_error.shape == (6,)
+    assert Sliding(rc).kd == 160.0 and Sliding(rc).lamb == 30.0
+    assert np.isclose(Joint(rc, kp=16).kv, 4.0)
+    r = RestingConfig(rc, [None, 1.0, None, None, None, None], kp=4)
+    assert r.rest_indices == [False, True, False, False, False, False] and not r.account_for_gravity
+    assert Damping(rc, 10).kv == 10
+
+    class Foreign:
+        N_JOINTS = 6
+
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        OSC(Foreign())
+
+
+def test_compute_fails_loudly_without_gpu(L):
+    from abr_control_amd import AbrkError, device_count
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC
+
+    if device_count() > 0:
+        pytest.skip("a GPU is present")
+    rc = ur5.Config()
+    with pytest.raises(AbrkError, match="ENODEV"):
+        rc.M(np.zeros(6))
+    with pytest.raises(AbrkError, match="ENODEV"):
+        OSC(rc, kp=200).generate(np.zeros(6), np.zeros(6), np.zeros(6))
+
+
+def test_argument_validation_before_device(L):
+    """bad arguments are rejected with EINVAL/EFRAME even without a device"""
+    from abr_control_amd import AbrkError, engine
+
+    p = _abi.make_osc_params(6, kp=1)
+    q = np.zeros((2, 6))
+    with pytest.raises(AbrkError, match="ENOARM"):
+        engine.osc_generate(999, 6, p, q, q, q)
+    p.ref_frame = 99
+    with pytest.raises(AbrkError, match="EFRAME"):
+        engine.osc_generate(0, 6, p, q, q, q)
+    p = _abi.make_osc_params(6, kp=1, ctrlr_dof=[0] * 6)
+    with pytest.raises(AbrkError, match="EINVAL"):
+        engine.osc_generate(0, 6, p, q, q, q)
+    with pytest.raises(ValueError):
+        engine.osc_generate(0, 6, _abi.make_osc_params(6), q, q, np.zeros((2, 5)))
+    with pytest.raises(TypeError):
+        engine.osc_generate(0, 6, _abi.make_osc_params(6), q, q, q, dtype=np.float16)
+    # empty batch is a no-op even without a device
+    u = engine.osc_generate(0, 6, _abi.make_osc_params(6), np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((0, 6)))
+    assert u.shape == (0, 6)

@@ -1,0 +1,264 @@
+"""Parity tests proper: libabrk.so (HIP kernels on the MI355X) through the C ABI against
+(a) the reference-generated golden vectors, (b) the CPU oracle on fresh seeded inputs,
+(c) size-independent properties at BASELINE.json's full batch sizes.  `-m gpu` only."""
+import numpy as np
+import pytest
+
+from abr_control_amd import _abi
+from tests import cases
+from tests.conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+ARMS = ["twojoint", "threejoint", "ur5", "jaco2"]
+
+
+def draw(seed, B, n, nt=6):
+    """the reference benchmark's input distribution (examples/timing_plots.py:18-20)"""
+    rng = np.random.RandomState(seed)
+    return rng.uniform(0, 2 * np.pi, (B, n)), rng.uniform(0, 5, (B, n)), rng.uniform(-1, 1, (B, nt))
+
+
+def test_native_library_is_loaded():
+    import abr_control_amd as a
+
+    assert a.device_count() >= 1
+    assert "gfx950" in a.device_name(0)
+    maps = open("/proc/self/maps").read()
+    assert "libabrk.so" in maps, "the HIP extension is not the one running"
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("arm", ARMS)
+def test_gpu_dynamics_match_reference(arm, variant):
+    cases.check_dynamics_against_golden(cases.GpuBackend(arm, variant), arm, golden(arm))
+
+
+@pytest.mark.parametrize("case_id", sorted(cases.CASES))
+def test_gpu_controllers_match_reference(case_id):
+    arm = cases.CASES[case_id]["arm"]
+    cases.check_case_against_golden(cases.GpuBackend(arm, "static"), case_id, golden(arm))
+
+
+@pytest.mark.parametrize("case_id", ["twojoint:cfg1", "ur5:cfg2", "ur5:cfg4", "ur5:osc6_alg0", "ur5:osc_null2",
+                                     "ur5:sliding", "jaco2:cfg3", "jaco2:osc6_alg1", "threejoint:cfg5", "ur5:joint"])
+def test_gpu_runtime_table_arms(case_id):
+    arm = cases.CASES[case_id]["arm"]
+    cases.check_case_against_golden(cases.GpuBackend(arm, "rt"), case_id, golden(arm))
+
+
+def test_gpu_fp32_config5_full_size():
+    """BASELINE config 5: threejoint Sliding, batch 65536, fp32, tolerance 1e-4"""
+    g = golden("threejoint")
+    be = cases.GpuBackend("threejoint")
+    # golden sample (reference as shipped)
+    u, _ = cases.run_case(be, cases.CASES["threejoint:cfg5"], g, dtype=np.float32)
+    q = g["cfg5_q"]
+    well = (np.abs(np.sin(q[:, 1])) > 0.05) & (np.abs(np.sin(q[:, 2])) > 0.05)
+    assert cases.rel_err(u.astype(float), g["cfg5_uS"])[well].max() <= cases.TOL_F32
+    # full size vs the fp64 kernel (itself pinned above) + oracle on a sample
+    B = 65536
+    q, dq, t = draw(5, B, 3, 3)
+    p = _abi.make_sliding_params(3)
+    u32, _ = be.sliding(p, q, dq, t, dtype=np.float32)
+    u64, _ = be.sliding(p, q, dq, t)
+    well = (np.abs(np.sin(q[:, 1])) > 0.05) & (np.abs(np.sin(q[:, 2])) > 0.05)
+    assert np.all(np.isfinite(u32))
+    assert cases.rel_err(u32.astype(float), u64)[well].max() <= cases.TOL_F32
+    uo, _ = cases.OracleBackend("threejoint").sliding(p, q[:4096], dq[:4096], t[:4096])
+    assert cases.rel_err(u64[:4096], uo).max() <= 1e-6
+
+
+def test_gpu_config2_config4_full_size_vs_oracle():
+    """BASELINE configs 2 (B=4096) and 4 (B=2^20 on one GPU): oracle on a sample + properties"""
+    be, orc = cases.GpuBackend("ur5"), cases.OracleBackend("ur5")
+    p2 = _abi.make_osc_params(6, kp=200)
+    p4 = _abi.make_osc_params(6, kp=200, use_g=True, use_C=True)
+    q, dq, t = draw(1, 4096, 6)
+    u, _ = be.osc(p2, q, dq, t)
+    uo, _ = orc.osc(p2, q, dq, t)
+    assert cases.rel_err(u, uo).max() <= 1e-6
+    B = 1 << 20
+    q, dq, t = draw(2, B, 6)
+    u, ts = be.osc(p4, q, dq, t)
+    assert np.all(np.isfinite(u))
+    idx = np.random.RandomState(0).choice(B, 4096, replace=False)
+    uo, _ = orc.osc(p4, q[idx], dq[idx], t[idx])
+    assert cases.rel_err(u[idx], uo).max() <= 1e-6
+    # rows are independent: any sub-batch / permutation reproduces the same bits
+    perm = np.random.RandomState(1).permutation(B)[:100003]
+    u_sub, _ = be.osc(p4, q[perm], dq[perm], t[perm])
+    assert np.array_equal(u_sub, u[perm])
+    # u = training_signal - g   (osc.py:297-301)
+    gq = be.dynamics(q[:65536], None, "EE", None, ("g",))["g"]
+    assert np.allclose(u[:65536], ts[:65536] - gq, rtol=1e-12, atol=1e-12)
+    # use_C only subtracts C(q,dq) dq (osc.py:291-292)
+    u_noC, _ = be.osc(_abi.make_osc_params(6, kp=200), q[:65536], dq[:65536], t[:65536])
+    Cq = be.dynamics(q[:65536], dq[:65536], "EE", None, ("C",))["C"]
+    assert np.allclose(u_noC - np.einsum("bij,bj->bi", Cq, dq[:65536]), u[:65536], rtol=1e-10, atol=1e-9)
+
+
+def test_gpu_config3_full_size():
+    """BASELINE config 3: Jaco2 OSC + null-space Damping, batch 16384"""
+    be, orc = cases.GpuBackend("jaco2"), cases.OracleBackend("jaco2")
+    p = _abi.make_osc_params(6, kp=200, null_controllers=[_abi.make_damping(10)])
+    q, dq, t = draw(0, 16384, 6)
+    u, _ = be.osc(p, q, dq, t)
+    uo, _ = orc.osc(p, q[:2048], dq[:2048], t[:2048])
+    assert cases.rel_err(u[:2048], uo).max() <= 1e-6
+    # the damping term lives in the null space of J: J Minv (u_damped - u_plain) ... = 0
+    u0, _ = be.osc(_abi.make_osc_params(6, kp=200), q, dq, t)
+    r = be.dynamics(q, None, "EE", None, ("J", "M"))
+    du = u - u0
+    acc = np.einsum("bij,bj->bi", r["J"][:, :3], np.linalg.solve(r["M"], du[..., None])[..., 0])
+    scale = np.abs(du).max(axis=1) + 1e-30
+    cond_ok = np.linalg.cond(r["M"]) < 1e6
+    assert (np.abs(acc).max(axis=1) / scale)[cond_ok].max() < 1e-6
+
+
+def test_gpu_dynamics_properties_large_batch():
+    be = cases.GpuBackend("ur5")
+    B = 200_000
+    q, dq, _ = draw(3, B, 6)
+    r = be.dynamics(q, dq, "EE", None, ("M", "C", "J", "dJ", "g", "R", "quat", "T", "Tinv"))
+    M = r["M"]
+    assert np.array_equal(M, M.transpose(0, 2, 1))                       # exactly symmetric
+    assert np.linalg.eigvalsh(M[:20000]).min() > 0                         # positive definite
+    # Mdot - 2C skew-symmetric (Christoffel form), checked with a central difference of M
+    h = 1e-6
+    Mp = be.dynamics(q[:4096] + h * dq[:4096], None, "EE", None, ("M",))["M"]
+    Mm = be.dynamics(q[:4096] - h * dq[:4096], None, "EE", None, ("M",))["M"]
+    N = (Mp - Mm) / (2 * h) - 2 * r["C"][:4096]
+    assert np.abs(N + N.transpose(0, 2, 1)).max() < 1e-5
+    # dJ is the directional derivative of J
+    Jp = be.dynamics(q[:4096] + h * dq[:4096], None, "EE", None, ("J",))["J"]
+    Jm = be.dynamics(q[:4096] - h * dq[:4096], None, "EE", None, ("J",))["J"]
+    assert np.abs((Jp - Jm) / (2 * h) - r["dJ"][:4096]).max() < 1e-5
+    # rotations orthonormal, quaternion consistent with R, T_inv T = I
+    R = r["R"]
+    assert np.abs(np.einsum("bij,bkj->bik", R, R) - np.eye(3)).max() < 1e-13
+    w, x, y, z = r["quat"].T
+    assert np.allclose(w * w + x * x + y * y + z * z, 1.0, atol=1e-14) and (w >= 0).all()
+    assert np.allclose(1 - 2 * (y * y + z * z), R[:, 0, 0], atol=1e-12)
+    assert np.abs(np.einsum("bij,bjk->bik", r["Tinv"], r["T"]) - np.eye(4)).max() < 1e-13
+
+
+def test_gpu_batch_edges_and_device_arrays():
+    import abr_control_amd as a
+    from abr_control_amd import engine
+
+    be, orc = cases.GpuBackend("ur5"), cases.OracleBackend("ur5")
+    p = _abi.make_osc_params(6, kp=200)
+    for B in (1, 63, 64, 65, 1000):
+        q, dq, t = draw(B, B, 6)
+        u, _ = be.osc(p, q, dq, t)
+        uo, _ = orc.osc(p, q, dq, t)
+        assert u.shape == (B, 6) and cases.rel_err(u, uo).max() <= 1e-6
+    # empty batch
+    assert be.osc(p, np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((0, 6)))[0].shape == (0, 6)
+    # device-resident arrays: zero-copy, same bits as the staged host path
+    q, dq, t = draw(9, 5000, 6)
+    dq_, q_, t_ = a.DeviceArray.from_numpy(dq), a.DeviceArray.from_numpy(q), a.DeviceArray.from_numpy(t)
+    ud = engine.osc_generate(be.arm_id, 6, p, q_, dq_, t_)
+    assert isinstance(ud, a.DeviceArray)
+    assert np.array_equal(ud.numpy(), be.osc(p, q, dq, t)[0])
+    # explicit stream
+    s = a.Stream(0)
+    ud2 = engine.osc_generate(be.arm_id, 6, p, q_, dq_, t_, stream=s)
+    s.sync()
+    assert np.array_equal(ud2.numpy(), ud.numpy())
+    with pytest.raises(TypeError):
+        engine.osc_generate(be.arm_id, 6, p, q_, dq, t)
+
+
+def test_gpu_python_api_drop_in():
+    """robot_config / controller classes: reference shapes, dtypes and per-call state"""
+    from abr_control_amd.arms import jaco2, threejoint, twojoint, ur5
+    from abr_control_amd.controllers import OSC, Damping, Joint, RestingConfig, Sliding
+
+    g = golden("ur5")
+    rc = ur5.Config(use_cython=True)
+    q, dq = g["dyn_q"], g["dyn_dq"]
+    # single state: reference dtypes (float32 casts at base_config.py:223-336; Tx float64)
+    J = rc.J("EE", q[5])
+    assert J.shape == (6, 6) and J.dtype == np.float32 and np.array_equal(J, g["J_EE"][5].astype(np.float32))
+    M = rc.M(q[5])
+    assert M.dtype == np.float32 and np.allclose(M, g["M"][5].astype(np.float32), rtol=2e-7)
+    assert rc.g(q[5]).dtype == np.float32 and rc.g(q[5]).shape == (6,)
+    assert rc.C(q[5], dq[5]).shape == (6, 6) and rc.dJ("EE", q[5], dq[5]).shape == (6, 6)
+    Tx = rc.Tx("EE", q[5])
+    assert Tx.dtype == np.float64 and Tx.shape == (3,) and np.allclose(Tx, g["Tx_EE"][5], atol=1e-14)
+    assert np.allclose(rc.Tx("EE", q[5], x=g["xoff"]), g["Tx_EE_x"][5], atol=1e-14)
+    assert rc.R("EE", q[5]).shape == (3, 3) and rc.T("EE", q[5]).shape == (4, 4)
+    assert np.allclose(rc.quaternion("EE", q[5]), g["quat_EE"][5], atol=1e-12)
+    assert np.allclose(rc.Tx("link3", q[5]), g["Tx_link3"][5], atol=1e-14)
+    with pytest.raises(Exception, match="Invalid transformation name"):
+        rc.Tx("link9", q[5])
+    # batch
+    assert rc.M(q).shape == (len(q), 6, 6) and rc.Tx("EE", q).shape == (len(q), 3)
+    d = rc.dynamics(q, dq, want=("Tx", "J", "M", "g", "C"))
+    assert np.allclose(d["C"], g["C"], atol=1e-12)
+
+    # OSC single-call == golden (Oracle-D) and state handling of ki (osc.py:81-82, 262-264)
+    c = OSC(rc, kp=200)
+    u = c.generate(g["cfg2_q"][0], g["cfg2_dq"][0], g["cfg2_target"][0])
+    assert u.shape == (6,) and u.dtype == np.float64
+    assert cases.rel_err(u[None], g["cfg2_uD"][:1]).max() < 1e-6
+    assert np.allclose(c.training_signal, g["cfg2_tsD"][0], rtol=1e-9)
+    ub = c.generate(g["cfg2_q"], g["cfg2_dq"], g["cfg2_target"])
+    assert cases.rel_err(ub, g["cfg2_uD"]).max() < 1e-6
+    key = "osc_xyz_vmax_ki"
+    c = OSC(rc, kp=100, kv=15, ki=0.2, ctrlr_dof=[True] * 3 + [False] * 3, vmax=[0.5, 1.0])
+    for s in range(5):
+        u = c.generate(g[f"{key}_q"][3], g[f"{key}_dq"][3], g[f"{key}_target"][3])
+        assert cases.rel_err(u[None], g[f"{key}_uD"][s, 3][None]).max() < 1e-6
+    assert c.integrated_error.shape == (6,)
+    # fused + Python null controllers (osc.py:310-318)
+    class PyDamping:
+        def __init__(self, rc_, kv):
+            self.rc, self.kv = rc_, kv
+
+        def generate(self, q_, dq_):
+            return np.dot(self.rc.M(q_).astype(float), -self.kv * dq_)
+
+    key = "osc_null2"
+    rest = RestingConfig(rc, [None, 0.8, -1.6, None, 1.5, None], kp=40, kv=8)
+    c = OSC(rc, kp=200, null_controllers=[Damping(rc, 10), rest])
+    u = c.generate(g[f"{key}_q"], g[f"{key}_dq"], g[f"{key}_target"])
+    assert cases.rel_err(u, g[f"{key}_uD"]).max() < 1e-6
+    c = OSC(rc, kp=200, null_controllers=[PyDamping(rc, 10), rest])
+    u = c.generate(g[f"{key}_q"][:16], g[f"{key}_dq"][:16], g[f"{key}_target"][:16])
+    assert cases.rel_err(u, g[f"{key}_uS"][:16]).max() < 1e-4  # float32 M in the Python controller
+    # other controllers
+    assert cases.rel_err(Joint(rc, kp=50, kv=9).generate(g["joint_q"], g["joint_dq"], g["joint_target"] * 3.0),
+                         g["joint_uD"]).max() < 1e-6
+    sl = Sliding(rc)
+    u = sl.generate(g["sliding_q"][0], g["sliding_dq"][0], g["sliding_target"][0])
+    assert u.shape == (6,) and sl.s.shape == (6,)
+    assert cases.rel_err(u[None], g["sliding_uD"][:1]).max() < 1e-6
+    g2 = golden("jaco2")
+    rj = jaco2.Config()
+    assert cases.rel_err(Damping(rj, 10).generate(g2["damping_q"], g2["damping_dq"]), g2["damping_uD"]).max() < 1e-6
+    # twojoint config 1: batch of one through the public classes
+    g1 = golden("twojoint")
+    c1 = OSC(twojoint.Config(), kp=10, kv=3, ctrlr_dof=[True, True, False, False, False, False])
+    u = c1.generate(g1["cfg1_q"][0], g1["cfg1_dq"][0], g1["cfg1_target"][0])
+    assert cases.rel_err(u[None], g1["cfg1_uD"][:1]).max() < 1e-6
+    # fp32 config
+    g3 = golden("threejoint")
+    s32 = Sliding(threejoint.Config(dtype=np.float32, reference_dtypes=False))
+    u = s32.generate(g3["cfg5_q"][:64], g3["cfg5_dq"][:64], g3["cfg5_target"][:64])
+    assert u.dtype == np.float32
+
+
+def test_gpu_user_arm_from_table_matches_builtin():
+    from abr_control_amd import arms
+    from abr_control_amd.controllers import OSC
+
+    tab = _abi.load_table("jaco2")
+    user = arms.from_table(tab)
+    builtin = arms.jaco2.Config()
+    q, dq, t = draw(11, 3000, 6)
+    a = OSC(user, kp=200).generate(q, dq, t)
+    b = OSC(builtin, kp=200).generate(q, dq, t)
+    assert cases.rel_err(a, b).max() < 1e-9

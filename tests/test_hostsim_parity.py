@@ -1,0 +1,109 @@
+"""Checks the arithmetic of the GPU row programs WITHOUT a GPU: tests/hostsim compiles
+abr_control_amd/csrc/abrk_rows.h (exactly what one GPU lane executes) for the host.
+Compared against the reference-generated golden vectors and the oracle, for the
+compile-time specialised arms ("static") and the runtime-table arms ("rt").
+The `-m gpu` tests repeat the same checks through libabrk.so on the device."""
+import numpy as np
+import pytest
+
+from tests import cases
+from tests.conftest import golden
+
+ARMS = ["twojoint", "threejoint", "ur5", "jaco2"]
+BIG = {"ur5:cfg2": 1024, "ur5:cfg4": 512, "jaco2:cfg3": 512, "threejoint:cfg5": 1024}
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("arm", ARMS)
+def test_rows_dynamics_match_reference(arm, variant):
+    cases.check_dynamics_against_golden(cases.HostsimBackend(arm, variant), arm, golden(arm))
+
+
+@pytest.mark.parametrize("case_id", sorted(cases.CASES))
+def test_rows_controllers_match_reference(case_id):
+    arm = cases.CASES[case_id]["arm"]
+    cases.check_case_against_golden(cases.HostsimBackend(arm, "static"), case_id, golden(arm), rows=BIG.get(case_id))
+
+
+@pytest.mark.parametrize("case_id", ["twojoint:cfg1", "ur5:cfg2", "ur5:osc6_alg0", "ur5:osc_null2", "ur5:sliding",
+                                     "jaco2:cfg3", "jaco2:osc6_alg1", "threejoint:cfg5", "ur5:joint"])
+def test_rows_runtime_table_arms(case_id):
+    arm = cases.CASES[case_id]["arm"]
+    cases.check_case_against_golden(cases.HostsimBackend(arm, "rt"), case_id, golden(arm), rows=256)
+
+
+def test_rows_fp32_config5():
+    """BASELINE config 5: threejoint Sliding in fp32, tolerance 1e-4 vs the as-shipped reference"""
+    g = golden("threejoint")
+    be = cases.HostsimBackend("threejoint")
+    u, _ = cases.run_case(be, cases.CASES["threejoint:cfg5"], g, dtype=np.float32, rows=1024)
+    assert u.dtype == np.float32
+    r = cases.rel_err(u.astype(float), g["cfg5_uS"][:1024])
+    # J[:3] of the planar arm loses rank when the arm is (nearly) straight: pinv amplifies fp32 rounding there
+    q = g["cfg5_q"][:1024]
+    well = (np.abs(np.sin(q[:, 1])) > 0.05) & (np.abs(np.sin(q[:, 2])) > 0.05)
+    assert r[well].max() <= cases.TOL_F32, r[well].max()
+
+
+def test_rows_fp32_other_kernels():
+    g = golden("ur5")
+    be = cases.HostsimBackend("ur5")
+    cases.check_case_against_golden(be, "ur5:cfg2", g, dtype=np.float32, rows=512)
+    cases.check_case_against_golden(be, "ur5:joint", g, dtype=np.float32)
+
+
+def test_rows_twojoint_closed_forms():
+    """reference's analytic known answers (arms/tests/dummy_base_arm.py) on its test grids"""
+    k = golden("known_answers")
+    be = cases.HostsimBackend("twojoint")
+    Q = k["q_grid"]
+    for f in ("link0", "joint0", "link1", "joint1", "link2", "EE"):
+        r = be.dynamics(Q, None, f, None, ("Tx", "J", "R", "Tinv"))
+        assert np.allclose(r["Tx"], k[f"Tx_{f}"])
+        assert np.allclose(r["J"], k[f"J_{f}"])
+        assert np.allclose(r["R"], k[f"R_{f}"])
+        assert np.allclose(r["Tinv"], k[f"Tinv_{f}"])
+    r = be.dynamics(Q, None, "EE", None, ("M", "g"))
+    assert np.allclose(r["M"], k["M"]) and np.allclose(r["g"], k["g"])
+    QD = k["qdq_grid"]
+    for f in ("link0", "joint0", "link1", "joint1", "link2", "EE"):
+        r = be.dynamics(QD[:, :2], QD[:, 2:], f, None, ("dJ", "C"))
+        assert np.allclose(r["dJ"], k[f"dJ_{f}"])
+    assert np.allclose(r["C"], k["C"])
+
+
+def test_rows_external_null_signal_equals_fused():
+    """u_null_ext path (caller-evaluated secondary controller) == fused Damping (osc.py:310-318)"""
+    from abr_control_amd._abi import make_damping, make_osc_params as P
+
+    g = golden("jaco2")
+    be = cases.HostsimBackend("jaco2")
+    q, dq, t = g["cfg3_q"][:128], g["cfg3_dq"][:128], g["cfg3_target"][:128]
+    u_fused, _ = be.osc(P(6, kp=200, null_controllers=[make_damping(10)]), q, dq, t)
+    une = be.joint(make_damping(10), False, q, dq)
+    u_ext, _ = be.osc(P(6, kp=200), q, dq, t, une=une)
+    assert np.max(cases.rel_err(u_ext, u_fused)) < 1e-9
+    assert np.max(cases.rel_err(u_fused, g["cfg3_uD"][:128])) < 1e-6
+
+
+def test_rows_edge_inputs():
+    """angles far outside [0, 2pi), negative velocities, zero state, exact singular task"""
+    from abr_control_amd._abi import make_osc_params as P
+
+    be, orc = cases.HostsimBackend("ur5"), cases.OracleBackend("ur5")
+    rng = np.random.RandomState(7)
+    q = np.vstack([np.zeros(6), rng.uniform(-500, 500, (30, 6)), np.full(6, np.pi / 2)])
+    dq = rng.uniform(-8, 8, q.shape)
+    t = rng.uniform(-1, 1, (len(q), 6))
+    for p in (P(6, kp=200), P(6, kp=50, ko=30, ctrlr_dof=[1] * 6, orientation_algorithm=1)):
+        u, _ = be.osc(p, q, dq, t)
+        uo, _ = orc.osc(p, q, dq, t)
+        assert np.all(np.isfinite(u))
+        assert np.max(cases.rel_err(u, uo)) < 1e-6
+    # planar arm asked to control z as well: Mx_inv is exactly singular -> pinv truncation
+    be3, or3 = cases.HostsimBackend("threejoint"), cases.OracleBackend("threejoint")
+    q3, dq3, t3 = rng.uniform(0, 6, (32, 3)), rng.uniform(0, 5, (32, 3)), rng.uniform(-1, 1, (32, 6))
+    p = P(3, kp=40, ctrlr_dof=[1, 1, 1, 0, 0, 0])
+    u, _ = be3.osc(p, q3, dq3, t3)
+    uo, _ = or3.osc(p, q3, dq3, t3)
+    assert np.all(np.isfinite(u)) and np.max(cases.rel_err(u, uo)) < 1e-6
