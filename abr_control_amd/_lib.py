@@ -9,7 +9,7 @@ import numpy as np
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libabrk.so")
+LIB_PATH = os.environ.get("ABRK_LIB_PATH") or os.path.join(_HERE, "libabrk.so")  # env override: kernel-variant experiments
 _lib = None
 
 _vp = C.c_void_p

@@ -47,7 +47,7 @@ struct JointP {
 // ---------------------------------------------------------------- small dense algebra
 template <class T>
 ABRK_INL T rcp(T x) {
-  return T(1) / x;
+  return Rm<T>::rcp(x);
 }
 
 // Cholesky of a symmetric K x K matrix in lower-triangular packed storage.
@@ -57,17 +57,18 @@ ABRK_INL bool chol(const T (&S)[K * (K + 1) / 2], T (&L)[K * (K + 1) / 2], T (&i
   bool ok = true;
   sfor<K>([&](auto j) ABRK_LAMBDA {
     T dgn = S[tri(j(), j())];
-    sfor<j()>([&](auto k) ABRK_LAMBDA { dgn -= L[tri(j(), k())] * L[tri(j(), k())]; });
+    sfor<j()>([&](auto k) ABRK_LAMBDA { dgn = Rm<T>::fma(-L[tri(j(), k())], L[tri(j(), k())], dgn); });
     bool pos = dgn > T(0);
     ok = ok && pos;
-    T sq = Rm<T>::sqrt(pos ? dgn : T(1));
-    T inv = pos ? rcp(sq) : T(0);
-    L[tri(j(), j())] = sq;
+    T dsafe = pos ? dgn : T(1);
+    T rs = Rm<T>::rsqrt(dsafe);
+    T inv = pos ? rs : T(0);
+    L[tri(j(), j())] = dsafe * rs;
     il[j()] = inv;
     sfor<K - 1 - j()>([&](auto ii) ABRK_LAMBDA {
       constexpr int i = j() + 1 + ii();
       T acc = S[tri(i, j())];
-      sfor<j()>([&](auto k) ABRK_LAMBDA { acc -= L[tri(i, k())] * L[tri(j(), k())]; });
+      sfor<j()>([&](auto k) ABRK_LAMBDA { acc = Rm<T>::fma(-L[tri(i, k())], L[tri(j(), k())], acc); });
       L[tri(i, j())] = acc * inv;
     });
   });
@@ -78,7 +79,7 @@ template <int K, class T>
 ABRK_INL void chol_fwd(const T (&L)[K * (K + 1) / 2], const T (&il)[K], const T (&b)[K], T (&x)[K]) {
   sfor<K>([&](auto i) ABRK_LAMBDA {
     T acc = b[i()];
-    sfor<i()>([&](auto k) ABRK_LAMBDA { acc -= L[tri(i(), k())] * x[k()]; });
+    sfor<i()>([&](auto k) ABRK_LAMBDA { acc = Rm<T>::fma(-L[tri(i(), k())], x[k()], acc); });
     x[i()] = acc * il[i()];
   });
 }
@@ -90,7 +91,7 @@ ABRK_INL void chol_bwd(const T (&L)[K * (K + 1) / 2], const T (&il)[K], const T 
     T acc = b[i];
     sfor<K - 1 - i>([&](auto kk) ABRK_LAMBDA {
       constexpr int k = i + 1 + kk();
-      acc -= L[tri(k, i)] * x[k];
+      acc = Rm<T>::fma(-L[tri(k, i)], x[k], acc);
     });
     x[i] = acc * il[i];
   });
@@ -99,8 +100,8 @@ ABRK_INL void chol_bwd(const T (&L)[K * (K + 1) / 2], const T (&il)[K], const T 
 template <int K, class T>
 ABRK_INL void symv(const T (&S)[K * (K + 1) / 2], const T (&v)[K], T (&o)[K]) {
   sfor<K>([&](auto i) ABRK_LAMBDA {
-    T acc = T(0);
-    sfor<K>([&](auto j) ABRK_LAMBDA { acc += S[tri(i(), j())] * v[j()]; });
+    T acc = S[tri(i(), 0)] * v[0];
+    sfor<K - 1>([&](auto jj) ABRK_LAMBDA { acc = Rm<T>::fma(S[tri(i(), jj() + 1)], v[jj() + 1], acc); });
     o[i()] = acc;
   });
 }
@@ -112,7 +113,7 @@ ABRK_INL void chol_inverse(const T (&L)[K * (K + 1) / 2], const T (&il)[K], T (&
     Li[tri(j(), j())] = il[j()];
     sfor<K - 1 - j()>([&](auto ii) ABRK_LAMBDA {
       constexpr int i = j() + 1 + ii();
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<i - j()>([&](auto kk) ABRK_LAMBDA {
         constexpr int k = j() + kk();
         acc -= L[tri(i, k)] * Li[tri(k, j())];
@@ -122,7 +123,7 @@ ABRK_INL void chol_inverse(const T (&L)[K * (K + 1) / 2], const T (&il)[K], T (&
   });
   sfor<K>([&](auto i) ABRK_LAMBDA {
     sfor<i() + 1>([&](auto j) ABRK_LAMBDA {
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<K - i()>([&](auto kk) ABRK_LAMBDA {
         constexpr int k = i() + kk();
         acc += Li[tri(k, i())] * Li[tri(k, j())];
@@ -153,7 +154,7 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
         if (apq != T(0)) {
           T theta = (S[tri(q, q)] - S[tri(p, p)]) / (T(2) * apq);
           T t = (theta >= T(0) ? T(1) : T(-1)) / (Rm<T>::fabs(theta) + Rm<T>::sqrt(theta * theta + T(1)));
-          T c = rcp(Rm<T>::sqrt(t * t + T(1)));
+          T c = Rm<T>::rsqrt(t * t + T(1));
           T s = t * c;
           sfor<K>([&](auto k) ABRK_LAMBDA {
             if constexpr (k() != p && k() != q) {
@@ -191,7 +192,7 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P
     sfor<3>([&](auto qq) ABRK_LAMBDA {
       sfor<qq()>([&](auto pp) ABRK_LAMBDA {
         constexpr int p = pp(), q = qq();
-        T alpha = T(0), beta = T(0), gamma = T(0);
+        T alpha = T(-0.0), beta = T(-0.0), gamma = T(-0.0);
         sfor<N>([&](auto i) ABRK_LAMBDA {
           alpha += G[i()][p] * G[i()][p];
           beta += G[i()][q] * G[i()][q];
@@ -202,7 +203,7 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P
           worst = Rm<T>::fmax(worst, Rm<T>::fabs(gamma) / lim);
           T zeta = (beta - alpha) / (T(2) * gamma);
           T t = (zeta >= T(0) ? T(1) : T(-1)) / (Rm<T>::fabs(zeta) + Rm<T>::sqrt(T(1) + zeta * zeta));
-          T c = rcp(Rm<T>::sqrt(T(1) + t * t));
+          T c = Rm<T>::rsqrt(T(1) + t * t);
           T s = c * t;
           sfor<N>([&](auto i) ABRK_LAMBDA {
             T gp = G[i()][p], gq = G[i()][q];
@@ -221,7 +222,7 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P
   }
   T sig2[3], smax2 = T(0);
   sfor<3>([&](auto j) ABRK_LAMBDA {
-    T acc = T(0);
+    T acc = T(-0.0);
     sfor<N>([&](auto i) ABRK_LAMBDA { acc += G[i()][j()] * G[i()][j()]; });
     sig2[j()] = acc;
     smax2 = Rm<T>::fmax(smax2, acc);
@@ -231,7 +232,7 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P
   sfor<3>([&](auto j) ABRK_LAMBDA { w[j()] = (Rm<T>::sqrt(sig2[j()]) > cut) ? rcp(sig2[j()]) : T(0); });
   sfor<N>([&](auto i) ABRK_LAMBDA {
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<3>([&](auto j) ABRK_LAMBDA { acc += G[i()][j()] * V[r()][j()] * w[j()]; });
       P[i()][r()] = acc;
     });
@@ -276,7 +277,7 @@ ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
   });
   sfor<3>([&](auto it) ABRK_LAMBDA {
     T nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    T inv = rcp(Rm<T>::sqrt(nn));
+    T inv = Rm<T>::rsqrt(nn);
     T w[4];
     sfor<4>([&](auto i) ABRK_LAMBDA {
       w[i()] = (Bm[i()][0] * v[0] + Bm[i()][1] * v[1] + Bm[i()][2] * v[2] + Bm[i()][3] * v[3]) * inv;
@@ -284,7 +285,7 @@ ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
     sfor<4>([&](auto i) ABRK_LAMBDA { v[i()] = w[i()]; });
   });
   T nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-  T inv = rcp(Rm<T>::sqrt(nn));
+  T inv = Rm<T>::rsqrt(nn);
   T sg = (v[3] < T(0)) ? -inv : inv;
   qo[0] = v[3] * sg;
   qo[1] = v[0] * sg;
@@ -309,7 +310,7 @@ ABRK_INL void quat_from_euler_rxyz(T ai, T aj, T ak, T (&q)[4]) {
   q[3] = cj * sc - sj * cs;
   q[2] = -(cj * ss + sj * cc);
   q[1] = cj * cs - sj * sc;
-  T inv = rcp(Rm<T>::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));
+  T inv = Rm<T>::rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   sfor<4>([&](auto i) ABRK_LAMBDA { q[i()] *= inv; });
 }
 
@@ -405,10 +406,14 @@ ABRK_INL void null_command(const NullP<T>& c, const T (&q)[N], const T (&dq)[N],
 // KM = 3 (FAST: task rows are exactly x,y,z of the EE) or 6 (all six task rows, unselected
 // rows masked: their Jacobian row is zeroed and Mx_inv gets a unit diagonal there, which
 // leaves det, the inverse and the singular values of the selected block unchanged).
-template <class A, class T, int KM, bool USE_C>
+// `late()` loads the inputs that are not needed by the kinematics (target, velocities, state; dq
+// too unless the Coriolis term is on) - it is invoked after the register-pressure peak.
+// FEAT = false compiles out the optional inputs (target velocity, integral state, secondary
+// controllers): the plain law needs ~70 registers fewer and fits two waves per SIMD.
+template <class A, class T, int KM, bool USE_C, bool FEAT, class Late>
 ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
                       bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
-                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N]) {
+                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late) {
   constexpr int N = A::N;
   constexpr bool FAST = (KM == 3);
   Joints<A, T> jt;
@@ -443,6 +448,8 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   // task Jacobian, rows masked (osc.py:242-244)
   T Jv[N][3], Jw[N][3];
   jacobian(jt, p, m, Jv, Jw);
+  ABRK_SCHED_FENCE();
+  late();
   T Jr[N][KM];
   bool sel[KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA {
@@ -467,7 +474,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   T trace = T(0);
   sfor<KM>([&](auto r) ABRK_LAMBDA {
     sfor<r() + 1>([&](auto c) ABRK_LAMBDA {
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<N>([&](auto i) ABRK_LAMBDA { acc += Y[i()][r()] * Y[i()][c()]; });
       Am[tri(r(), c())] = acc;
     });
@@ -502,7 +509,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
       sfor<KM>([&](auto r) ABRK_LAMBDA { wv[r()] = (Rm<T>::fabs(lam[r()]) > cut) ? rcp(lam[r()]) : T(0); });
       sfor<KM>([&](auto a) ABRK_LAMBDA {
         sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
-          T acc = T(0);
+          T acc = T(-0.0);
           sfor<KM>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
           Mx[tri(a(), b())] = acc;
         });
@@ -521,7 +528,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     }
   }
   // integral term (osc.py:262-264)
-  if (have_ierr) {
+  if (FEAT && have_ierr) {
     sfor<6>([&](auto r) ABRK_LAMBDA {
       ierr[r()] += ut[r()];
       ut[r()] += P.ki * ierr[r()];
@@ -547,14 +554,14 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   }
   // velocity compensation (osc.py:274-282)
   bool tv_zero = true;
-  if (tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
+  if (FEAT && tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
   T Mdq[N];
   symv<N>(d.Ms, dq, Mdq);
   if (tv_zero) {
     sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(-1) * P.kv * Mdq[i()]; });
   } else {
     sfor<6>([&](auto r) ABRK_LAMBDA {
-      T dx = T(0);
+      T dx = T(-0.0);
       if constexpr (r() < KM) {
         sfor<N>([&](auto i) ABRK_LAMBDA { dx += Jr[i()][r()] * dq[i()]; });
       }
@@ -567,7 +574,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
   symv<KM>(Mx, uts, f);
   sfor<N>([&](auto i) ABRK_LAMBDA {
-    T acc = T(0);
+    T acc = T(-0.0);
     sfor<KM>([&](auto r) ABRK_LAMBDA { acc += Jr[i()][r()] * f[r()]; });
     u[i()] -= acc;
   });
@@ -577,7 +584,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
 
   // secondary controllers through the null-space filter I - J^T Jbar^T (osc.py:310-318).
   // With u_null = M v the filtered signal is M v - J^T Mx (J v) (Jbar^T M = Mx J).
-  if (P.n_null > 0 || have_ext) {
+  if (FEAT && (P.n_null > 0 || have_ext)) {
     T v[N];
     sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = T(0); });
     for (int c = 0; c < P.n_null; c++) null_command<N>(P.nul[c], q, dq, v);
@@ -595,13 +602,13 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     }
     T jv[KM], f2[KM];
     sfor<KM>([&](auto r) ABRK_LAMBDA {
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<N>([&](auto i) ABRK_LAMBDA { acc += Jr[i()][r()] * v[i()]; });
       jv[r()] = acc;
     });
     symv<KM>(Mx, jv, f2);
     sfor<N>([&](auto i) ABRK_LAMBDA {
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<KM>([&](auto r) ABRK_LAMBDA { acc += Jr[i()][r()] * f2[r()]; });
       u[i()] += un[i()] - acc;
     });
@@ -634,14 +641,14 @@ ABRK_INL void sliding_row(const A& arm, const SlidingP<T>& P, const T (&q)[A::N]
     pinv_3xN<N>(Jv, T(1e-15), Ji);
     T dx[3], a[3], w[3];
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<N>([&](auto i) ABRK_LAMBDA { acc += Jv[i()][r()] * dq[i()]; });
       dx[r()] = acc;
       a[r()] = tv[r()] + P.lamb * (tgt[r()] - p[r()]);
     });
     sfor<N>([&](auto i) ABRK_LAMBDA { dq_ref[i()] = Ji[i()][0] * a[0] + Ji[i()][1] * a[1] + Ji[i()][2] * a[2]; });
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      T acc = T(0);
+      T acc = T(-0.0);
       sfor<N>([&](auto i) ABRK_LAMBDA { acc += dJv[i()][r()] * dq_ref[i()]; });
       w[r()] = ta[r()] + P.lamb * (tv[r()] - dx[r()]) - acc;
     });
@@ -656,7 +663,7 @@ ABRK_INL void sliding_row(const A& arm, const SlidingP<T>& P, const T (&q)[A::N]
   symv<N>(d.Ms, ddq_ref, a1);
   sfor<N>([&](auto i) ABRK_LAMBDA {
     s[i()] = dq[i()] - dq_ref[i()];
-    T a2 = T(0);
+    T a2 = T(-0.0);
     sfor<N>([&](auto j) ABRK_LAMBDA { a2 += d.Cm[i() * N + j()] * dq_ref[j()]; });
     u[i()] = a1[i()] + a2 + T(-9.81) * d.gz[i()] - P.kd * s[i()];
   });

@@ -30,6 +30,13 @@
 #endif
 #define ABRK_INL ABRK_HD __forceinline__
 #define ABRK_LAMBDA __attribute__((always_inline))
+// Scheduling fence: keeps the late input loads (and everything after) below the forward-kinematics
+// phase so their registers are not live during the register-pressure peak.  No-op on the host.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ABRK_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define ABRK_SCHED_FENCE() ((void)0)
+#endif
 
 namespace abrk {
 
@@ -52,12 +59,83 @@ template <class T>
 struct Rm;
 template <>
 struct Rm<double> {
-  static ABRK_INL void sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+  // a*b + c with c held in scalar registers (see sincos)
+  static ABRK_INL double fma_sc(double a, double b, double c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return ::fma(a, b, c);
+#endif
+  }
+  // sin and cos of a joint angle.  Joint angles are moderate (|x| < 1e5), so the argument is
+  // reduced with a 3-term Cody-Waite split of pi/2 under fma (exact products) and the two
+  // kernels are degree-13/14 minimax polynomials on [-pi/4, pi/4]: ~25 fp64 instructions
+  // against ~65 on the main path of the library sincos (whose double-double reduction serves
+  // |x| up to 2^1024).  Absolute error <= 1.2e-16; larger arguments take the library path.
+  static ABRK_INL void sincos(double x, double& s, double& c) {
+    if (!(::fabs(x) < 1.0e5)) {
+      ::sincos(x, &s, &c);
+      return;
+    }
+    const double n = ::rint(x * 0.6366197723675814);
+    double r = ::fma(-n, 1.5707963267948966, x);
+    r = ::fma(-n, 6.123233995736766e-17, r);
+    r = ::fma(-n, -1.4973849048591698e-33, r);
+    const double z = r * r;
+    // Horner steps p*z + c with the coefficient c as a SCALAR source operand: the compiler's
+    // default (v_fmac with c pre-loaded into the destination VGPR pair) costs two v_mov per
+    // coefficient - a third of this routine's vector instructions.
+    double ps = fma_sc(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma_sc(z, ps, 2.75573137070700676789e-06);
+    ps = fma_sc(z, ps, -1.98412698298579493134e-04);
+    ps = fma_sc(z, ps, 8.33333333332248946124e-03);
+    ps = fma_sc(z, ps, -1.66666666666666324348e-01);
+    const double sr = ::fma(z * r, ps, r);
+    double pc = fma_sc(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma_sc(z, pc, -2.75573143513906633035e-07);
+    pc = fma_sc(z, pc, 2.48015872894767294178e-05);
+    pc = fma_sc(z, pc, -1.38888888888741095749e-03);
+    pc = fma_sc(z, pc, 4.16666666666666019037e-02);
+    const double cr = ::fma(z * z, pc, ::fma(z, -0.5, 1.0));
+    const int k = (int)n;
+    const bool swap = (k & 1) != 0;
+    const double ss = swap ? cr : sr, cs = swap ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cs : cs;
+  }
   static ABRK_INL double sqrt(double x) { return ::sqrt(x); }
   static ABRK_INL double fabs(double x) { return ::fabs(x); }
   static ABRK_INL double fma(double a, double b, double c) { return ::fma(a, b, c); }
   static ABRK_INL double fmod(double a, double b) { return ::fmod(a, b); }
   static ABRK_INL double fmax(double a, double b) { return ::fmax(a, b); }
+  // 1/x and 1/sqrt(x) from the hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-23 relative) plus two
+  // Newton steps -> ~1-2 ulp in 5 / 9 instructions instead of the 11 + 12 of an IEEE divide and
+  // sqrt.  x must be a normal positive number (pivots of SPD factorizations here).
+  static ABRK_INL double rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = ::fma(-x, y, 1.0);
+    y = ::fma(y, e, y);
+    e = ::fma(-x, y, 1.0);
+    return ::fma(y, e, y);
+#else
+    return 1.0 / x;
+#endif
+  }
+  static ABRK_INL double rsqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rsq(x);
+    double h = 0.5 * x;
+    double e = ::fma(-h * y, y, 0.5);
+    y = ::fma(y, e, y);
+    e = ::fma(-h * y, y, 0.5);
+    return ::fma(y, e, y);
+#else
+    return 1.0 / ::sqrt(x);
+#endif
+  }
   static constexpr double eps() { return 2.220446049250313e-16; }
   static constexpr double tiny() { return 1e-300; }
 };
@@ -69,6 +147,24 @@ struct Rm<float> {
   static ABRK_INL float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
   static ABRK_INL float fmod(float a, float b) { return ::fmodf(a, b); }
   static ABRK_INL float fmax(float a, float b) { return ::fmaxf(a, b); }
+  static ABRK_INL float rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float y = __builtin_amdgcn_rcpf(x);
+    float e = ::fmaf(-x, y, 1.0f);
+    return ::fmaf(y, e, y);
+#else
+    return 1.0f / x;
+#endif
+  }
+  static ABRK_INL float rsqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float y = __builtin_amdgcn_rsqf(x);
+    float e = ::fmaf(-0.5f * x * y, y, 0.5f);
+    return ::fmaf(y, e, y);
+#else
+    return 1.0f / ::sqrtf(x);
+#endif
+  }
   static constexpr float eps() { return 1.1920929e-07f; }
   static constexpr float tiny() { return 1e-37f; }
 };
@@ -83,6 +179,12 @@ ABRK_INL void cross3(const T (&a)[3], const T (&b)[3], T (&o)[3]) {
 template <class T>
 ABRK_INL T dot3(const T (&a)[3], const T (&b)[3]) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+// acc + a.b as an fma chain (one op fewer than dot3 + add; no reassociation is implied
+// elsewhere: the kernels are compiled with strict IEEE semantics)
+template <class T>
+ABRK_INL T fdot3(T acc, const T (&a)[3], const T (&b)[3]) {
+  return Rm<T>::fma(a[2], b[2], Rm<T>::fma(a[1], b[1], Rm<T>::fma(a[0], b[0], acc)));
 }
 template <class T>
 ABRK_INL void matvec3(const T (&M)[9], const T (&v)[3], T (&o)[3]) {
@@ -331,7 +433,7 @@ ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (
       T r0[3], r1[3];
       cross3(c1, c2, r0);
       cross3(c2, c0, r1);
-      T idet = T(1) / dot3(c0, r0);
+      T idet = Rm<T>::rcp(dot3(c0, r0));
       sfor<3>([&](auto a) ABRK_LAMBDA {
         sfor<3>([&](auto b) ABRK_LAMBDA {
           jt.W[I][a() * 3 + b()] = (c1[a()] * r0[b()] - c0[a()] * r1[b()]) * idet;
@@ -411,7 +513,7 @@ ABRK_INL void omega_apply(const Joints<A, T>& jt, const Dyn<A, T, CM>& d, const 
   } else if constexpr (A::kOrtho) {
     cross3(d.om[J], v, out);
   } else {
-    T acc[3] = {T(0), T(0), T(0)};
+    T acc[3] = {T(-0.0), T(-0.0), T(-0.0)};
     sfor<J>([&](auto k) ABRK_LAMBDA {
       T t[3];
       wapply<k()>(jt, v, t);
@@ -443,18 +545,15 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
     wapply<i()>(jt, dlt, e[i()]);
   });
   T m0 = AccMD<A, T, L, 0>::get(arm), m1 = AccMD<A, T, L, 1>::get(arm), m2 = AccMD<A, T, L, 2>::get(arm);
-  T me[NJ][3];  // D_l e_i
   sfor<NJ>([&](auto i) ABRK_LAMBDA {
-    me[i()][0] = m0 * e[i()][0];
-    me[i()][1] = m1 * e[i()][1];
-    me[i()][2] = m2 * e[i()][2];
-    d.gz[i()] += me[i()][2];
-    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] += dot3(me[i()], e[j()]); });
+    T me[3] = {m0 * e[i()][0], m1 * e[i()][1], m2 * e[i()][2]};  // D_l e_i (transient)
+    d.gz[i()] += me[2];
+    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = fdot3(d.Ms[tri(i(), j())], me, e[j()]); });
   });
   if constexpr (CM != CMODE_NONE) {
-    T s[3] = {T(0), T(0), T(0)};
-    T a[3] = {T(0), T(0), T(0)};  // COM bias acceleration  Edot dq
-    T ed[NJ][3];
+    T s[3] = {T(-0.0), T(-0.0), T(-0.0)};
+    T a[3] = {T(-0.0), T(-0.0), T(-0.0)};  // COM bias acceleration  Edot dq
+    T ed[CM == CMODE_MAT ? NJ : 1][3];
     sfor<NJ>([&](auto jr) ABRK_LAMBDA {
       constexpr int j = NJ - 1 - jr();
       sfor<3>([&](auto r) ABRK_LAMBDA { s[r()] += e[j][r()] * dq[j]; });
@@ -462,15 +561,18 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
       wapply<j>(jt, s, t1);
       omega_apply<j>(jt, d, dq, e[j], t2);
       sfor<3>([&](auto r) ABRK_LAMBDA {
-        ed[j][r()] = t1[r()] + t2[r()];
-        a[r()] += dq[j] * ed[j][r()];
+        T edj = t1[r()] + t2[r()];
+        a[r()] += dq[j] * edj;
+        if constexpr (CM == CMODE_MAT) ed[j][r()] = edj;
       });
     });
     if constexpr (CM == CMODE_VEC) {
-      sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] += dot3(me[k()], a); });
+      T ma[3] = {m0 * a[0], m1 * a[1], m2 * a[2]};
+      sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], e[k()], ma); });
     } else {
-      sfor<NJ>([&](auto k) ABRK_LAMBDA {
-        sfor<NJ>([&](auto j) ABRK_LAMBDA { d.Cm[k() * A::N + j()] += dot3(me[k()], ed[j()]); });
+      sfor<NJ>([&](auto j) ABRK_LAMBDA {
+        T med[3] = {m0 * ed[j()][0], m1 * ed[j()][1], m2 * ed[j()][2]};
+        sfor<NJ>([&](auto k) ABRK_LAMBDA { d.Cm[k() * A::N + j()] = fdot3(d.Cm[k() * A::N + j()], e[k()], med); });
       });
     }
   }
@@ -479,16 +581,15 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
 template <class A, class T, int CM>
 ABRK_INL void dyn_init(Dyn<A, T, CM>& d) {
   constexpr int N = A::N;
-  sfor<N*(N + 1) / 2>([&](auto e) ABRK_LAMBDA { d.Ms[e()] = T(0); });
-  sfor<N>([&](auto i) ABRK_LAMBDA { d.gz[i()] = T(0); });
-  if constexpr (CM == CMODE_MAT) sfor<N * N>([&](auto e) ABRK_LAMBDA { d.Cm[e()] = T(0); });
-  if constexpr (CM == CMODE_VEC) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(0); });
+  sfor<N*(N + 1) / 2>([&](auto e) ABRK_LAMBDA { d.Ms[e()] = T(-0.0); });  // -0.0: exact additive identity, lets the first fma fold to a mul
+  sfor<N>([&](auto i) ABRK_LAMBDA { d.gz[i()] = T(-0.0); });
+  if constexpr (CM == CMODE_MAT) sfor<N * N>([&](auto e) ABRK_LAMBDA { d.Cm[e()] = T(-0.0); });
+  if constexpr (CM == CMODE_VEC) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(-0.0); });
 }
 
 // weighted dot  sum_r Isuf(m,r) a[r] b[r]
 template <int Mx, class A, class T>
-ABRK_INL T idot(const A& arm, const T (&a)[3], const T (&b)[3]) {
-  T acc = T(-0.0);
+ABRK_INL T idot(const A& arm, const T (&a)[3], const T (&b)[3], T acc = T(-0.0)) {
   sfor<3>([&](auto r) ABRK_LAMBDA { acc = cfma<AccIsuf<A, T, Mx, r()>>(arm, a[r()] * b[r()], acc); });
   return acc;
 }
@@ -499,10 +600,42 @@ template <class A, class T, int CM>
 ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
   constexpr int N = A::N;
   sfor<N>([&](auto i) ABRK_LAMBDA {
-    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] += idot<i()>(arm, jt.z[i()], jt.z[j()]); });
+    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = idot<i()>(arm, jt.z[i()], jt.z[j()], d.Ms[tri(i(), j())]); });
   });
-  if constexpr (CM == CMODE_VEC) {
-    // c^w_k = zdot_k.y_k + z_k.y'_k - sum_{i>k} dq_i (W_k z_i).y_i
+  if constexpr (CM == CMODE_VEC && A::kOrtho) {
+    // c^w_k = zdot_k.y_k + z_k.y'_k - sum_{i>k} dq_i (z_k x z_i).y_i        (zdot_i = omega_i x z_i)
+    //   y_k  = Ibar_k o (sum_{i<=k} z_i dq_i)    + sum_{i>k} Ibar_i o (z_i dq_i)
+    //   y'_k = Ibar_k o (sum_{i<=k} zdot_i dq_i) + sum_{i>k} Ibar_i o (zdot_i dq_i)
+    // evaluated in ONE backward sweep with four running 3-vectors (no per-joint arrays: this
+    // phase used to hold 54 extra doubles live), using (z_k x z_i).y_i = z_k.(z_i x y_i).
+    T pall[3] = {T(-0.0), T(-0.0), T(-0.0)};  // sum_i zdot_i dq_i
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      T zd[3];
+      cross3(d.om[i()], jt.z[i()], zd);
+      sfor<3>([&](auto r) ABRK_LAMBDA { pall[r()] += zd[r()] * dq[i()]; });
+    });
+    T Q[3] = {T(0), T(0), T(0)}, Qp[3] = {T(0), T(0), T(0)}, Sp[3] = {T(0), T(0), T(0)}, Rr[3] = {T(0), T(0), T(0)};
+    sfor<N>([&](auto kr) ABRK_LAMBDA {
+      constexpr int k = N - 1 - kr();
+      T zd[3], y[3], yp[3], zy[3];
+      cross3(d.om[k], jt.z[k], zd);
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        T pk = d.om[k][r()] + jt.z[k][r()] * dq[k];  // sum_{i<=k} z_i dq_i
+        y[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, pk, Q[r()]);
+        yp[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, pall[r()] - Sp[r()], Qp[r()]);
+      });
+      d.cv[k] += dot3(zd, y) + dot3(jt.z[k], yp) - dot3(jt.z[k], Rr);
+      cross3(jt.z[k], y, zy);
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        Q[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, jt.z[k][r()] * dq[k], Q[r()]);
+        Qp[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, zd[r()] * dq[k], Qp[r()]);
+        Sp[r()] += zd[r()] * dq[k];
+        Rr[r()] += dq[k] * zy[r()];
+      });
+    });
+  }
+  if constexpr (CM == CMODE_VEC && !A::kOrtho) {
+    // general affine chain: c^w_k = zdot_k.y_k + z_k.y'_k - sum_{i>k} dq_i (W_k z_i).y_i
     //   y_k  = sum_i Ibar_max(k,i) o (z_i dq_i),   y'_k = sum_i Ibar_max(k,i) o (zdot_i dq_i)
     T zd[N][3];
     sfor<N>([&](auto k) ABRK_LAMBDA { omega_apply<k()>(jt, d, dq, jt.z[k()], zd[k()]); });
@@ -542,14 +675,14 @@ ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)
     });
     auto dM = [&](auto a, auto b, auto c) ABRK_LAMBDA -> T {
       constexpr int m = (a() > b() ? a() : b());
-      T acc = T(0);
+      T acc = T(-0.0);
       if constexpr (c() < a()) acc += idot<m>(arm, X[c()][a()], jt.z[b()]);
       if constexpr (c() < b()) acc += idot<m>(arm, jt.z[a()], X[c()][b()]);
       return acc;
     };
     sfor<N>([&](auto k) ABRK_LAMBDA {
       sfor<N>([&](auto j) ABRK_LAMBDA {
-        T acc = T(0);
+        T acc = T(-0.0);
         sfor<N>([&](auto i) ABRK_LAMBDA { acc += (dM(k, j, i) + dM(k, i, j) - dM(i, j, k)) * dq[i()]; });
         d.Cm[k() * N + j()] += T(0.5) * acc;
       });
@@ -613,7 +746,7 @@ ABRK_INL void jacobian_dot(const Joints<A, T>& jt, const T (&dq)[A::N], const T 
       sfor<3>([&](auto r) ABRK_LAMBDA { tmp.om[j() + 1][r()] = tmp.om[j()][r()] + dq[j()] * jt.z[j()][r()]; });
     });
   }
-  T s[3] = {T(0), T(0), T(0)};
+  T s[3] = {T(-0.0), T(-0.0), T(-0.0)};
   sfor<N>([&](auto jr) ABRK_LAMBDA {
     constexpr int j = N - 1 - jr();
     sfor<3>([&](auto r) ABRK_LAMBDA { s[r()] += Jv[j][r()] * dq[j]; });  // Jv is already 0 for j >= m

@@ -6,31 +6,69 @@
 
 namespace abrk {
 
-constexpr int kBlock = 64;  // one wavefront per workgroup: rows are independent, no LDS sharing
+#ifndef ABRK_BLOCK
+#define ABRK_BLOCK 64
+#endif
+#ifndef ABRK_MIN_WAVES
+#define ABRK_MIN_WAVES 1
+#endif
+constexpr int kBlock = ABRK_BLOCK;  // rows are independent, no LDS sharing: one wavefront per workgroup
 
 #define ABRK_ROW_INDEX                                     \
   long b = (long)blockIdx.x * kBlock + threadIdx.x;        \
   if (b >= B) return;
 
+// Cooperative, coalesced row stores: each lane parks its row in the wavefront's LDS slab (odd
+// row stride -> conflict-free ds_write), then the 64 lanes stream the slab out in linear order,
+// 512 contiguous bytes per store instruction.  The row-per-lane alternative writes 64 separate
+// 8-byte pieces per instruction and is what makes the full-output mode HBM-inefficient.
+constexpr int kMaxRow = 6 * 7;  // widest output row (J / dJ of a 7-joint arm = ABRK_MAX_JOINTS)
+template <class T>
+struct LdsStore {
+  T* buf;
+  long row0, B;
+  int lane;
+  template <int R>
+  __device__ __forceinline__ void put(T* __restrict__ out, long, bool, const T (&v)[R]) {
+    constexpr int S = R | 1;
+    sfor<R>([&](auto k) ABRK_LAMBDA { buf[lane * S + k()] = v[k()]; });
+    __syncthreads();
+    const long left = B - row0;
+    const int total = (int)(left < kBlock ? left : (long)kBlock) * R;
+    T* o = out + row0 * R;
+    sfor<R>([&](auto j) ABRK_LAMBDA {
+      const int e = lane + kBlock * j();
+      if (e < total) {
+        const int row = e / R, k = e - row * R;
+        o[e] = buf[row * S + k];
+      }
+    });
+    __syncthreads();
+  }
+};
+
 template <class A, class T, bool WITH_DQ>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, const T* __restrict__ qg,
            const T* __restrict__ dqg, DynOutP<T> out) {
-  ABRK_ROW_INDEX
-  dyn_body<A, T, WITH_DQ>(b, arm, frame, m, ox, oy, oz, want, B, qg, dqg, out);
+  __shared__ T slab[kBlock * (kMaxRow | 1)];
+  const long row0 = (long)blockIdx.x * kBlock;
+  const long b = row0 + threadIdx.x;
+  LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
+  dyn_body<A, T, WITH_DQ>(b, b < B, st, arm, frame, m, ox, oy, oz, want, B, qg, dqg, out);
 }
 
-template <class A, class T, int KM, bool USE_C>
-__global__ void __launch_bounds__(kBlock)
+template <class A, class T, int KM, bool USE_C, bool FEAT>
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
   ABRK_ROW_INDEX
-  osc_body<A, T, KM, USE_C>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg);
+  osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg);
 }
 
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 sliding_kernel(A arm, SlidingP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                const T* __restrict__ tg, const T* __restrict__ tvg, const T* __restrict__ tag,
                T* __restrict__ ug, T* __restrict__ sg) {
@@ -39,7 +77,7 @@ sliding_kernel(A arm, SlidingP<T> P, long B, const T* __restrict__ qg, const T* 
 }
 
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 joint_kernel(A arm, JointP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
              const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ug) {
   ABRK_ROW_INDEX
@@ -85,7 +123,6 @@ struct ArmOps {
 };
 
 inline dim3 grid_for(long B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
-
 template <class A, class T>
 struct Launch {
   static A arm_of(const LaunchArgs& la) {
@@ -105,19 +142,26 @@ struct Launch {
                          T(a.off[0]), T(a.off[1]), T(a.off[2]), a.want, la.B, (const T*)a.q, (const T*)a.dq, o);
     return hipGetLastError();
   }
-  template <int KM, bool UC>
+  template <int KM, bool UC, bool FEAT>
   static void osc_launch(const LaunchArgs& la, const OscArgs& a) {
-    hipLaunchKernelGGL((osc_kernel<A, T, KM, UC>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
+    hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
                        *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
                        (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts);
   }
+  template <int KM, bool UC>
+  static void osc_launch_feat(const LaunchArgs& la, const OscArgs& a) {
+    // optional inputs present?  (target velocity, integral state, fused / external null signals)
+    const bool feat = a.tv || a.ierr || a.une || static_cast<const OscP<T>*>(a.P)->n_null > 0;
+    if (feat) osc_launch<KM, UC, true>(la, a);
+    else osc_launch<KM, UC, false>(la, a);
+  }
   static hipError_t osc(const LaunchArgs& la, const OscArgs& a) {
     if (a.fast) {
-      if (a.use_C) osc_launch<3, true>(la, a);
-      else osc_launch<3, false>(la, a);
+      if (a.use_C) osc_launch_feat<3, true>(la, a);
+      else osc_launch_feat<3, false>(la, a);
     } else {
-      if (a.use_C) osc_launch<6, true>(la, a);
-      else osc_launch<6, false>(la, a);
+      if (a.use_C) osc_launch_feat<6, true>(la, a);
+      else osc_launch_feat<6, false>(la, a);
     }
     return hipGetLastError();
   }

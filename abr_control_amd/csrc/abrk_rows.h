@@ -29,14 +29,29 @@ ABRK_INL void store_row(T* __restrict__ base, long b, const T (&v)[N]) {
   sfor<N>([&](auto i) ABRK_LAMBDA { p[i()] = v[i()]; });
 }
 
+// Output policies of the dynamics program.  DirectStore: each lane writes its own row (host
+// check build; rows of 24..288 bytes at a 24..288-byte lane stride are badly coalesced).
+// The GPU kernel uses LdsStore (abrk_kernels.h): rows are transposed through LDS so that every
+// store instruction of the wavefront writes 512 contiguous bytes.
+template <class T>
+struct DirectStore {
+  template <int R>
+  ABRK_INL void put(T* __restrict__ out, long b, bool active, const T (&v)[R]) {
+    if (active) store_row<R>(out, b, v);
+  }
+};
+
 // ---- robot_config.{Tx,J,M,g,C,dJ,R,T,T_inv,quaternion} for B states (base_config.py:210-415)
-template <class A, class T, bool WITH_DQ>
-ABRK_INL void dyn_body(long b, const A& arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, const T* __restrict__ qg,
-           const T* __restrict__ dqg, const DynOutP<T>& out) {
+// `b` may be past the end for the padding lanes of the last wavefront (active = false): they
+// evaluate a clamped row and only take part in the cooperative stores.
+template <class A, class T, bool WITH_DQ, class St>
+ABRK_INL void dyn_body(long b, bool active, St& st, const A& arm, int frame, int m, T ox, T oy, T oz, unsigned want,
+                       long B, const T* __restrict__ qg, const T* __restrict__ dqg, const DynOutP<T>& out) {
   constexpr int N = A::N;
+  const long bl = active ? b : B - 1;
   T q[N], dq[N];
-  load_row<N>(qg, b, q);
-  if constexpr (WITH_DQ) load_row<N>(dqg, b, dq);
+  load_row<N>(qg, bl, q);
+  if constexpr (WITH_DQ) load_row<N>(dqg, bl, dq);
   else sfor<N>([&](auto i) ABRK_LAMBDA { dq[i()] = T(0); });
   Joints<A, T> jt;
   Dyn<A, T, WITH_DQ ? CMODE_MAT : CMODE_NONE> d;
@@ -50,91 +65,104 @@ ABRK_INL void dyn_body(long b, const A& arm, int frame, int m, T ox, T oy, T oz,
   sfor<3>([&](auto r) ABRK_LAMBDA {
     p[r()] = cap.o[r()] + cap.R[r() * 3] * ox + cap.R[r() * 3 + 1] * oy + cap.R[r() * 3 + 2] * oz;
   });
-  if (want & W_TX) store_row<3>(out.Tx, b, p);
+  if (want & W_TX) st.template put<3>(out.Tx, b, active, p);
   if (want & (W_J | W_DJ)) {
     T Jv[N][3], Jw[N][3];
     jacobian(jt, p, m, Jv, Jw);
     if (want & W_J) {
-      T* o = out.J + b * 6 * N;
+      T row[6 * N];
       sfor<3>([&](auto r) ABRK_LAMBDA {
         sfor<N>([&](auto i) ABRK_LAMBDA {
-          o[r() * N + i()] = Jv[i()][r()];
-          o[(3 + r()) * N + i()] = Jw[i()][r()];
+          row[r() * N + i()] = Jv[i()][r()];
+          row[(3 + r()) * N + i()] = Jw[i()][r()];
         });
       });
+      st.template put<6 * N>(out.J, b, active, row);
     }
     if constexpr (WITH_DQ) {
       if (want & W_DJ) {
         T dJv[N][3], dJw[N][3];
         jacobian_dot(jt, dq, Jv, m, dJv, dJw);
-        T* o = out.dJ + b * 6 * N;
+        T row[6 * N];
         sfor<3>([&](auto r) ABRK_LAMBDA {
           sfor<N>([&](auto i) ABRK_LAMBDA {
-            o[r() * N + i()] = dJv[i()][r()];
-            o[(3 + r()) * N + i()] = dJw[i()][r()];
+            row[r() * N + i()] = dJv[i()][r()];
+            row[(3 + r()) * N + i()] = dJw[i()][r()];
           });
         });
+        st.template put<6 * N>(out.dJ, b, active, row);
       }
     }
   }
   if (want & W_M) {
-    T* o = out.M + b * N * N;
-    sfor<N>([&](auto i) ABRK_LAMBDA { sfor<N>([&](auto j) ABRK_LAMBDA { o[i() * N + j()] = d.Ms[tri(i(), j())]; }); });
+    T row[N * N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { sfor<N>([&](auto j) ABRK_LAMBDA { row[i() * N + j()] = d.Ms[tri(i(), j())]; }); });
+    st.template put<N * N>(out.M, b, active, row);
   }
   if (want & W_G) {
-    T* o = out.g + b * N;
-    sfor<N>([&](auto i) ABRK_LAMBDA { o[i()] = T(-9.81) * d.gz[i()]; });
+    T row[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = T(-9.81) * d.gz[i()]; });
+    st.template put<N>(out.g, b, active, row);
   }
   if constexpr (WITH_DQ) {
-    if (want & W_C) {
-      T* o = out.C + b * N * N;
-      sfor<N * N>([&](auto e) ABRK_LAMBDA { o[e()] = d.Cm[e()]; });
-    }
+    if (want & W_C) st.template put<N * N>(out.C, b, active, d.Cm);
   }
-  if (want & W_R) store_row<9>(out.R, b, cap.R);
+  if (want & W_R) st.template put<9>(out.R, b, active, cap.R);
   if (want & W_T) {
-    T* o = out.Tm + b * 16;
+    T row[16];
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      sfor<3>([&](auto c) ABRK_LAMBDA { o[r() * 4 + c()] = cap.R[r() * 3 + c()]; });
-      o[r() * 4 + 3] = p[r()];   // T * [x,1] column: with x = 0 this is the frame origin
-      o[12 + r()] = T(0);
+      sfor<3>([&](auto c) ABRK_LAMBDA { row[r() * 4 + c()] = cap.R[r() * 3 + c()]; });
+      row[r() * 4 + 3] = p[r()];  // T * [x,1] column: with x = 0 this is the frame origin
+      row[12 + r()] = T(0);
     });
-    o[15] = T(1);
+    row[15] = T(1);
+    st.template put<16>(out.Tm, b, active, row);
   }
   if (want & W_TINV) {  // base_config.py:791-837: [R^T | -R^T t]
-    T* o = out.Tinv + b * 16;
+    T row[16];
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      sfor<3>([&](auto c) ABRK_LAMBDA { o[r() * 4 + c()] = cap.R[c() * 3 + r()]; });
-      o[r() * 4 + 3] = -(cap.R[0 * 3 + r()] * cap.o[0] + cap.R[1 * 3 + r()] * cap.o[1] + cap.R[2 * 3 + r()] * cap.o[2]);
-      o[12 + r()] = T(0);
+      sfor<3>([&](auto c) ABRK_LAMBDA { row[r() * 4 + c()] = cap.R[c() * 3 + r()]; });
+      row[r() * 4 + 3] =
+          -(cap.R[0 * 3 + r()] * cap.o[0] + cap.R[1 * 3 + r()] * cap.o[1] + cap.R[2 * 3 + r()] * cap.o[2]);
+      row[12 + r()] = T(0);
     });
-    o[15] = T(1);
+    row[15] = T(1);
+    st.template put<16>(out.Tinv, b, active, row);
   }
   if (want & W_QUAT) {
     T qq[4];
     quat_from_R(cap.R, qq);
-    store_row<4>(out.quat, b, qq);
+    st.template put<4>(out.quat, b, active, qq);
   }
 }
 
 // ---- OSC.generate for B states (osc.py:217-320)
-template <class A, class T, int KM, bool USE_C>
+template <class A, class T, int KM, bool USE_C, bool FEAT>
 ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
   constexpr int N = A::N;
   T q[N], dq[N], tgt[6], tv[6], ierr[6], une[N], u[N], ts[N];
+  const bool tv_given = FEAT && tvg != nullptr, have_ierr = FEAT && ierrg != nullptr,
+             have_ext = FEAT && uneg != nullptr;
   load_row<N>(qg, b, q);
-  load_row<N>(dqg, b, dq);
-  load_row<6>(tg, b, tgt);
-  const bool tv_given = tvg != nullptr, have_ierr = ierrg != nullptr, have_ext = uneg != nullptr;
-  if (tv_given) load_row<6>(tvg, b, tv);
-  else sfor<6>([&](auto r) ABRK_LAMBDA { tv[r()] = T(0); });
-  if (have_ierr) load_row<6>(ierrg, b, ierr);
-  else sfor<6>([&](auto r) ABRK_LAMBDA { ierr[r()] = T(0); });
-  if (have_ext) load_row<N>(uneg, b, une);
-  else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
-  osc_row<A, T, KM, USE_C>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts);
+  // FEAT=false: every input is requested up front (one HBM round trip; 36 extra registers still
+  // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
+  // kinematics to keep that kernel's register peak down.
+  constexpr bool EARLY = !FEAT;
+  if constexpr (USE_C || EARLY) load_row<N>(dqg, b, dq);
+  if constexpr (EARLY) load_row<6>(tg, b, tgt);
+  auto late = [&]() ABRK_LAMBDA {
+    if constexpr (!USE_C && !EARLY) load_row<N>(dqg, b, dq);
+    if constexpr (!EARLY) load_row<6>(tg, b, tgt);
+    if (tv_given) load_row<6>(tvg, b, tv);
+    else sfor<6>([&](auto r) ABRK_LAMBDA { tv[r()] = T(0); });
+    if (have_ierr) load_row<6>(ierrg, b, ierr);
+    else sfor<6>([&](auto r) ABRK_LAMBDA { ierr[r()] = T(0); });
+    if (have_ext) load_row<N>(uneg, b, une);
+    else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
+  };
+  osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late);
   store_row<N>(ug, b, u);
   if (tsg) store_row<N>(tsg, b, ts);
   if (have_ierr) store_row<6>(ierrg, b, ierr);

@@ -39,11 +39,17 @@ WORKLOADS = {
     "cfg3": ("jaco2", 16384, "f64", "osc_damp", dict(kp=200), 4500),
     "cfg4": ("ur5", (1 << 20) // 8, "f64", "osc", dict(kp=200, use_g=True, use_C=True), 10000),
     "cfg5": ("threejoint", 65536, "f32", "sliding", dict(), 1200),
+    # not a BASELINE config: the batched robot_config surface (Tx, J, M, g in one launch) - the
+    # HBM-bound "full outputs" mode of SURVEY.md 8d
+    "dynF": ("ur5", 4096, "f64", "dyn", dict(want=("Tx", "J", "M", "g")), 2500),
 }
 
 
 def algorithmic_bytes(n, esz, kind):
-    """SURVEY.md 8d, Mode U: read q, dq [n] + target, write u [n]"""
+    """SURVEY.md 8d.  Mode U (controllers): read q, dq [n] + target, write u [n].
+    Full-output dynamics: read q [n], write Tx[3] + J[6,n] + M[n,n] + g[n]."""
+    if kind == "dyn":
+        return esz * n + esz * (3 + 6 * n + n * n + n)
     nt = 3 if kind == "sliding" else 6
     return esz * (2 * n + nt) + esz * n
 
@@ -79,7 +85,12 @@ class Runner:
         self.dq = a.DeviceArray.from_numpy(dq, device)
         self.t = a.DeviceArray.from_numpy(t, device)
         self.u = a.DeviceArray((B, self.n), self.dt, device)
-        if kind == "sliding":
+        if kind == "dyn":
+            n = self.n
+            shapes = {"Tx": (3,), "J": (6, n), "M": (n, n), "g": (n,)}
+            self.want = kw["want"]
+            self.dyn_out = {w: a.DeviceArray((B,) + shapes[w], self.dt, device) for w in self.want}
+        elif kind == "sliding":
             self.params = _abi.make_sliding_params(self.n)
         else:
             nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
@@ -87,7 +98,10 @@ class Runner:
         self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
 
     def step(self):
-        if self.kind == "sliding":
+        if self.kind == "dyn":
+            self.engine.dynamics(self.arm_id, self.n, self.q, None, None, None, self.want, self.dt, self.device,
+                                 self.stream, out=self.dyn_out)
+        elif self.kind == "sliding":
             self.engine.sliding_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
                                          dtype=self.dt, device=self.device, stream=self.stream)
         else:
@@ -121,7 +135,7 @@ def roofline(runner, ms_per_launch, label):
     gbs = evals_s * runner.bytes_per_eval / 1e9
     tf = evals_s * runner.flops / 1e12
     return {
-        "kernel": "osc_kernel" if runner.kind != "sliding" else "sliding_kernel",
+        "kernel": {"sliding": "sliding_kernel", "dyn": "dyn_kernel"}.get(runner.kind, "osc_kernel"),
         "workload": label, "batch": runner.B, "bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
         "bytes_per_eval": runner.bytes_per_eval, "us_per_launch": round(ms_per_launch * 1e3, 3),
@@ -142,7 +156,9 @@ def cpu_baseline(workload, budget_s=12.0):
     nt = 3 if kind == "sliding" else 6
     Bs = 2048
     q, dq, t = make_inputs(1, Bs, o.n, nt, np.float64)
-    if kind == "sliding":
+    if kind == "dyn":
+        fn = lambda: [(o.Tx("EE", q[i]), o.J("EE", q[i]), o.M(q[i]), o.g(q[i])) for i in range(Bs)]
+    elif kind == "sliding":
         p = _abi.make_sliding_params(o.n)
         fn = lambda: o.sliding_batch(p, q, dq, t)
     else:
@@ -217,8 +233,7 @@ def main():
             "vs_baseline": None, "dtype": dts, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {arm} {kind} batch={B} per GPU, inputs resident in HBM, "
                                    f"q~U(0,2pi) dq~U(0,5) target~U(-1,1) seed 1", "arm": arm, "batch_per_gpu": B,
-                       "global_batch": B * world, "params": {k: (v if not isinstance(v, list) else list(v))
-                                                              for k, v in kw.items()},
+                       "global_batch": B * world, "params": {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in kw.items()},
                        "parallelism": f"batch-shard x{world}, no collective", "device": a.device_name(device)},
             "roofline_config": roofline(run, ms, f"{args.workload} batch={B} (cache-resident, launch-bound)"),
         }

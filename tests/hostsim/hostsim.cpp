@@ -24,11 +24,12 @@ int run_dyn(const A& arm, int n, int64_t B, const void* q, const void* dq, int f
   for (int i = 0; i < 10; i++) po[i] = static_cast<T*>(outs[i]);
   int m = frame_m(frame, n);
   T ox = T(off ? off[0] : 0), oy = T(off ? off[1] : 0), oz = T(off ? off[2] : 0);
+  DirectStore<T> st;
   for (long b = 0; b < B; b++) {
     if (want & (W_C | W_DJ))
-      dyn_body<A, T, true>(b, arm, frame, m, ox, oy, oz, want, (long)B, (const T*)q, (const T*)dq, o);
+      dyn_body<A, T, true>(b, true, st, arm, frame, m, ox, oy, oz, want, (long)B, (const T*)q, (const T*)dq, o);
     else
-      dyn_body<A, T, false>(b, arm, frame, m, ox, oy, oz, want, (long)B, (const T*)q, (const T*)dq, o);
+      dyn_body<A, T, false>(b, true, st, arm, frame, m, ox, oy, oz, want, (long)B, (const T*)q, (const T*)dq, o);
   }
   return 0;
 }
@@ -38,10 +39,17 @@ int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void
   OscP<T> p = make_oscp<T>(*P, n);
   bool fast = osc_is_fast(*P, n, une != nullptr);
   if (P->ki == 0) ie = nullptr;
+  const bool feat = tv || ie || une || p.n_null > 0;  // same dispatch rule as Launch::osc_launch_feat
   for (long b = 0; b < B; b++) {
-#define CALL(KM, UC)                                                                                  \
-  osc_body<A, T, KM, UC>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, \
-                         (T*)ie, (const T*)une, (T*)u, (T*)ts)
+#define CALL(KM, UC)                                                                                          \
+  do {                                                                                                        \
+    if (feat)                                                                                                 \
+      osc_body<A, T, KM, UC, true>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, \
+                                   (T*)ie, (const T*)une, (T*)u, (T*)ts);                                     \
+    else                                                                                                      \
+      osc_body<A, T, KM, UC, false>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg,              \
+                                    (const T*)tv, (T*)ie, (const T*)une, (T*)u, (T*)ts);                      \
+  } while (0)
     if (fast) {
       if (P->use_C) CALL(3, true); else CALL(3, false);
     } else {

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Kernel-variant experiment: rebuild only the UR5 translation unit with different launch
+# bounds / block sizes and link each into its own libabrk_<tag>.so (selected at run time with
+# ABRK_LIB_PATH).  Usage: tools/build_variants.sh "w1b64:-DABRK_MIN_WAVES=1 -DABRK_BLOCK=64" ...
+set -e
+cd "$(dirname "$0")/../abr_control_amd/csrc"
+mkdir -p build/variants
+OTHERS=$(ls build/*.o | grep -v abrk_arm_ur5.o)
+for spec in "$@"; do
+  tag="${spec%%:*}"; flags="${spec#*:}"
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c abrk_arm_ur5.hip -o build/variants/ur5_$tag.o \
+    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libabrk_$tag.so build/variants/ur5_$tag.o $OTHERS \
+    && echo "built $tag" ) &
+done
+wait
