@@ -130,20 +130,51 @@ class Runner:
         return wall, ev1.elapsed_ms_since(ev0) / steps
 
 
+def profiled_traffic(kernel, batch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/round1/traffic.json, tools/gpu_profiles.sh); None when that (kernel, batch) was not profiled."""
+    try:
+        t = json.load(open(os.path.join(REPO, "profiles", "round1", "traffic.json")))[f"{kernel}:{batch}"]
+        return round(t["read_bytes"] + t["write_bytes"], 1)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline(runner, ms_per_launch, label):
     evals_s = runner.B / (ms_per_launch * 1e-3)
     gbs = evals_s * runner.bytes_per_eval / 1e9
     tf = evals_s * runner.flops / 1e12
+    kname = {"sliding": "sliding_kernel", "dyn": "dyn_kernel"}.get(runner.kind, "osc_kernel")
     return {
-        "kernel": {"sliding": "sliding_kernel", "dyn": "dyn_kernel"}.get(runner.kind, "osc_kernel"),
+        "kernel": kname,
         "workload": label, "batch": runner.B, "bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": profiled_traffic(kname, runner.B),
+        "algorithmic_bytes_per_launch": runner.B * runner.bytes_per_eval,
         "bytes_per_eval": runner.bytes_per_eval, "us_per_launch": round(ms_per_launch * 1e3, 3),
         "evals_per_s": round(evals_s, 1),
         "binding": "fp64_valu" if runner.dt == np.float64 else "fp32_valu",
         "valu_tflops": round(tf, 3), "valu_peak_tflops": FP64_VALU_PEAK_TF if runner.dt == np.float64 else 157.3,
         "valu_frac": round(tf / (FP64_VALU_PEAK_TF if runner.dt == np.float64 else 157.3), 5),
+        "traffic_profiled": "profiles/round1/SUMMARY.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
     }
+
+
+def parity_vs_reference(device):
+    """max |du| of the GPU result against outputs of the reference itself (tests/golden/ur5.npz, written by
+    oracle/gen_golden.py): `cfg2_uS` = the reference's Cython path as shipped (float32-rounding wrappers),
+    `cfg2_uD` = the same osc.py formulas fed by its fp64 generated functions."""
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC
+
+    g = np.load(os.path.join(REPO, "tests", "golden", "ur5.npz"))
+    u = OSC(ur5.Config(device=device), kp=200).generate(g["cfg2_q"], g["cfg2_dq"], g["cfg2_target"])
+    rel = lambda a, b: np.max(np.abs(a - b), axis=1) / np.max(np.abs(b), axis=1)
+    rS, rD = rel(u, g["cfg2_uS"]), rel(u, g["cfg2_uD"])
+    return {"rows": int(len(u)), "max_abs_du_vs_cython_ref": float(np.max(np.abs(u - g["cfg2_uS"]))),
+            "median_rel_vs_cython_ref": float(np.median(rS)), "max_rel_vs_cython_ref": float(rS.max()),
+            "max_abs_du_vs_fp64_ref": float(np.max(np.abs(u - g["cfg2_uD"]))), "max_rel_vs_fp64_ref": float(rD.max()),
+            "note": "the shipped reference rounds J,M,g to float32 (base_config.py:223-285): its own distance from "
+                    "the fp64 evaluation of the same formulas is the median/max rel vs_cython_ref seen here"}
 
 
 def cpu_baseline(workload, budget_s=12.0):
@@ -226,9 +257,9 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "OSC control-signal evaluations/sec (batched UR5 6-DOF, fp64)" if args.workload == "cfg2"
-            else f"control-signal evaluations/sec ({args.workload})",
-            "value": round(value, 1), "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "OSC control steps/sec (batched UR5 6-DOF)" if args.workload == "cfg2"
+            else f"control steps/sec ({args.workload})",
+            "value": round(value, 1), "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dts, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {arm} {kind} batch={B} per GPU, inputs resident in HBM, "
@@ -248,6 +279,14 @@ def main():
         del big
     elif rank == 0:
         out["roofline"] = out["roofline_config"]
+    if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg:
+        # the HBM-bound mode of the same path: every robot_config output of a row (Tx, J, M, g) in one launch
+        full = Runner("dynF", args.roofline_batch // 2, device, stream)
+        _, ms_full = full.timed(args.roofline_steps, 3)
+        out["roofline_full_outputs"] = roofline(full, ms_full, f"dynF batch={full.B}: Tx,J,M,g per row, 696 B/row")
+        del full
+    if rank == 0 and args.workload == "cfg2":
+        out["parity"] = parity_vs_reference(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:

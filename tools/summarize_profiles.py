@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Condense a gpurun_out/<dir> produced by tools/gpu_profiles.sh into profiles/<round>/ (tracked):
+kernel stats of the bench command, per-kernel averages of the PMC passes, bench JSON lines, test logs."""
+import json
+import os
+import shutil
+import sys
+
+import pandas as pd
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+lines = ["# rocprofv3 evidence (MI355X, ROCm 7.2)", "",
+         "Commands: `tools/gpu_profiles.sh` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
+         "`--pmc` passes as MI355X_MICROARCH.md prescribes).  `FETCH_SIZE`/`WRITE_SIZE` are in KiB; on gfx950 "
+         "FETCH_SIZE counts 64 B per 128-B request, so read bytes = FETCH_SIZE x 1024 x 2.", ""]
+for f in ("pytest_gpu.log", "smoke.log"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+for f in sorted(os.listdir(src)):
+    if f.startswith("bench_") and f.endswith(".json") and os.path.getsize(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+ks = os.path.join(src, "stats", "bench_kernel_stats.csv")
+if os.path.exists(ks):
+    shutil.copy(ks, os.path.join(dst, "bench_kernel_stats.csv"))
+    df = pd.read_csv(ks)
+    lines += ["## `rocprofv3 --kernel-trace --stats -- python bench.py` (kernel_stats)", "",
+              "| kernel | calls | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|"]
+    for _, r in df.iterrows():
+        lines.append(f"| `{r['Name'].split('(')[0][:90]}` | {r['Calls']} | {r['AverageNs']:.0f} | {r['MinNs']} | "
+                     f"{r['MaxNs']} | {r['Percentage']} |")
+    kt = pd.read_csv(os.path.join(src, "stats", "bench_kernel_trace.csv"))
+    kt["dur"] = kt["End_Timestamp"] - kt["Start_Timestamp"]
+    kt["kernel"] = kt["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:60]
+    g = kt.groupby(["kernel", "Grid_Size_X"])["dur"].agg(["count", "mean", "min", "max"]).reset_index()
+    lines += ["", "per (kernel, grid) from the kernel trace of the same run:", "",
+              "| kernel | rows (grid) | launches | mean us | min us | max us |", "|---|---|---|---|---|---|"]
+    for _, r in g.iterrows():
+        lines.append(f"| `{r['kernel']}` | {r['Grid_Size_X']} | {r['count']} | {r['mean']/1e3:.2f} | {r['min']/1e3:.2f} | "
+                     f"{r['max']/1e3:.2f} |")
+rows = []
+for d in sorted(os.listdir(src)):
+    cc = os.path.join(src, d, "bench_counter_collection.csv")
+    if d.startswith("pmc_") and os.path.exists(cc):
+        df = pd.read_csv(cc)
+        df["kernel"] = df["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:60]
+        g = df.groupby(["kernel", "Grid_Size", "Counter_Name", "VGPR_Count", "Accum_VGPR_Count", "Scratch_Size",
+                        "LDS_Block_Size"])["Counter_Value"].mean().reset_index()
+        g.to_csv(os.path.join(dst, f"{d}_mean_per_launch.csv"), index=False)
+        rows.append(g)
+if rows:
+    allc = pd.concat(rows)
+    lines += ["", "## PMC passes (mean per launch)", "", "| kernel | rows | counter | mean per launch |", "|---|---|---|---|"]
+    for _, r in allc.iterrows():
+        lines.append(f"| `{r['kernel']}` | {r['Grid_Size']} | {r['Counter_Name']} | {r['Counter_Value']:.6g} |")
+    lines += ["", "## Derived", ""]
+    piv = allc.pivot_table(index=["kernel", "Grid_Size"], columns="Counter_Name", values="Counter_Value")
+    traffic = {}
+    for (k, gsz), r in piv.iterrows():
+        if "FETCH_SIZE" in r and "WRITE_SIZE" in r and r["FETCH_SIZE"] == r["FETCH_SIZE"]:
+            traffic[f"{k.split('<')[0]}:{int(gsz)}"] = {
+                "read_bytes": float(r["FETCH_SIZE"] * 1024 * 2), "write_bytes": float(r["WRITE_SIZE"] * 1024),
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    for (k, gsz), r in piv.iterrows():
+        if gsz < 100000:
+            continue
+        bits = [f"* `{k}`, {gsz} rows:"]
+        if "FETCH_SIZE" in r and "WRITE_SIZE" in r and r["FETCH_SIZE"] == r["FETCH_SIZE"]:
+            rd, wr = r["FETCH_SIZE"] * 1024 * 2, r["WRITE_SIZE"] * 1024
+            bits.append(f"HBM traffic = {rd/1e6:.1f} MB read (FETCH_SIZE x2) + {wr/1e6:.1f} MB written = "
+                        f"{(rd+wr)/gsz:.1f} B/row")
+        if "SQ_WAVES" in r and r["SQ_WAVES"] == r["SQ_WAVES"]:
+            w = r["SQ_WAVES"]
+            bits.append(f"{r['SQ_INSTS_VALU']/w:.0f} VALU + {r['SQ_INSTS_SALU']/w:.0f} SALU instr/wave; "
+                        f"wave-cycles/wave {4*r['SQ_WAVE_CYCLES']/w:.0f}, VALU-active {4*r['SQ_ACTIVE_INST_VALU']/w:.0f}, "
+                        f"wait-any {4*r['SQ_WAIT_ANY']/w:.0f}, issue-stall {4*r['SQ_WAIT_INST_ANY']/w:.0f} cycles")
+        lines.append(" ".join(bits))
+open(os.path.join(dst, "SUMMARY.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
