@@ -44,6 +44,7 @@ def lib():
         L.abrk_osc_generate_batch.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
             C.c_int, _vp]
+        L.abrk_osc_law_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64] + [_vp] * 14 + [C.c_int, _vp]
         L.abrk_sliding_generate_batch.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.SlidingParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
             C.c_int, _vp]

@@ -14,7 +14,12 @@ class OSC(Controller):
     def __init__(self, robot_config, kp=1, ko=None, kv=None, ki=0, vmax=None, ctrlr_dof=None,
                  null_controllers=None, use_g=True, use_C=False, orientation_algorithm=0):
         super().__init__(robot_config)
-        self._require_batched_config()
+        from ..arms.base_config import BatchedConfig
+
+        # A foreign (duck-typed) robot_config - e.g. the reference's MujocoConfig, whose J/M/g/Tx/R are
+        # read from the simulator - keeps working: its methods are called per state on the host exactly as
+        # osc.py:242-301 does, and the control law itself runs on the GPU (abrk_osc_law_batch).
+        self._fused_config = isinstance(robot_config, BatchedConfig)
         # osc.py:70-90
         self.kp = kp
         self.ko = kp if ko is None else ko
@@ -52,7 +57,9 @@ class OSC(Controller):
         # object with generate(q, dq) is evaluated by the caller's code and only projected
         self._fused, self._foreign = [], []
         for nc in null_controllers or []:
-            if type(nc) is Damping:
+            if not self._fused_config:
+                self._foreign.append(nc)  # evaluated with the foreign config's own M(q)
+            elif type(nc) is Damping:
                 self._fused.append(_abi.make_damping(nc.kv))
             elif type(nc) is RestingConfig:
                 self._fused.append(_abi.make_resting(nc.rest_angles_list, nc.kp, nc.kv))
@@ -61,6 +68,8 @@ class OSC(Controller):
 
     def _params(self, ref_frame, xyz_offset):
         rc = self.robot_config
+        if not self._fused_config:
+            ref_frame, xyz_offset = "EE", None  # applied by the foreign config when it produced J/Tx/R
         return _abi.make_osc_params(
             rc.N_JOINTS, kp=self.kp, ko=self.ko, kv=self.kv, ki=self.ki, vmax=self.vmax,
             ctrlr_dof=self.ctrlr_dof, null_controllers=self._fused, use_g=self.use_g, use_C=self.use_C,
@@ -73,6 +82,8 @@ class OSC(Controller):
         target_velocity: None, (6,) or (B, 6).  Returns float64 (n,) or (B, n)
         (kernel dtype for a float32 config / DeviceArrays)."""
         rc = self.robot_config
+        if not self._fused_config:
+            return self._generate_foreign(q, dq, target, target_velocity, ref_frame, xyz_offset)
         params = self._params(ref_frame, xyz_offset)
         (q2, dq2, t2, tv2), single = self._rows(q, dq, target, target_velocity)
         on_device = isinstance(q2, DeviceArray)
@@ -107,5 +118,48 @@ class OSC(Controller):
             self.integrated_error = ie[0] if single else ie
         if rc.reference_dtypes:
             u, ts = u.astype(np.float64), ts.astype(np.float64)
+        self.training_signal = ts[0] if single else ts
+        return u[0] if single else u
+
+    def _generate_foreign(self, q, dq, target, target_velocity, ref_frame, xyz_offset):
+        """robot_config is not an abr_control_amd config: gather its J/M/Tx/g/C/R per state (its own code,
+        as osc.py:242-301 calls them) and run the law on the GPU."""
+        rc = self.robot_config
+        n = rc.N_JOINTS
+        single = np.ndim(q) == 1
+        q2, dq2 = np.atleast_2d(np.asarray(q, float)), np.atleast_2d(np.asarray(dq, float))
+        B = q2.shape[0]
+        t2 = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(target, float)), (B, 6)))
+        tv2 = None
+        if target_velocity is not None:
+            tv2 = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(target_velocity, float)), (B, 6)))
+        pos_on, ori_on = bool(np.sum(self.ctrlr_dof[:3])), bool(np.sum(self.ctrlr_dof[3:]))
+        J = np.array([rc.J(ref_frame, q2[b], x=xyz_offset) for b in range(B)], dtype=float)
+        M = np.array([rc.M(q2[b]) for b in range(B)], dtype=float)
+        xyz = np.array([rc.Tx(ref_frame, q2[b], x=xyz_offset) for b in range(B)], dtype=float) if pos_on else None
+        R = np.array([rc.R(ref_frame, q2[b]) for b in range(B)], dtype=float) if ori_on else None
+        g = np.array([rc.g(q=q2[b]) for b in range(B)], dtype=float) if self.use_g else None
+        Cdq = None
+        if self.use_C:
+            Cdq = np.array([np.dot(rc.C(q=q2[b], dq=dq2[b]), dq2[b]) for b in range(B)], dtype=float)
+        une = None
+        if self._foreign:
+            une = np.zeros((B, n))
+            for nc in self._foreign:
+                for b in range(B):
+                    une[b] += nc.generate(q2[b], dq2[b])
+        ie = None
+        if self.ki != 0:
+            ie = np.asarray(self.integrated_error, dtype=float)
+            ie = ie.reshape(1, 6) if ie.shape == (6,) and B == 1 else ie
+            if ie.shape != (B, 6):
+                ie = np.zeros((B, 6))
+            ie = np.ascontiguousarray(ie)
+        device = getattr(rc, "device", 0)
+        u, ts = engine.osc_law(n, self._params(ref_frame, xyz_offset), J, M, dq2, t2, g=g, Cdq=Cdq, xyz=xyz, R=R,
+                               q=q2, target_velocity=tv2, integrated_error=ie, u_null_ext=une,
+                               training_signal=True, device=device)
+        if self.ki != 0:
+            self.integrated_error = ie[0] if single else ie
         self.training_signal = ts[0] if single else ts
         return u[0] if single else u

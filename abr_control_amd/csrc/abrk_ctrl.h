@@ -406,50 +406,19 @@ ABRK_INL void null_command(const NullP<T>& c, const T (&q)[N], const T (&dq)[N],
 // KM = 3 (FAST: task rows are exactly x,y,z of the EE) or 6 (all six task rows, unselected
 // rows masked: their Jacobian row is zeroed and Mx_inv gets a unit diagonal there, which
 // leaves det, the inverse and the singular values of the selected block unchanged).
-// `late()` loads the inputs that are not needed by the kinematics (target, velocities, state; dq
-// too unless the Coriolis term is on) - it is invoked after the register-pressure peak.
-// FEAT = false compiles out the optional inputs (target velocity, integral state, secondary
-// controllers): the plain law needs ~70 registers fewer and fits two waves per SIMD.
-template <class A, class T, int KM, bool USE_C, bool FEAT, class Late>
-ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
-                      bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
-                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late) {
-  constexpr int N = A::N;
+//
+// ---- the control law proper (osc.py:244-318), fed with M, g, C dq, the task Jacobian (Jv/Jw
+// columns), the task point p and the frame rotation RF.  Called by osc_row after the fused
+// kinematics, and by the law-only kernel for robot_configs whose J/M/g come from elsewhere
+// (the reference's duck-typed boundary, e.g. MujocoConfig).  The gravity torque is gscale * gz
+// (fused path: 9.81 * gz accumulators; law-only path: -1 * g).
+template <int N, class T, int KM, bool USE_C, bool FEAT>
+ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
+                      const T (&cvec)[N], const T (&Jv)[N][3], const T (&Jw)[N][3], const T (&p)[3],
+                      const T (&RF)[9], const T (&q)[N], const T (&dq)[N], const T (&tgt)[6], bool tv_given,
+                      const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext, const T (&une)[N],
+                      T (&u)[N], T (&ts)[N]) {
   constexpr bool FAST = (KM == 3);
-  Joints<A, T> jt;
-  Dyn<A, T, USE_C ? CMODE_VEC : CMODE_NONE> d;
-  T XR[9], xo[3];
-  T p[3], RF[9];
-  int m = N;
-  if constexpr (FAST) {
-    NoCap nc;
-    kin_dyn(arm, q, dq, jt, d, XR, xo, nc);
-    if (P.has_off) {
-      T oe[3];
-      mulBE<A, T>(arm, XR, xo, RF, oe);
-      sfor<3>([&](auto r) ABRK_LAMBDA {
-        p[r()] = oe[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
-      });
-    } else {
-      mulBE_pt<A, T>(arm, XR, xo, p);
-    }
-  } else {
-    FrameCap<T> cap;
-    cap.frame = P.ref_frame;
-    sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = T(0); });
-    sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = T(0); });
-    kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
-    sfor<9>([&](auto e) ABRK_LAMBDA { RF[e()] = cap.R[e()]; });
-    sfor<3>([&](auto r) ABRK_LAMBDA {
-      p[r()] = cap.o[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
-    });
-    m = P.m_joints;
-  }
-  // task Jacobian, rows masked (osc.py:242-244)
-  T Jv[N][3], Jw[N][3];
-  jacobian(jt, p, m, Jv, Jw);
-  ABRK_SCHED_FENCE();
-  late();
   T Jr[N][KM];
   bool sel[KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA {
@@ -462,7 +431,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
 
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T through the Cholesky factor of M
   T L[N * (N + 1) / 2], il[N];
-  chol<N>(d.Ms, L, il);
+  chol<N>(Ms, L, il);
   T Y[N][KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA {
     T b[N], x[N];
@@ -556,7 +525,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   bool tv_zero = true;
   if (FEAT && tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
   T Mdq[N];
-  symv<N>(d.Ms, dq, Mdq);
+  symv<N>(Ms, dq, Mdq);
   if (tv_zero) {
     sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(-1) * P.kv * Mdq[i()]; });
   } else {
@@ -578,9 +547,9 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     sfor<KM>([&](auto r) ABRK_LAMBDA { acc += Jr[i()][r()] * f[r()]; });
     u[i()] -= acc;
   });
-  if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= d.cv[i()]; });  // osc.py:291-292
+  if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= cvec[i()]; });  // osc.py:291-292
   sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297
-  if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += T(9.81) * d.gz[i()]; }); // osc.py:300-301
+  if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gscale, gz[i()], u[i()]); }); // osc.py:300-301
 
   // secondary controllers through the null-space filter I - J^T Jbar^T (osc.py:310-318).
   // With u_null = M v the filtered signal is M v - J^T Mx (J v) (Jbar^T M = Mx J).
@@ -589,7 +558,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = T(0); });
     for (int c = 0; c < P.n_null; c++) null_command<N>(P.nul[c], q, dq, v);
     T un[N];
-    symv<N>(d.Ms, v, un);
+    symv<N>(Ms, v, un);
     if (have_ext) {
       // caller-evaluated u_null: v_ext = M^-1 u_ext
       T y[N], w[N];
@@ -613,6 +582,58 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
       u[i()] += un[i()] - acc;
     });
   }
+}
+
+// `late()` loads the inputs that are not needed by the kinematics (target, velocities, state; dq
+// too unless the Coriolis term is on) - it is invoked after the register-pressure peak.
+// FEAT = false compiles out the optional inputs (target velocity, integral state, secondary
+// controllers): the plain law needs ~70 registers fewer and fits two waves per SIMD.
+template <class A, class T, int KM, bool USE_C, bool FEAT, class Late>
+ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
+                      bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
+                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late) {
+  constexpr int N = A::N;
+  constexpr bool FAST = (KM == 3);
+  Joints<A, T> jt;
+  Dyn<A, T, USE_C ? CMODE_VEC : CMODE_NONE> d;
+  T XR[9], xo[3];
+  T p[3], RF[9];
+  int m = N;
+  if constexpr (FAST) {
+    NoCap nc;
+    kin_dyn(arm, q, dq, jt, d, XR, xo, nc);
+    if (P.has_off) {
+      T oe[3];
+      mulBE<A, T>(arm, XR, xo, RF, oe);
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        p[r()] = oe[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
+      });
+    } else {
+      mulBE_pt<A, T>(arm, XR, xo, p);
+    }
+  } else {
+    FrameCap<T> cap;
+    cap.frame = P.ref_frame;
+    sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = T(0); });
+    sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = T(0); });
+    kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
+    sfor<9>([&](auto e) ABRK_LAMBDA { RF[e()] = cap.R[e()]; });
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      p[r()] = cap.o[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
+    });
+    m = P.m_joints;
+  }
+  // task Jacobian, rows masked (osc.py:242-244)
+  T Jv[N][3], Jw[N][3];
+  jacobian(jt, p, m, Jv, Jw);
+  ABRK_SCHED_FENCE();
+  late();
+  if constexpr (USE_C)
+    osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
+                                  ierr, have_ext, une, u, ts);
+  else  // no Coriolis vector: the slot is not read (d.gz stands in for the array type)
+    osc_law<N, T, KM, false, FEAT>(P, d.Ms, d.gz, T(9.81), d.gz, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin,
+                                   have_ierr, ierr, have_ext, une, u, ts);
 }
 
 // ---------------------------------------------------------------- Sliding.generate, one row (sliding.py:34-99)

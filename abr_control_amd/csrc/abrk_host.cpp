@@ -567,3 +567,82 @@ extern "C" int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_
   HIPCHK(a->ops->joint(dtype, la, ja));
   return st.finish();
 }
+
+// ------------------------------------------------------------------------------- OSC law on supplied dynamics
+extern "C" int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params* P, int64_t B, const void* J,
+                                  const void* M, const void* g, const void* Cdq, const void* xyz, const void* R,
+                                  const void* q, const void* dq, const void* target, const void* target_velocity,
+                                  void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
+                                  int device, void* stream) {
+  const int n = n_joints;
+  if (n < 1 || n > ABRK_MAX_JOINTS) return fail(ABRK_EINVAL, "n_joints=%d outside 1..%d", n, ABRK_MAX_JOINTS);
+  if (dtype != ABRK_F64 && dtype != ABRK_F32) return fail(ABRK_EINVAL, "dtype %d is not ABRK_F64/ABRK_F32", dtype);
+  if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (P->n_null < 0 || P->n_null > ABRK_MAX_NULL) return fail(ABRK_EINVAL, "n_null=%d outside 0..%d", P->n_null, ABRK_MAX_NULL);
+  if (P->orientation_algorithm != 0 && P->orientation_algorithm != 1)
+    return fail(ABRK_EINVAL, "Invalid algorithm number %d for calculating orientation error", P->orientation_algorithm);
+  int k = 0, pos = 0, ori = 0;
+  for (int r = 0; r < 6; r++) {
+    k += P->ctrlr_dof[r] ? 1 : 0;
+    (r < 3 ? pos : ori) += P->ctrlr_dof[r] ? 1 : 0;
+  }
+  if (k == 0) return fail(ABRK_EINVAL, "ctrlr_dof selects no task-space dimension");
+  if (!J || !M || !dq || !target || !u) return fail(ABRK_EINVAL, "J, M, dq, target and u are required");
+  if (pos && !xyz) return fail(ABRK_EINVAL, "position control needs xyz (robot_config.Tx)");
+  if (ori && !R) return fail(ABRK_EINVAL, "orientation control needs R (robot_config.R)");
+  if (P->use_g && !g) return fail(ABRK_EINVAL, "use_g needs g (robot_config.g)");
+  if (P->use_C && !Cdq) return fail(ABRK_EINVAL, "use_C needs Cdq (robot_config.C(q,dq) @ dq)");
+  if (P->ki != 0 && !integrated_error) return fail(ABRK_EINVAL, "ki != 0 needs the integrated_error state array");
+  for (int c = 0; c < P->n_null; c++)
+    if (P->null_ctrl[c].kind == ABRK_NULL_RESTING && !q) return fail(ABRK_EINVAL, "RestingConfig needs q");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  void* ie = (P->ki != 0) ? integrated_error : nullptr;
+  const void* c_in = P->use_C ? Cdq : nullptr;
+  const void* g_in = P->use_g ? g : nullptr;
+  const void* J_ = st.add(J, B * 6 * n * s, true, false);
+  const void* M_ = st.add(M, B * n * n * s, true, false);
+  const void* g_ = st.add(g_in, B * n * s, true, false);
+  const void* c_ = st.add(c_in, B * n * s, true, false);
+  const void* x_ = st.add(xyz, B * 3 * s, true, false);
+  const void* R_ = st.add(R, B * 9 * s, true, false);
+  const void* q_ = st.add(q, B * n * s, true, false);
+  const void* dq_ = st.add(dq, B * n * s, true, false);
+  const void* t_ = st.add(target, B * 6 * s, true, false);
+  const void* tv_ = st.add(target_velocity, B * 6 * s, true, false);
+  void* ie_ = st.add(ie, B * 6 * s, true, true);
+  const void* une_ = st.add(u_null_ext, B * n * s, true, false);
+  void* u_ = st.add(u, B * n * s, false, true);
+  void* ts_ = st.add(training_signal, B * n * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  LawArgs a;
+  a.J = st.fix(J_, J);
+  a.M = st.fix(M_, M);
+  a.g = st.fix(g_, g_in);
+  a.c = st.fix(c_, c_in);
+  a.xyz = st.fix(x_, xyz);
+  a.R = st.fix(R_, R);
+  a.q = st.fix(q_, q);
+  a.dq = st.fix(dq_, dq);
+  a.target = st.fix(t_, target);
+  a.tv = st.fix(tv_, target_velocity);
+  a.ierr = st.fix(ie_, ie);
+  a.une = st.fix(une_, u_null_ext);
+  a.u = st.fix(u_, u);
+  a.ts = st.fix(ts_, training_signal);
+  OscP<double> p64;
+  OscP<float> p32;
+  if (dtype == ABRK_F64) {
+    p64 = make_oscp<double>(*P, n);
+    a.P = &p64;
+  } else {
+    p32 = make_oscp<float>(*P, n);
+    a.P = &p32;
+  }
+  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
+  HIPCHK(launch_osc_law(n, dtype, la, a));
+  return st.finish();
+}

@@ -84,6 +84,17 @@ joint_kernel(A arm, JointP<T> P, long B, const T* __restrict__ qg, const T* __re
   joint_body<A, T>(b, arm, P, B, qg, dqg, tg, tvg, ug);
 }
 
+template <int N, class T>
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+osc_law_kernel(OscP<T> P, long B, const T* __restrict__ Jg, const T* __restrict__ Mg, const T* __restrict__ gg,
+               const T* __restrict__ cg, const T* __restrict__ xg, const T* __restrict__ Rg,
+               const T* __restrict__ qg, const T* __restrict__ dqg, const T* __restrict__ tg,
+               const T* __restrict__ tvg, T* __restrict__ ierrg, const T* __restrict__ uneg, T* __restrict__ ug,
+               T* __restrict__ tsg) {
+  ABRK_ROW_INDEX
+  osc_law_body<N, T>(b, P, B, Jg, Mg, gg, cg, xg, Rg, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg);
+}
+
 // ---------------------------------------------------------------- launch table
 // Type-erased launchers the host ABI (abrk_host.cpp) calls; pointers are device pointers.
 struct LaunchArgs {
@@ -91,6 +102,13 @@ struct LaunchArgs {
   long B;
   hipStream_t stream;
 };
+struct LawArgs {
+  const void* P;  // OscP<T>
+  const void *J, *M, *g, *c, *xyz, *R, *q, *dq, *target, *tv, *une;
+  void *ierr, *u, *ts;
+};
+hipError_t launch_osc_law(int n_joints, int dtype, const LaunchArgs& la, const LawArgs& a);  // abrk_law.hip
+
 struct DynArgs {
   int frame, m;
   double off[3];

@@ -1,0 +1,22 @@
+// Law-only OSC kernels (caller-supplied J, M, g, ...) for 1..7 joints, both arithmetic types.
+#include "abrk_kernels.h"
+namespace abrk {
+template <int N, class T>
+static hipError_t law_launch(const LaunchArgs& la, const LawArgs& a) {
+  hipLaunchKernelGGL((osc_law_kernel<N, T>), grid_for(la.B), dim3(kBlock), 0, la.stream,
+                     *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.J, (const T*)a.M, (const T*)a.g,
+                     (const T*)a.c, (const T*)a.xyz, (const T*)a.R, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
+                     (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts);
+  return hipGetLastError();
+}
+hipError_t launch_osc_law(int n, int dtype, const LaunchArgs& la, const LawArgs& a) {
+#define ABRK_CASE(NN) \
+  case NN:            \
+    return dtype == 0 ? law_launch<NN, double>(la, a) : law_launch<NN, float>(la, a);
+  switch (n) {
+    ABRK_CASE(1) ABRK_CASE(2) ABRK_CASE(3) ABRK_CASE(4) ABRK_CASE(5) ABRK_CASE(6) ABRK_CASE(7)
+  }
+#undef ABRK_CASE
+  return hipErrorInvalidValue;
+}
+}  // namespace abrk

@@ -168,6 +168,49 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   if (have_ierr) store_row<6>(ierrg, b, ierr);
 }
 
+// ---- OSC control law on caller-supplied dynamics (osc.py:244-318): for robot_configs whose
+// J / M / g / Tx / R come from elsewhere (the reference's duck-typed boundary, e.g. MujocoConfig,
+// abr_control/arms/mujoco_config.py:201-451).  Inputs per row, row-major: J [6,N], M [N,N];
+// optional g [N], Cdq [N] (= C(q,dq) dq), xyz [3], R [3,3], q [N] (RestingConfig only).
+template <int N, class T>
+ABRK_INL void osc_law_body(long b, const OscP<T>& P, long B, const T* __restrict__ Jg, const T* __restrict__ Mg,
+                           const T* __restrict__ gg, const T* __restrict__ cg, const T* __restrict__ xg,
+                           const T* __restrict__ Rg, const T* __restrict__ qg, const T* __restrict__ dqg,
+                           const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
+                           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
+  T Jf[6 * N], Mf[N * N], Ms[N * (N + 1) / 2], gv[N], cv[N], Jv[N][3], Jw[N][3], p[3], RF[9];
+  T q[N], dq[N], tgt[6], tv[6], ierr[6], une[N], u[N], ts[N];
+  load_row<6 * N>(Jg, b, Jf);
+  load_row<N * N>(Mg, b, Mf);
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      Jv[i()][r()] = Jf[r() * N + i()];
+      Jw[i()][r()] = Jf[(3 + r()) * N + i()];
+    });
+    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { Ms[tri(i(), j())] = Mf[i() * N + j()]; });
+  });
+  auto opt = [&](const T* ptr, auto& dst, auto n, T fill) ABRK_LAMBDA {
+    if (ptr) load_row<n()>(ptr, b, dst);
+    else sfor<n()>([&](auto e) ABRK_LAMBDA { dst[e()] = fill; });
+  };
+  opt(gg, gv, ic<N>{}, T(0));
+  opt(cg, cv, ic<N>{}, T(0));
+  opt(xg, p, ic<3>{}, T(0));
+  if (Rg) load_row<9>(Rg, b, RF);
+  else sfor<9>([&](auto e) ABRK_LAMBDA { RF[e()] = (e() % 4 == 0) ? T(1) : T(0); });
+  opt(qg, q, ic<N>{}, T(0));
+  load_row<N>(dqg, b, dq);
+  load_row<6>(tg, b, tgt);
+  opt(tvg, tv, ic<6>{}, T(0));
+  opt(ierrg, ierr, ic<6>{}, T(0));
+  opt(uneg, une, ic<N>{}, T(0));
+  osc_law<N, T, 6, true, true>(P, Ms, gv, T(-1), cv, Jv, Jw, p, RF, q, dq, tgt, tvg != nullptr, tv, ierrg != nullptr,
+                               ierr, uneg != nullptr, une, u, ts);
+  store_row<N>(ug, b, u);
+  if (tsg) store_row<N>(tsg, b, ts);
+  if (ierrg) store_row<6>(ierrg, b, ierr);
+}
+
 // ---- Sliding.generate for B states (sliding.py:34-99)
 template <class A, class T>
 ABRK_INL void sliding_body(long b, const A& arm, const SlidingP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,

@@ -143,6 +143,41 @@ def osc_generate(arm_id, n, params, q, dq, target, target_velocity=None, integra
     return (uo, tso) if tso is not None else uo
 
 
+def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=None, target_velocity=None,
+            integrated_error=None, u_null_ext=None, training_signal=False, dtype=np.float64, device=0, stream=None):
+    """The OSC control law on caller-supplied dynamics (abrk_osc_law_batch): J [B,6,n], M [B,n,n] and,
+    as the controller options require, g [B,n], Cdq [B,n], xyz [B,3], R [B,3,3], q [B,n]."""
+    a = _Args(dtype)
+    B = J.shape[0]
+    Jp = a.inp(J, (B, 6, n), "J")
+    Mp = a.inp(M, (B, n, n), "M")
+    gp = a.inp(g, (B, n), "g")
+    cp = a.inp(Cdq, (B, n), "Cdq")
+    xp = a.inp(xyz, (B, 3), "xyz")
+    Rp = a.inp(R, (B, 3, 3), "R")
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq")
+    tp = a.inp(target, (B, 6), "target")
+    tvp = a.inp(target_velocity, (B, 6), "target_velocity")
+    unp = a.inp(u_null_ext, (B, n), "u_null_ext")
+    iep = None
+    if integrated_error is not None:
+        if isinstance(integrated_error, DeviceArray):
+            iep = a.inp(integrated_error, (B, 6), "integrated_error")
+        else:
+            if (not isinstance(integrated_error, np.ndarray) or integrated_error.dtype != a.np_dtype
+                    or integrated_error.shape != (B, 6) or not integrated_error.flags.c_contiguous):
+                raise ValueError("integrated_error must be a C-contiguous ndarray [B,6] of the call dtype")
+            iep = integrated_error.ctypes.data
+    up, uo = a.out(None, (B, n), device, "u")
+    tsp, tso = (None, None)
+    if training_signal:
+        tsp, tso = a.out(None, (B, n), device, "training_signal")
+    check(lib().abrk_osc_law_batch(n, a.code, C.byref(params), B, Jp, Mp, gp, cp, xp, Rp, qp, dqp, tp, tvp, iep, unp,
+                                   up, tsp, device, _sp(stream)))
+    return (uo, tso) if training_signal else uo
+
+
 def sliding_generate(arm_id, n, params, q, dq, target, target_velocity=None, target_acc=None, u=None,
                      want_s=False, dtype=np.float64, device=0, stream=None):
     a = _Args(dtype)

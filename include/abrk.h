@@ -188,6 +188,20 @@ int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_params* params
                             const void* u_null_ext, void* u, void* training_signal,
                             int device, void* stream);
 
+/* The same control law (osc.py:244-318) on CALLER-SUPPLIED dynamics: keeps `OSC(robot_config=<any duck
+ * type>)` working for configs whose arithmetic lives elsewhere (the reference's MujocoConfig,
+ * abr_control/arms/mujoco_config.py:201-451: J/M/g/Tx/R read from mjData).  Per row, row-major:
+ *   J [B,6,n] = robot_config.J(ref_frame,q,x); M [B,n,n] = robot_config.M(q);
+ *   g [B,n] (iff use_g); Cdq [B,n] = C(q,dq)@dq (iff use_C); xyz [B,3] = robot_config.Tx(...) (iff any
+ *   of ctrlr_dof[0:3]); R [B,3,3] = robot_config.R(...) (iff any of ctrlr_dof[3:6]);
+ *   q [B,n] only for a fused RestingConfig; the remaining arguments as abrk_osc_generate_batch.
+ * params->ref_frame / xyz_offset are ignored (already applied by whoever produced J, xyz, R).    */
+int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params* params, int64_t B, const void* J,
+                       const void* M, const void* g, const void* Cdq, const void* xyz, const void* R,
+                       const void* q, const void* dq, const void* target, const void* target_velocity,
+                       void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
+                       int device, void* stream);
+
 /* Sliding.generate (controllers/sliding.py:34-99), cartesian=True or False.
  *   target [B,3] (cartesian) or [B,n]; target_velocity / target_acc same shape or NULL
  *   (== 0); u [B,n] out; s [B,n] out or NULL (Sliding.s, sliding.py:89).              */

@@ -19,7 +19,7 @@ def build(force=False):
         os.path.join(_HERE, "..", "..", "abr_control_amd", "csrc", f)
         for f in ("abrk_device.h", "abrk_ctrl.h", "abrk_rows.h", "abrk_params.h", "abrk_rt.h", "abrk_arms_builtin.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared",
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only",
                         "--cuda-host-only", "-o", _SO, srcs[0]], check=True)
     return _SO
 
@@ -109,3 +109,18 @@ def joint_generate(arm, ctrl, account_for_gravity, q, dq, target=None, target_ve
                              C.c_int64(B), _p(q), _p(dq), _p(target), _p(tv), _p(u))
     assert rc == 0, rc
     return u
+
+
+def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=None, target_velocity=None,
+            integrated_error=None, u_null_ext=None, dtype=np.float64):
+    dt = np.dtype(dtype)
+    J, M, dq, target = _in(J, dt), _in(M, dt), _in(dq, dt), _in(target, dt)
+    g, Cdq, xyz, R, q = _in(g, dt), _in(Cdq, dt), _in(xyz, dt), _in(R, dt), _in(q, dt)
+    tv, une = _in(target_velocity, dt), _in(u_null_ext, dt)
+    B = J.shape[0]
+    u = np.full((B, n), np.nan, dt)
+    ts = np.full((B, n), np.nan, dt)
+    rc = lib().hostsim_osc_law(n, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(J), _p(M), _p(g), _p(Cdq), _p(xyz),
+                               _p(R), _p(q), _p(dq), _p(target), _p(tv), _p(integrated_error), _p(une), _p(u), _p(ts))
+    assert rc == 0, rc
+    return u, ts

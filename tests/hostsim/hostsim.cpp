@@ -143,3 +143,34 @@ extern "C" int hostsim_joint(const char* builtin, const abrk_arm_desc* d, int dt
     return run_joint<A, T>(a, n, c, grav, B, q, dq, tg, tv, u);
   });
 }
+
+extern "C" int hostsim_osc_law(int n, int dtype, const abrk_osc_params* P, int64_t B, const void* J, const void* M,
+                               const void* g, const void* c, const void* xyz, const void* R, const void* q,
+                               const void* dq, const void* tg, const void* tv, void* ie, const void* une, void* u,
+                               void* ts) {
+  if (P->ki == 0) ie = nullptr;
+  if (!P->use_g) g = nullptr;
+  if (!P->use_C) c = nullptr;
+#define LAW_CASE(NN)                                                                                              \
+  if (n == NN) {                                                                                                  \
+    if (dtype == 0) {                                                                                             \
+      OscP<double> p = make_oscp<double>(*P, n);                                                                  \
+      for (long b = 0; b < B; b++)                                                                                \
+        osc_law_body<NN, double>(b, p, (long)B, (const double*)J, (const double*)M, (const double*)g,             \
+                                 (const double*)c, (const double*)xyz, (const double*)R, (const double*)q,        \
+                                 (const double*)dq, (const double*)tg, (const double*)tv, (double*)ie,            \
+                                 (const double*)une, (double*)u, (double*)ts);                                    \
+    } else {                                                                                                      \
+      OscP<float> p = make_oscp<float>(*P, n);                                                                    \
+      for (long b = 0; b < B; b++)                                                                                \
+        osc_law_body<NN, float>(b, p, (long)B, (const float*)J, (const float*)M, (const float*)g, (const float*)c, \
+                                (const float*)xyz, (const float*)R, (const float*)q, (const float*)dq,            \
+                                (const float*)tg, (const float*)tv, (float*)ie, (const float*)une, (float*)u,     \
+                                (float*)ts);                                                                      \
+    }                                                                                                             \
+    return 0;                                                                                                     \
+  }
+  LAW_CASE(1) LAW_CASE(2) LAW_CASE(3) LAW_CASE(4) LAW_CASE(5) LAW_CASE(6) LAW_CASE(7)
+#undef LAW_CASE
+  return -1;
+}

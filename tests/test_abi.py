@@ -115,11 +115,12 @@ def test_python_surface_mirrors_reference():
     assert r.rest_indices == [False, True, False, False, False, False] and not r.account_for_gravity
     assert Damping(rc, 10).kv == 10
 
-    class Foreign:
-        N_JOINTS = 6
+    class Foreign:  # any duck-typed robot_config (e.g. the reference's MujocoConfig) is accepted by OSC:
+        N_JOINTS = 6  # its J/M/g/Tx come from its own code, the law runs on the GPU (abrk_osc_law_batch)
 
+    assert OSC(Foreign(), kp=10)._fused_config is False
     with pytest.raises(TypeError, match="no CPU fallback"):
-        OSC(Foreign())
+        Sliding(Foreign())
 
 
 def test_compute_fails_loudly_without_gpu(L):

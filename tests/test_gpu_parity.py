@@ -267,3 +267,89 @@ def test_gpu_user_arm_from_table_matches_builtin():
     a = OSC(user, kp=200).generate(q, dq, t)
     b = OSC(builtin, kp=200).generate(q, dq, t)
     assert cases.rel_err(a, b).max() < 1e-9
+
+
+def test_gpu_nonfinite_and_huge_inputs():
+    """NaN / Inf states must not turn into finite torques (the kernels are built with
+    -ffinite-math-only for constant folding: documented behaviour, pinned here); angles beyond
+    1e5 rad take the library sincos path and still match the oracle."""
+    be, orc = cases.GpuBackend("ur5"), cases.OracleBackend("ur5")
+    q, dq, t = draw(21, 256, 6)
+    qn = q.copy()
+    qn[3, 2] = np.nan
+    qn[10, 0] = np.inf
+    dqn = dq.copy()
+    dqn[20, 5] = np.nan
+    tn = t.copy()
+    tn[30, 1] = np.nan
+    for p in (_abi.make_osc_params(6, kp=200), _abi.make_osc_params(6, kp=200, use_C=True),
+              _abi.make_osc_params(6, kp=50, ctrlr_dof=[1] * 6)):
+        u, _ = be.osc(p, qn, dqn, tn)
+        bad = [3, 10, 20, 30]
+        assert np.isnan(u[bad]).any(axis=1).all(), "a non-finite state produced a finite control signal"
+        good = np.setdiff1d(np.arange(256), bad)
+        uo, _ = orc.osc(p, q[good], dq[good], t[good])
+        assert cases.rel_err(u[good], uo).max() <= 1e-6  # neighbours in the same wavefront are unaffected
+    qh = q.copy()
+    qh[:, 0] += 3.0e5
+    qh[:, 3] -= 7.0e6
+    p = _abi.make_osc_params(6, kp=200)
+    u, _ = be.osc(p, qh, dq, t)
+    uo, _ = orc.osc(p, qh, dq, t)
+    assert cases.rel_err(u, uo).max() <= 1e-6
+
+
+def test_gpu_foreign_robot_config_runs_the_law_on_the_gpu():
+    """OSC over a duck-typed robot_config that is NOT an abr_control_amd config (stand-in for the
+    reference's MujocoConfig, arms/mujoco_config.py:201-451): its J/M/g/Tx/R/C are called per state
+    like osc.py:242-301 does, the control law runs through abrk_osc_law_batch."""
+    from abr_control_amd.controllers import OSC
+    from oracle.oracle import Oracle
+
+    class ForeignConfig:  # float32 casts like the reference's wrappers
+        def __init__(self, arm):
+            self.o = Oracle(_abi.load_table(arm))
+            self.N_JOINTS = self.o.n
+
+        def J(self, name, q, x=None):
+            return self.o.J(name, q, x)
+
+        def M(self, q):
+            return self.o.M(q)
+
+        def g(self, q):
+            return self.o.g(q)
+
+        def C(self, q, dq):
+            return self.o.C(q, dq)
+
+        def Tx(self, name, q, x=None):
+            return self.o.Tx(name, q, x)
+
+        def R(self, name, q):
+            return self.o.R(name, q)
+
+    class ForeignDamping:
+        def __init__(self, rc, kv):
+            self.rc, self.kv = rc, kv
+
+        def generate(self, q, dq):
+            return np.dot(self.rc.M(q), -self.kv * dq)
+
+    g = golden("ur5")
+    rc = ForeignConfig("ur5")
+    for key, kw in (("cfg2", dict(kp=200)), ("cfg4", dict(kp=200, use_C=True)),
+                    ("osc6_alg0", dict(kp=200, ko=150, kv=25, ctrlr_dof=[True] * 6, orientation_algorithm=0)),
+                    ("osc_link5", dict(kp=200))):
+        c = OSC(rc, **kw)
+        gen = dict(ref_frame="link5") if key == "osc_link5" else {}
+        u = c.generate(g[f"{key}_q"][:128], g[f"{key}_dq"][:128], g[f"{key}_target"][:128], **gen)
+        assert cases.rel_err(u, g[f"{key}_uD"][:128]).max() <= 1e-6, key
+        u1 = c.generate(g[f"{key}_q"][7], g[f"{key}_dq"][7], g[f"{key}_target"][7], **gen)
+        assert u1.shape == (6,) and np.allclose(u1, u[7], rtol=1e-12, atol=1e-12)
+        assert np.allclose(c.training_signal, g[f"{key}_tsD"][7], rtol=1e-9, atol=1e-9)
+    g2 = golden("jaco2")
+    rj = ForeignConfig("jaco2")
+    c = OSC(rj, kp=200, null_controllers=[ForeignDamping(rj, 10)])
+    u = c.generate(g2["cfg3_q"][:64], g2["cfg3_dq"][:64], g2["cfg3_target"][:64])
+    assert cases.rel_err(u, g2["cfg3_uD"][:64]).max() <= 1e-6

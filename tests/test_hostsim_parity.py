@@ -107,3 +107,37 @@ def test_rows_edge_inputs():
     u, _ = be3.osc(p, q3, dq3, t3)
     uo, _ = or3.osc(p, q3, dq3, t3)
     assert np.all(np.isfinite(u)) and np.max(cases.rel_err(u, uo)) < 1e-6
+
+
+@pytest.mark.parametrize("case_id", ["ur5:cfg2", "ur5:cfg4", "ur5:osc6_alg0", "ur5:osc6_alg1", "ur5:osc_xz_b",
+                                     "ur5:osc_xyz_tvel", "ur5:osc6_vmax", "ur5:osc_null2", "jaco2:osc5",
+                                     "threejoint:osc_xyg_alg1", "twojoint:cfg1"])
+def test_rows_law_only_path(case_id):
+    """abrk_osc_law_batch's row program (control law on caller-supplied J, M, g, Cdq, xyz, R - the
+    duck-typed robot_config boundary, e.g. MujocoConfig): dynamics from the oracle, law on the row code."""
+    from tests import hostsim
+
+    case = cases.CASES[case_id]
+    arm, key = case["arm"], case["key"]
+    g = golden(arm)
+    orc = cases.OracleBackend(arm)
+    n = orc.n
+    rows = min(200, len(g[f"{key}_q"]))
+    q, dq, t = g[f"{key}_q"][:rows], g[f"{key}_dq"][:rows], g[f"{key}_target"][:rows]
+    tv = g[f"{key}_tvel"][:rows] if case["tv"] else None
+    params = case["params"](n)
+    frame = "EE"
+    d = orc.dynamics(q, dq, frame, None, ("J", "M", "g", "C", "Tx", "R"))
+    Cdq = np.einsum("bij,bj->bi", d["C"], dq)
+    une = None
+    if params.n_null:  # secondary controllers are the caller's business on this path
+        une = sum(orc.joint(params.null_ctrl[c], False, q, dq) for c in range(params.n_null))
+        params.n_null = 0
+    u, ts = hostsim.osc_law(n, params, d["J"], d["M"], dq, t, g=d["g"], Cdq=Cdq, xyz=d["Tx"], R=d["R"], q=q,
+                            target_velocity=tv, u_null_ext=une)
+    ok = np.ones(rows, bool)
+    band = cases.threshold_band(g, key)
+    if band is not None:
+        ok &= ~band[:rows]
+    tol = cases.TOL_THREEJOINT if arm == "threejoint" else 1e-6
+    assert cases.rel_err(u, g[f"{key}_uD"][:rows])[ok].max() <= tol

@@ -8,7 +8,7 @@ mkdir -p build/variants
 OTHERS=$(ls build/*.o | grep -v abrk_arm_ur5.o)
 for spec in "$@"; do
   tag="${spec%%:*}"; flags="${spec#*:}"
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 $flags -c abrk_arm_ur5.hip -o build/variants/ur5_$tag.o \
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only $flags -c abrk_arm_ur5.hip -o build/variants/ur5_$tag.o \
     && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libabrk_$tag.so build/variants/ur5_$tag.o $OTHERS \
     && echo "built $tag" ) &
 done
