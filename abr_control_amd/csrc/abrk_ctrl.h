@@ -454,7 +454,9 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   bool okA = chol<KM>(Am, LA, ila);
   T det = T(1);
   sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
-  chol_inverse<KM>(LA, ila, Mx);
+  // FEAT = false needs Mx only once (Mx u_task): solved with the factor instead of forming the inverse
+  bool mx_explicit = FEAT;
+  if constexpr (FEAT) chol_inverse<KM>(LA, ila, Mx);
   const T thr = T(1e-3), rcond = T(1e-3) * T(0.1);
   if (!(okA && det >= thr)) {
     // pinv branch (osc.py:142-145).  pinv == inv unless some singular value is below
@@ -483,6 +485,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
           Mx[tri(a(), b())] = acc;
         });
       });
+      mx_explicit = true;
     }
   }
 
@@ -541,7 +544,13 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   // u -= J^T (Mx u_task[ctrlr_dof]) (osc.py:285-288)
   T uts[KM], f[KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
-  symv<KM>(Mx, uts, f);
+  if (mx_explicit) {
+    symv<KM>(Mx, uts, f);
+  } else {
+    T y[KM];
+    chol_fwd<KM>(LA, ila, uts, y);
+    chol_bwd<KM>(LA, ila, y, f);
+  }
   sfor<N>([&](auto i) ABRK_LAMBDA {
     T acc = T(-0.0);
     sfor<KM>([&](auto r) ABRK_LAMBDA { acc += Jr[i()][r()] * f[r()]; });

@@ -102,8 +102,9 @@ struct Rm<double> {
     const int k = (int)n;
     const bool swap = (k & 1) != 0;
     const double ss = swap ? cr : sr, cs = swap ? sr : cr;
-    s = (k & 2) ? -ss : ss;
-    c = ((k + 1) & 2) ? -cs : cs;
+    // quadrant signs straight into the sign bits: sin flips for k & 2, cos for (k + 1) & 2
+    s = __builtin_bit_cast(double, __builtin_bit_cast(long long, ss) ^ ((long long)(k & 2) << 62));
+    c = __builtin_bit_cast(double, __builtin_bit_cast(long long, cs) ^ ((long long)((k + 1) & 2) << 62));
   }
   static ABRK_INL double sqrt(double x) { return ::sqrt(x); }
   static ABRK_INL double fabs(double x) { return ::fabs(x); }
@@ -115,23 +116,20 @@ struct Rm<double> {
   // sqrt.  x must be a normal positive number (pivots of SPD factorizations here).
   static ABRK_INL double rcp(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double y = __builtin_amdgcn_rcp(x);
-    double e = ::fma(-x, y, 1.0);
-    y = ::fma(y, e, y);
-    e = ::fma(-x, y, 1.0);
-    return ::fma(y, e, y);
+    // seed error e0 <= 2^-23; y (1 + e + e^2) leaves e0^3: one cubic step reaches double precision
+    const double y = __builtin_amdgcn_rcp(x);
+    const double e = ::fma(-x, y, 1.0);
+    return ::fma(y, ::fma(e, e, e), y);
 #else
     return 1.0 / x;
 #endif
   }
   static ABRK_INL double rsqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    double y = __builtin_amdgcn_rsq(x);
-    double h = 0.5 * x;
-    double e = ::fma(-h * y, y, 0.5);
-    y = ::fma(y, e, y);
-    e = ::fma(-h * y, y, 0.5);
-    return ::fma(y, e, y);
+    // e = 1 - x y^2;  y (1 + e/2 + 3 e^2/8) leaves O(e^3)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = ::fma(-(x * y), y, 1.0);
+    return ::fma(y * e, ::fma(e, 0.375, 0.5), y);
 #else
     return 1.0 / ::sqrt(x);
 #endif

@@ -177,6 +177,28 @@ def parity_vs_reference(device):
                     "the fp64 evaluation of the same formulas is the median/max rel vs_cython_ref seen here"}
 
 
+def host_staged_rate(device):
+    """End-to-end rate when the boundary hands over HOST arrays (NumPy in, NumPy out): the library stages
+    q, dq, target over PCIe and copies u back on every call.  Reported beside `value`, never as `value`
+    (bounded by 63 GB/s / 192 B = 0.33 G evals/s)."""
+    from abr_control_amd import _abi, engine
+    from abr_control_amd._lib import check, lib
+
+    arm_id = check(lib().abrk_arm_builtin(b"ur5"))
+    p = _abi.make_osc_params(6, kp=200)
+    res = {}
+    for B, reps in ((1, 200), (4096, 100), (1 << 20, 5)):
+        q, dq, t = make_inputs(1, B, 6, 6, np.float64)
+        u = np.empty((B, 6))
+        engine.osc_generate(arm_id, 6, p, q, dq, t, u=u, device=device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            engine.osc_generate(arm_id, 6, p, q, dq, t, u=u, device=device)
+        dt = (time.perf_counter() - t0) / reps
+        res[f"batch_{B}"] = {"us_per_call": round(dt * 1e6, 2), "evals_per_s": round(B / dt, 1)}
+    return res
+
+
 def cpu_baseline(workload, budget_s=12.0):
     """the oracle (plain-C port of the reference path) on one host core, bounded sample"""
     from abr_control_amd import _abi
@@ -236,7 +258,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--roofline-batch", type=int, default=8 << 20, help="rows of the HBM-sized roofline leg")
-    ap.add_argument("--roofline-steps", type=int, default=20)
+    ap.add_argument("--roofline-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
     args = ap.parse_args()
@@ -308,6 +330,7 @@ def main():
         del full
     if rank == 0 and args.workload == "cfg2":
         out["parity"] = parity_vs_reference(device)
+        out["host_staged"] = host_staged_rate(device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
