@@ -87,6 +87,25 @@ class SlidingParams(C.Structure):
     ]
 
 
+class TwoLinkPlant(C.Structure):
+    _fields_ = [("K1", C.c_double), ("K2", C.c_double), ("K3", C.c_double), ("K4", C.c_double), ("dt", C.c_double)]
+
+
+def make_twolink_plant(L, M_LINKS, dt=0.001):
+    """The constants ArmSim.__init__ derives from robot_config.L / _M_LINKS
+    (abr_control/arms/twojoint/arm_sim.py:26-41), expression for expression."""
+    L = np.asarray(L, dtype=float)
+    M = M_LINKS
+    Ls = [np.sum(L[ii * 2: ii * 2 + 2]) for ii in range(int(L.shape[0] / 2))]
+    p = TwoLinkPlant()
+    p.K1 = (1 / 3.0 * M[1][0, 0] + M[2][0, 0]) * Ls[1] ** 2.0 + 1 / 3.0 * M[2][0, 0] * Ls[2] ** 2.0
+    p.K2 = M[2][0, 0] * Ls[1] * Ls[2]
+    p.K3 = 1 / 3.0 * M[2][0, 0] * Ls[2] ** 2.0
+    p.K4 = 1 / 2.0 * M[2][0, 0] * Ls[1] * Ls[2]
+    p.dt = dt
+    return p
+
+
 TABLE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "arms", "tables")
 BUILTIN_ARMS = ("ur5", "jaco2", "twojoint", "threejoint", "onejoint")
 

@@ -45,6 +45,10 @@ def lib():
             C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
             C.c_int, _vp]
         L.abrk_osc_law_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64] + [_vp] * 14 + [C.c_int, _vp]
+        L.abrk_twolink_step_batch.argtypes = [C.c_int, C.POINTER(_abi.TwoLinkPlant), _i64, _vp, _vp, _vp, C.c_int, _vp]
+        L.abrk_osc_rollout_twolink_batch.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.OSCParams), C.POINTER(_abi.TwoLinkPlant), _i64, C.c_int32, C.c_int32,
+            _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
         L.abrk_sliding_generate_batch.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.SlidingParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
             C.c_int, _vp]

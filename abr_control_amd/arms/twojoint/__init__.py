@@ -1,1 +1,2 @@
+from .arm_sim import ArmSim
 from .config import Config

@@ -39,6 +39,11 @@ struct SlidingP {
 };
 
 template <class T>
+struct TwoLinkP {  // ArmSim constants (arms/twojoint/arm_sim.py:33-41)
+  T K1, K2, K3, K4, dt;
+};
+
+template <class T>
 struct JointP {
   NullP<T> c;  // kind 0: Joint; 1: Damping; 2: RestingConfig
   int account_for_gravity;
@@ -697,6 +702,25 @@ ABRK_INL void sliding_row(const A& arm, const SlidingP<T>& P, const T (&q)[A::N]
     sfor<N>([&](auto j) ABRK_LAMBDA { a2 += d.Cm[i() * N + j()] * dq_ref[j()]; });
     u[i()] = a1[i()] + a2 + T(-9.81) * d.gz[i()] - P.kd * s[i()];
   });
+}
+
+// ---------------------------------------------------------------- two-link plant, one Euler step
+// ArmSim._step (arms/twojoint/arm_sim.py:101-137): closed-form inverse of the 2x2 inertia matrix.
+template <class T>
+ABRK_INL void twolink_step(const TwoLinkP<T>& K, T (&q)[2], T (&dq)[2], const T (&u)[2]) {
+  T S2, C2;
+  Rm<T>::sincos(q[1], S2, C2);
+  const T M11 = K.K1 + K.K2 * C2;
+  const T M12 = K.K3 + K.K4 * C2;
+  const T M21 = M12, M22 = K.K3;
+  const T H1 = -K.K2 * S2 * dq[0] * dq[1] - T(0.5) * K.K2 * S2 * (dq[1] * dq[1]);
+  const T H2 = T(0.5) * K.K2 * S2 * (dq[0] * dq[0]);
+  const T ddq1 = (H2 * M11 - H1 * M21 - M11 * u[1] + M21 * u[0]) / (M12 * M12 - M11 * M22);
+  const T ddq0 = (-H2 + u[1] - M22 * ddq1) / M21;
+  dq[0] += ddq0 * K.dt;
+  dq[1] += ddq1 * K.dt;
+  q[0] += dq[0] * K.dt;
+  q[1] += dq[1] * K.dt;
 }
 
 // ---------------------------------------------------------------- Joint / Damping / RestingConfig, one row

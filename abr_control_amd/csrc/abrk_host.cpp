@@ -646,3 +646,103 @@ extern "C" int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params
   HIPCHK(launch_osc_law(n, dtype, la, a));
   return st.finish();
 }
+
+// ------------------------------------------------------------------------------- two-link plant / closed loop
+namespace {
+template <class T>
+TwoLinkP<T> make_plant(const abrk_twolink_plant& s) {
+  TwoLinkP<T> k;
+  k.K1 = T(s.K1);
+  k.K2 = T(s.K2);
+  k.K3 = T(s.K3);
+  k.K4 = T(s.K4);
+  k.dt = T(s.dt);
+  return k;
+}
+}  // namespace
+
+extern "C" int abrk_twolink_step_batch(int dtype, const abrk_twolink_plant* plant, int64_t B, void* q, void* dq,
+                                       const void* u, int device, void* stream) {
+  if (dtype != ABRK_F64 && dtype != ABRK_F32) return fail(ABRK_EINVAL, "dtype %d is not ABRK_F64/ABRK_F32", dtype);
+  if (!plant || !q || !dq || !u) return fail(ABRK_EINVAL, "plant, q, dq and u are required");
+  if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  void* q_ = st.add(q, B * 2 * s, true, true);
+  void* dq_ = st.add(dq, B * 2 * s, true, true);
+  const void* u_ = st.add(u, B * 2 * s, true, false);
+  if (int rc = st.reserve()) return rc;
+  TwoLinkP<double> k64 = make_plant<double>(*plant);
+  TwoLinkP<float> k32 = make_plant<float>(*plant);
+  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
+  HIPCHK(launch_twolink_step(dtype, la, dtype == ABRK_F64 ? (const void*)&k64 : (const void*)&k32, st.fix(q_, q),
+                             st.fix(dq_, dq), st.fix(u_, u)));
+  return st.finish();
+}
+
+extern "C" int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_osc_params* P,
+                                              const abrk_twolink_plant* plant, int64_t B, int32_t n_steps,
+                                              int32_t every, void* q, void* dq, const void* target,
+                                              void* integrated_error, void* q_traj, void* dq_traj, void* u_traj,
+                                              int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (n != 2 || !a->ops->rollout)
+    return fail(ABRK_EINVAL, "the plant of this entry point is the two-link arm (arms/twojoint/arm_sim.py); arm has %d joints", n);
+  if (!P || !plant) return fail(ABRK_EINVAL, "params / plant is NULL");
+  if (P->ref_frame < 0 || P->ref_frame > 2 * n + 1)
+    return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", P->ref_frame);
+  if (P->n_null < 0 || P->n_null > ABRK_MAX_NULL) return fail(ABRK_EINVAL, "n_null=%d outside 0..%d", P->n_null, ABRK_MAX_NULL);
+  int k = 0;
+  for (int r = 0; r < 6; r++) k += P->ctrlr_dof[r] ? 1 : 0;
+  if (k == 0) return fail(ABRK_EINVAL, "ctrlr_dof selects no task-space dimension");
+  if (n_steps < 0 || every < 0) return fail(ABRK_EINVAL, "negative n_steps / every");
+  if (!q || !dq || !target) return fail(ABRK_EINVAL, "q, dq and target are required");
+  if (P->ki != 0 && !integrated_error) return fail(ABRK_EINVAL, "ki != 0 needs the integrated_error state array");
+  if ((q_traj || dq_traj || u_traj) && every <= 0) return fail(ABRK_EINVAL, "trajectory outputs need every > 0");
+  if (B == 0 || n_steps == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  const size_t n_chk = every > 0 ? (size_t)(n_steps / every) : 0;
+  Stager st{device, (hipStream_t)stream};
+  void* ie = (P->ki != 0) ? integrated_error : nullptr;
+  void* q_ = st.add(q, B * 2 * s, true, true);
+  void* dq_ = st.add(dq, B * 2 * s, true, true);
+  const void* t_ = st.add(target, B * 6 * s, true, false);
+  void* ie_ = st.add(ie, B * 6 * s, true, true);
+  void* qt_ = st.add(q_traj, B * n_chk * 2 * s, false, true);
+  void* dqt_ = st.add(dq_traj, B * n_chk * 2 * s, false, true);
+  void* ut_ = st.add(u_traj, B * n_chk * 2 * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  RolloutArgs ra;
+  ra.use_C = P->use_C ? 1 : 0;
+  ra.n_steps = n_steps;
+  ra.every = every;
+  ra.q = st.fix(q_, q);
+  ra.dq = st.fix(dq_, dq);
+  ra.target = st.fix(t_, target);
+  ra.ierr = st.fix(ie_, ie);
+  ra.qt = st.fix(qt_, q_traj);
+  ra.dqt = st.fix(dqt_, dq_traj);
+  ra.ut = st.fix(ut_, u_traj);
+  OscP<double> p64;
+  OscP<float> p32;
+  TwoLinkP<double> k64 = make_plant<double>(*plant);
+  TwoLinkP<float> k32 = make_plant<float>(*plant);
+  if (dtype == ABRK_F64) {
+    p64 = make_oscp<double>(*P, n);
+    ra.P = &p64;
+    ra.K = &k64;
+  } else {
+    p32 = make_oscp<float>(*P, n);
+    ra.P = &p32;
+    ra.K = &k32;
+  }
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->rollout(dtype, la, ra));
+  return st.finish();
+}

@@ -102,6 +102,30 @@ struct LaunchArgs {
   long B;
   hipStream_t stream;
 };
+template <class A, class T, bool USE_C>
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+rollout_kernel(A arm, OscP<T> P, TwoLinkP<T> K, long B, int n_steps, int every, T* __restrict__ qg,
+               T* __restrict__ dqg, const T* __restrict__ tg, T* __restrict__ ierrg, T* __restrict__ qt,
+               T* __restrict__ dqt, T* __restrict__ ut) {
+  ABRK_ROW_INDEX
+  rollout_body<A, T, USE_C>(b, arm, P, K, B, n_steps, every, qg, dqg, tg, ierrg, qt, dqt, ut);
+}
+
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+twolink_step_kernel(TwoLinkP<T> K, long B, T* __restrict__ qg, T* __restrict__ dqg, const T* __restrict__ ug) {
+  ABRK_ROW_INDEX
+  twolink_step_body<T>(b, K, qg, dqg, ug);
+}
+
+struct RolloutArgs {
+  const void *P, *K;  // OscP<T>, TwoLinkP<T>
+  int use_C, n_steps, every;
+  void *q, *dq;
+  const void* target;
+  void *ierr, *qt, *dqt, *ut;
+};
+
 struct LawArgs {
   const void* P;  // OscP<T>
   const void *J, *M, *g, *c, *xyz, *R, *q, *dq, *target, *tv, *une;
@@ -138,7 +162,9 @@ struct ArmOps {
   hipError_t (*osc)(int dtype, const LaunchArgs&, const OscArgs&);
   hipError_t (*sliding)(int dtype, const LaunchArgs&, const SlidingArgs&);
   hipError_t (*joint)(int dtype, const LaunchArgs&, const JointArgs&);
+  hipError_t (*rollout)(int dtype, const LaunchArgs&, const RolloutArgs&);  // two-joint arms only, else null
 };
+hipError_t launch_twolink_step(int dtype, const LaunchArgs& la, const void* K, void* q, void* dq, const void* u);
 
 inline dim3 grid_for(long B) { return dim3((unsigned)((B + kBlock - 1) / kBlock)); }
 template <class A, class T>
@@ -212,8 +238,28 @@ struct OpsFor {
   static hipError_t joint(int dt, const LaunchArgs& la, const JointArgs& a) {
     return dt == 0 ? Launch<AD, double>::joint(la, a) : Launch<AF, float>::joint(la, a);
   }
+  template <class A, class T>
+  static hipError_t rollout_t(const LaunchArgs& la, const RolloutArgs& a) {
+    if constexpr (A::N == 2) {
+      A arm = Launch<A, T>::arm_of(la);
+      if (a.use_C)
+        hipLaunchKernelGGL((rollout_kernel<A, T, true>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm,
+                           *static_cast<const OscP<T>*>(a.P), *static_cast<const TwoLinkP<T>*>(a.K), la.B, a.n_steps,
+                           a.every, (T*)a.q, (T*)a.dq, (const T*)a.target, (T*)a.ierr, (T*)a.qt, (T*)a.dqt, (T*)a.ut);
+      else
+        hipLaunchKernelGGL((rollout_kernel<A, T, false>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm,
+                           *static_cast<const OscP<T>*>(a.P), *static_cast<const TwoLinkP<T>*>(a.K), la.B, a.n_steps,
+                           a.every, (T*)a.q, (T*)a.dq, (const T*)a.target, (T*)a.ierr, (T*)a.qt, (T*)a.dqt, (T*)a.ut);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  static hipError_t rollout(int dt, const LaunchArgs& la, const RolloutArgs& a) {
+    return dt == 0 ? rollout_t<AD, double>(la, a) : rollout_t<AF, float>(la, a);
+  }
   static const ArmOps* ops() {
-    static const ArmOps o = {AD::N, &dyn, &osc, &sliding, &joint};
+    static const ArmOps o = {AD::N, &dyn, &osc, &sliding, &joint, AD::N == 2 ? &rollout : nullptr};
     return &o;
   }
 };

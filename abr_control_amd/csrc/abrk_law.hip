@@ -19,4 +19,13 @@ hipError_t launch_osc_law(int n, int dtype, const LaunchArgs& la, const LawArgs&
 #undef ABRK_CASE
   return hipErrorInvalidValue;
 }
+hipError_t launch_twolink_step(int dtype, const LaunchArgs& la, const void* K, void* q, void* dq, const void* u) {
+  if (dtype == 0)
+    hipLaunchKernelGGL((twolink_step_kernel<double>), grid_for(la.B), dim3(kBlock), 0, la.stream,
+                       *static_cast<const TwoLinkP<double>*>(K), la.B, (double*)q, (double*)dq, (const double*)u);
+  else
+    hipLaunchKernelGGL((twolink_step_kernel<float>), grid_for(la.B), dim3(kBlock), 0, la.stream,
+                       *static_cast<const TwoLinkP<float>*>(K), la.B, (float*)q, (float*)dq, (const float*)u);
+  return hipGetLastError();
+}
 }  // namespace abrk

@@ -249,4 +249,53 @@ ABRK_INL void joint_body(long b, const A& arm, const JointP<T>& P, long B, const
   store_row<N>(ug, b, u);
 }
 
+// ---- closed loop: n_steps x { OSC.generate ; ArmSim._step } with the state kept in registers
+// (examples/PyGame/force_osc_xy.py:57-78).  Two-joint arms only.
+template <class A, class T, bool USE_C>
+ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLinkP<T>& K, long B, int n_steps, int every,
+                           T* __restrict__ qg, T* __restrict__ dqg, const T* __restrict__ tg, T* __restrict__ ierrg,
+                           T* __restrict__ qt, T* __restrict__ dqt, T* __restrict__ ut) {
+  static_assert(A::N == 2, "the reference's Python plant is the two-link arm");
+  T q[2], dq[2], tgt[6], tv[6], ierr[6], une[2], u[2], ts[2];
+  load_row<2>(qg, b, q);
+  load_row<2>(dqg, b, dq);
+  load_row<6>(tg, b, tgt);
+  const bool have_ierr = ierrg != nullptr;
+  if (have_ierr) load_row<6>(ierrg, b, ierr);
+  else sfor<6>([&](auto r) ABRK_LAMBDA { ierr[r()] = T(0); });
+  sfor<6>([&](auto r) ABRK_LAMBDA { tv[r()] = T(0); });
+  une[0] = une[1] = T(0);
+  const int n_chk = every > 0 ? n_steps / every : 0;
+  int chk = 0, until = every;
+  for (int t = 0; t < n_steps; t++) {
+    osc_row<A, T, 6, USE_C, true>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {});
+    twolink_step(K, q, dq, u);
+    if (every > 0 && --until == 0) {
+      until = every;
+      if (chk < n_chk) {
+        const long o = (b * n_chk + chk) * 2;
+        if (qt) { qt[o] = q[0]; qt[o + 1] = q[1]; }
+        if (dqt) { dqt[o] = dq[0]; dqt[o + 1] = dq[1]; }
+        if (ut) { ut[o] = u[0]; ut[o + 1] = u[1]; }
+      }
+      chk++;
+    }
+  }
+  store_row<2>(qg, b, q);
+  store_row<2>(dqg, b, dq);
+  if (have_ierr) store_row<6>(ierrg, b, ierr);
+}
+
+template <class T>
+ABRK_INL void twolink_step_body(long b, const TwoLinkP<T>& K, T* __restrict__ qg, T* __restrict__ dqg,
+                                const T* __restrict__ ug) {
+  T q[2], dq[2], u[2];
+  load_row<2>(qg, b, q);
+  load_row<2>(dqg, b, dq);
+  load_row<2>(ug, b, u);
+  twolink_step(K, q, dq, u);
+  store_row<2>(qg, b, q);
+  store_row<2>(dqg, b, dq);
+}
+
 }  // namespace abrk

@@ -209,3 +209,43 @@ def joint_generate(arm_id, n, ctrl, account_for_gravity, q, dq, target=None, tar
     check(lib().abrk_joint_generate_batch(arm_id, a.code, C.byref(ctrl), int(bool(account_for_gravity)), B, qp, dqp,
                                           tp, tvp, up, device, _sp(stream)))
     return uo
+
+
+def _inout(a, arr, shape, name):
+    """in/out state array: DeviceArray, or a C-contiguous ndarray of the call dtype updated in place"""
+    if isinstance(arr, DeviceArray):
+        return a.inp(arr, shape, name)
+    if (not isinstance(arr, np.ndarray) or arr.dtype != a.np_dtype or arr.shape != tuple(shape)
+            or not arr.flags.c_contiguous):
+        raise ValueError(f"{name} must be a C-contiguous ndarray {tuple(shape)} of the call dtype (updated in place)")
+    a._mode(False)
+    return arr.ctypes.data
+
+
+def twolink_step(plant, q, dq, u, dtype=np.float64, device=0, stream=None):
+    """ArmSim._step for a batch: (q, dq) [B,2] advanced in place by torques u [B,2]."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp, dqp = _inout(a, q, (B, 2), "q"), _inout(a, dq, (B, 2), "dq")
+    up = a.inp(u, (B, 2), "u")
+    check(lib().abrk_twolink_step_batch(a.code, C.byref(plant), B, qp, dqp, up, device, _sp(stream)))
+
+
+def osc_rollout_twolink(arm_id, params, plant, q, dq, target, n_steps, every=0, integrated_error=None,
+                        want_traj=False, dtype=np.float64, device=0, stream=None):
+    """n_steps x { OSC.generate ; ArmSim._step } in one launch.  q, dq [B,2] are advanced in place.
+    Returns (q_traj, dq_traj, u_traj) [B, n_steps // every, 2] when want_traj, else None."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp, dqp = _inout(a, q, (B, 2), "q"), _inout(a, dq, (B, 2), "dq")
+    tp = a.inp(target, (B, 6), "target")
+    iep = None if integrated_error is None else _inout(a, integrated_error, (B, 6), "integrated_error")
+    outs, ptrs = (None, None, None), (None, None, None)
+    if want_traj:
+        n_chk = n_steps // every if every else 0
+        pairs = [a.out(None, (B, n_chk, 2), device, nm) for nm in ("q_traj", "dq_traj", "u_traj")]
+        ptrs, outs = tuple(p for p, _ in pairs), tuple(o for _, o in pairs)
+    check(lib().abrk_osc_rollout_twolink_batch(arm_id, a.code, C.byref(params), C.byref(plant), B, int(n_steps),
+                                               int(every), qp, dqp, tp, iep, ptrs[0], ptrs[1], ptrs[2], device,
+                                               _sp(stream)))
+    return outs if want_traj else None

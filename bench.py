@@ -42,7 +42,11 @@ WORKLOADS = {
     # not a BASELINE config: the batched robot_config surface (Tx, J, M, g in one launch) - the
     # HBM-bound "full outputs" mode of SURVEY.md 8d
     "dynF": ("ur5", 4096, "f64", "dyn", dict(want=("Tx", "J", "M", "g")), 2500),
+    # SURVEY 8f-1 (first "next" row): the examples' closed loop on the device - OSC.generate followed by the
+    # two-link plant step (arms/twojoint/arm_sim.py:101-137), `rollout_steps` control steps per launch
+    "rollout": ("twojoint", 4096, "f64", "rollout", dict(kp=20, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 0]), 600),
 }
+ROLLOUT_STEPS = 1000
 
 
 def algorithmic_bytes(n, esz, kind):
@@ -50,6 +54,8 @@ def algorithmic_bytes(n, esz, kind):
     Full-output dynamics: read q [n], write Tx[3] + J[6,n] + M[n,n] + g[n]."""
     if kind == "dyn":
         return esz * n + esz * (3 + 6 * n + n * n + n)
+    if kind == "rollout":  # per launch and row: q, dq in/out + target; amortised over ROLLOUT_STEPS
+        return esz * (4 * n + 6)
     nt = 3 if kind == "sliding" else 6
     return esz * (2 * n + nt) + esz * n
 
@@ -85,7 +91,20 @@ class Runner:
         self.dq = a.DeviceArray.from_numpy(dq, device)
         self.t = a.DeviceArray.from_numpy(t, device)
         self.u = a.DeviceArray((B, self.n), self.dt, device)
-        if kind == "dyn":
+        if kind == "rollout":
+            rc_L = np.array([[0, 0, 0], [0, 0, 0], [1.0, 0, 0], [1.0, 0, 0], [0.6, 0, 0], [0.6, 0, 0]])
+            M = [np.diag(tab["mdiag"][l]) for l in range(3)]
+            self.plant = _abi.make_twolink_plant(rc_L, M, 0.001)
+            nulls = [_abi.make_damping(10), _abi.make_resting([np.pi / 4, np.pi], kp=50, kv=np.sqrt(50))]
+            self.params = _abi.make_osc_params(2, null_controllers=nulls, **kw)
+            q0 = (np.array([np.pi / 4, np.pi / 4]) + np.random.RandomState(1).uniform(-0.6, 0.6, (B, 2))).astype(self.dt)
+            t6 = np.zeros((B, 6), self.dt)
+            t6[:, :2] = np.random.RandomState(2).uniform(-1.5, 1.5, (B, 2))
+            self.q0 = q0
+            self.q = a.DeviceArray.from_numpy(q0, device)
+            self.dq = a.DeviceArray.from_numpy(np.zeros((B, 2), self.dt), device)
+            self.t = a.DeviceArray.from_numpy(t6, device)
+        elif kind == "dyn":
             n = self.n
             shapes = {"Tx": (3,), "J": (6, n), "M": (n, n), "g": (n,)}
             self.want = kw["want"]
@@ -96,9 +115,13 @@ class Runner:
             nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
             self.params = _abi.make_osc_params(self.n, null_controllers=nulls, **kw)
         self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
+        self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else 1)
 
     def step(self):
-        if self.kind == "dyn":
+        if self.kind == "rollout":
+            self.engine.osc_rollout_twolink(self.arm_id, self.params, self.plant, self.q, self.dq, self.t,
+                                            ROLLOUT_STEPS, dtype=self.dt, device=self.device, stream=self.stream)
+        elif self.kind == "dyn":
             self.engine.dynamics(self.arm_id, self.n, self.q, None, None, None, self.want, self.dt, self.device,
                                  self.stream, out=self.dyn_out)
         elif self.kind == "sliding":
@@ -141,8 +164,8 @@ def profiled_traffic(kernel, batch):
 
 
 def roofline(runner, ms_per_launch, label):
-    evals_s = runner.B / (ms_per_launch * 1e-3)
-    gbs = evals_s * runner.bytes_per_eval / 1e9
+    evals_s = runner.evals_per_launch / (ms_per_launch * 1e-3)
+    gbs = runner.B / (ms_per_launch * 1e-3) * runner.bytes_per_eval / 1e9
     tf = evals_s * runner.flops / 1e12
     kname = {"sliding": "sliding_kernel", "dyn": "dyn_kernel"}.get(runner.kind, "osc_kernel")
     return {
@@ -295,7 +318,7 @@ def main():
         tt = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt[0])
-    value = world * B * args.steps / wall
+    value = world * run.evals_per_launch * args.steps / wall
 
     out = None
     if rank == 0:

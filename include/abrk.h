@@ -217,6 +217,30 @@ int abrk_sliding_generate_batch(int arm_id, int dtype, const abrk_sliding_params
                                 const void* target_velocity, const void* target_acc, void* u,
                                 void* s, int device, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Closed loop on the device: the reference's examples alternate OSC.generate and
+ * the two-link plant step ArmSim._step (abr_control/arms/twojoint/arm_sim.py:101-137) once per
+ * millisecond of simulated time (examples/PyGame/force_osc_xy.py:57-78).  K1..K4 are the constants
+ * ArmSim.__init__ derives (arm_sim.py:26-41); dt the Euler step.
+ * --------------------------------------------------------------------------------- */
+typedef struct abrk_twolink_plant {
+  double K1, K2, K3, K4;
+  double dt;
+} abrk_twolink_plant;
+
+/* ArmSim._step for B arms: (q, dq) [B,2] advanced in place by the torques u [B,2].            */
+int abrk_twolink_step_batch(int dtype, const abrk_twolink_plant* plant, int64_t B, void* q, void* dq,
+                            const void* u, int device, void* stream);
+
+/* n_steps x { u = OSC.generate(q, dq, target); ArmSim._step(u) } in ONE launch, state in registers.
+ *   arm_id: a two-joint arm; q, dq [B,2] in/out; target [B,6]; integrated_error [B,6] in/out (ki != 0);
+ *   checkpoints (optional, every `every` steps, n_chk = n_steps / every):
+ *   q_traj, dq_traj, u_traj [B, n_chk, 2] or NULL.                                              */
+int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_osc_params* params,
+                                   const abrk_twolink_plant* plant, int64_t B, int32_t n_steps, int32_t every,
+                                   void* q, void* dq, const void* target, void* integrated_error,
+                                   void* q_traj, void* dq_traj, void* u_traj, int device, void* stream);
+
 /* Joint.generate (controllers/joint.py:104-131) / Damping / RestingConfig standalone.
  *   ctrl.kind == ABRK_NULL_DAMPING: u = M (-kv dq)            (damping.py:31-32)
  *   ctrl.kind == ABRK_NULL_RESTING: RestingConfig.generate     (resting_config.py:33-42)

@@ -196,6 +196,36 @@ def gen_arm(arm):
 
     if arm == "twojoint":
         xy = [True, True, False, False, False, False]
+        # closed loop = the examples' hot loop (examples/PyGame/force_osc_xy.py:57-78): OSC.generate
+        # -> ArmSim._step (arms/twojoint/arm_sim.py:101-137), controller settings of that example
+        from abr_control.arms.twojoint import ArmSim
+
+        rng = np.random.RandomState(40)
+        Br, T, every = 48, 300, 25
+        q0 = np.asarray(rc.START_ANGLES, float) + rng.uniform(-0.6, 0.6, (Br, 2))
+        dq0 = rng.uniform(-0.5, 0.5, (Br, 2))
+        tgt = np.zeros((Br, 6))
+        tgt[:, :2] = rng.uniform(-1.6, 1.6, (Br, 2))
+        out["rollout_q0"], out["rollout_dq0"], out["rollout_target"] = q0, dq0, tgt
+        out["rollout_every"], out["rollout_T"] = every, T
+        for label, cfg in (("S", rc), ("D", raw)):
+            qs = np.zeros((Br, T // every, 2))
+            dqs = np.zeros((Br, T // every, 2))
+            us = np.zeros((Br, T // every, 2))
+            for b in range(Br):
+                ctrlr = OSC(cfg, kp=20, use_C=True, ctrlr_dof=xy, null_controllers=[
+                    Damping(cfg, kv=10),
+                    RestingConfig(cfg, kp=50, kv=np.sqrt(50), rest_angles=[np.pi / 4, np.pi])])
+                sim = ArmSim(rc, dt=0.001, q_init=q0[b].copy())
+                sim.dq = dq0[b].copy()
+                for t in range(T):
+                    u = ctrlr.generate(q=sim.q, dq=sim.dq, target=tgt[b])
+                    sim.send_forces(u)
+                    if (t + 1) % every == 0:
+                        qs[b, t // every], dqs[b, t // every], us[b, t // every] = sim.q, sim.dq, u
+            out[f"rollout_q{label}"], out[f"rollout_dq{label}"], out[f"rollout_u{label}"] = qs, dqs, us
+        d = np.max(np.abs(out["rollout_qS"] - out["rollout_qD"]))
+        print(f"  rollout: B={Br} T={T}: max |q_S - q_D| over checkpoints = {d:.2e}", flush=True)
         # BASELINE config 1: twojoint OSC position control (row 0 is the "batch=1" case)
         run_osc("cfg1", 256, 0, dict(kp=10, kv=3, ctrlr_dof=xy))
         run_osc("osc_xy_vmax", 128, 2, dict(kp=20, kv=5, ctrlr_dof=xy, vmax=[0.5, 0.5]))

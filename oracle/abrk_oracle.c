@@ -826,3 +826,44 @@ int abrk_oracle_sliding_generate_batch(const abrk_arm_desc* a, const abrk_slidin
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------ two-link plant + closed loop
+ * ArmSim._step, arms/twojoint/arm_sim.py:101-137 (constants K1..K4 arm_sim.py:33-41), and the example
+ * loop examples/PyGame/force_osc_xy.py:57-78: u = ctrlr.generate(q, dq, target); sim.send_forces(u). */
+void abrk_oracle_twolink_step(const abrk_twolink_plant* K, double q[2], double dq[2], const double u[2]) {
+  double C2 = cos(q[1]), S2 = sin(q[1]);
+  double M11 = K->K1 + K->K2 * C2;
+  double M12 = K->K3 + K->K4 * C2;
+  double M21 = M12, M22 = K->K3;
+  double H1 = -K->K2 * S2 * dq[0] * dq[1] - 1.0 / 2.0 * K->K2 * S2 * pow(dq[1], 2.0);
+  double H2 = 1.0 / 2.0 * K->K2 * S2 * pow(dq[0], 2.0);
+  double ddq1 = (H2 * M11 - H1 * M21 - M11 * u[1] + M21 * u[0]) / (pow(M12, 2.0) - M11 * M22);
+  double ddq0 = (-H2 + u[1] - M22 * ddq1) / M21;
+  dq[0] += ddq0 * K->dt;
+  dq[1] += ddq1 * K->dt;
+  q[0] += dq[0] * K->dt;
+  q[1] += dq[1] * K->dt;
+}
+
+int abrk_oracle_rollout_twolink(const abrk_arm_desc* a, const abrk_osc_params* P, const abrk_twolink_plant* K,
+                                int64_t B, int n_steps, int every, double* q, double* dq, const double* target,
+                                double* integrated_error, double* q_traj, double* dq_traj, double* u_traj) {
+  if (a->n_joints != 2) return -1;
+  int n_chk = every > 0 ? n_steps / every : 0;
+  for (int64_t b = 0; b < B; b++) {
+    double u[2];
+    for (int t = 0; t < n_steps; t++) {
+      int rc = abrk_oracle_osc_generate(a, P, q + b * 2, dq + b * 2, target + b * 6, NULL,
+                                        integrated_error ? integrated_error + b * 6 : NULL, NULL, u, NULL);
+      if (rc) return rc;
+      abrk_oracle_twolink_step(K, q + b * 2, dq + b * 2, u);
+      if (every > 0 && (t + 1) % every == 0 && (t + 1) / every <= n_chk) {
+        int64_t o = (b * n_chk + (t + 1) / every - 1) * 2;
+        if (q_traj) { q_traj[o] = q[b * 2]; q_traj[o + 1] = q[b * 2 + 1]; }
+        if (dq_traj) { dq_traj[o] = dq[b * 2]; dq_traj[o + 1] = dq[b * 2 + 1]; }
+        if (u_traj) { u_traj[o] = u[0]; u_traj[o + 1] = u[1]; }
+      }
+    }
+  }
+  return 0;
+}

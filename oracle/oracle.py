@@ -145,6 +145,19 @@ class Oracle:
         return u
 
 
+def rollout_twolink(table, params, plant, q0, dq0, target, n_steps, every):
+    """closed loop OSC.generate + ArmSim._step (examples/PyGame/force_osc_xy.py:57-78) on the oracle"""
+    o = Oracle(table)
+    q, dq, target = _c(q0).copy(), _c(dq0).copy(), _c(target)
+    B = q.shape[0]
+    n_chk = n_steps // every
+    qt, dqt, ut = np.zeros((B, n_chk, 2)), np.zeros((B, n_chk, 2)), np.zeros((B, n_chk, 2))
+    rc = o.L.abrk_oracle_rollout_twolink(o._d, C.byref(params), C.byref(plant), C.c_int64(B), n_steps, every,
+                                         _p(q), _p(dq), _p(target), None, _p(qt), _p(dqt), _p(ut))
+    assert rc == 0, rc
+    return q, dq, qt, dqt, ut
+
+
 def quat_from_matrix(R):
     out = np.zeros(4)
     lib().abrk_oracle_quat_from_matrix(_p(_c(R)), _p(out))

@@ -124,3 +124,16 @@ def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=N
                                _p(R), _p(q), _p(dq), _p(target), _p(tv), _p(integrated_error), _p(une), _p(u), _p(ts))
     assert rc == 0, rc
     return u, ts
+
+
+def rollout_twolink(arm, params, plant, q0, dq0, target, n_steps, every, dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q, dq, target = _in(q0, dt).copy(), _in(dq0, dt).copy(), _in(target, dt)
+    B = q.shape[0]
+    n_chk = n_steps // every
+    qt, dqt, ut = (np.full((B, n_chk, 2), np.nan, dt) for _ in range(3))
+    rc = lib().hostsim_rollout(name, desc, _dtype_code(dt), C.byref(params), C.byref(plant), C.c_int64(B), n_steps, every,
+                               _p(q), _p(dq), _p(target), _p(qt), _p(dqt), _p(ut))
+    assert rc == 0, rc
+    return q, dq, qt, dqt, ut

@@ -174,3 +174,27 @@ extern "C" int hostsim_osc_law(int n, int dtype, const abrk_osc_params* P, int64
 #undef LAW_CASE
   return -1;
 }
+
+extern "C" int hostsim_rollout(const char* builtin, const abrk_arm_desc* d, int dtype, const abrk_osc_params* P,
+                               const abrk_twolink_plant* plant, int64_t B, int n_steps, int every, void* q, void* dq,
+                               const void* tg, void* qt, void* dqt, void* ut) {
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int n) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    if constexpr (A::N == 2) {
+      OscP<T> p = make_oscp<T>(*P, n);
+      TwoLinkP<T> k{T(plant->K1), T(plant->K2), T(plant->K3), T(plant->K4), T(plant->dt)};
+      for (long b = 0; b < B; b++) {
+        if (P->use_C)
+          rollout_body<A, T, true>(b, a, p, k, (long)B, n_steps, every, (T*)q, (T*)dq, (const T*)tg, (T*)nullptr, (T*)qt,
+                                   (T*)dqt, (T*)ut);
+        else
+          rollout_body<A, T, false>(b, a, p, k, (long)B, n_steps, every, (T*)q, (T*)dq, (const T*)tg, (T*)nullptr,
+                                    (T*)qt, (T*)dqt, (T*)ut);
+      }
+      return 0;
+    } else {
+      return -1;
+    }
+  });
+}

@@ -353,3 +353,52 @@ def test_gpu_foreign_robot_config_runs_the_law_on_the_gpu():
     c = OSC(rj, kp=200, null_controllers=[ForeignDamping(rj, 10)])
     u = c.generate(g2["cfg3_q"][:64], g2["cfg3_dq"][:64], g2["cfg3_target"][:64])
     assert cases.rel_err(u, g2["cfg3_uD"][:64]).max() <= 1e-6
+
+
+def test_gpu_closed_loop_rollout_and_plant():
+    """two-link plant step and the fused on-device control loop vs the reference's own loop
+    (OSC.generate + ArmSim._step for 300 ms of simulated time, examples/PyGame/force_osc_xy.py:57-78)"""
+    from abr_control_amd.arms import twojoint
+    from abr_control_amd.controllers import OSC, Damping, RestingConfig
+
+    g = golden("twojoint")
+    T, every = int(g["rollout_T"]), int(g["rollout_every"])
+    rc = twojoint.Config()
+    mk = lambda: OSC(rc, kp=20, use_C=True, ctrlr_dof=[True, True, False, False, False, False], null_controllers=[
+        Damping(rc, kv=10), RestingConfig(rc, kp=50, kv=np.sqrt(50), rest_angles=[np.pi / 4, np.pi])])
+    # fused rollout, whole batch
+    sim = twojoint.ArmSim(rc, dt=0.001, q_init=g["rollout_q0"].copy())
+    sim.dq = g["rollout_dq0"].copy()
+    qt, dqt, ut = sim.rollout(mk(), g["rollout_target"], T, every)
+    assert np.max(np.abs(qt - g["rollout_qD"])) < 1e-9
+    assert np.max(np.abs(dqt - g["rollout_dqD"])) < 1e-7
+    assert np.max(np.abs(ut - g["rollout_uD"])) / np.max(np.abs(g["rollout_uD"])) < 1e-8
+    assert np.array_equal(sim.q, qt[:, -1]) and abs(sim.t - 0.3) < 1e-12
+    # the reference's own loop shape, one arm, step by step: generate -> send_forces
+    sim1 = twojoint.ArmSim(rc, dt=0.001, q_init=g["rollout_q0"][5].copy())
+    sim1.dq = g["rollout_dq0"][5].copy()
+    c = mk()
+    for t in range(50):
+        fb = sim1.get_feedback()
+        u = c.generate(q=fb["q"], dq=fb["dq"], target=g["rollout_target"][5])
+        sim1.send_forces(u)
+    assert sim1.q.shape == (2,)
+    assert np.max(np.abs(sim1.q - g["rollout_qD"][5, 1])) < 1e-9  # checkpoint 2 = step 50
+    # large batch: rollout == repeated single steps on the device (same bits), 4096 arms x 40 steps
+    rng = np.random.RandomState(3)
+    B = 4096
+    q0 = np.array([np.pi / 4, np.pi / 4]) + rng.uniform(-0.6, 0.6, (B, 2))
+    tgt = np.zeros((B, 6))
+    tgt[:, :2] = rng.uniform(-1.5, 1.5, (B, 2))
+    a = twojoint.ArmSim(rc, q_init=q0.copy())
+    a.rollout(mk(), tgt, 40)
+    b = twojoint.ArmSim(rc, q_init=q0.copy())
+    c = mk()
+    for t in range(40):
+        b.send_forces(c.generate(b.q, b.dq, tgt))
+    assert np.max(np.abs(a.q - b.q)) < 1e-12 and np.all(np.isfinite(a.q))
+    with pytest.raises(Exception, match="two-link"):
+        from abr_control_amd import engine
+        from abr_control_amd.arms import ur5
+        engine.osc_rollout_twolink(ur5.Config().arm_id, _abi.make_osc_params(6), a._plant, np.zeros((1, 2)),
+                                   np.zeros((1, 2)), np.zeros((1, 6)), 1)

@@ -141,3 +141,20 @@ def test_rows_law_only_path(case_id):
         ok &= ~band[:rows]
     tol = cases.TOL_THREEJOINT if arm == "threejoint" else 1e-6
     assert cases.rel_err(u, g[f"{key}_uD"][:rows])[ok].max() <= tol
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+def test_rows_closed_loop_rollout(variant):
+    """the fused rollout row program (OSC.generate + ArmSim._step per step, state in registers)"""
+    from tests import hostsim
+    from tests.test_oracle_golden import _rollout_setup
+
+    g, tab, plant, params = _rollout_setup()
+    T, every = int(g["rollout_T"]), int(g["rollout_every"])
+    arm = "twojoint" if variant == "static" else tab
+    q, dq, qt, dqt, ut = hostsim.rollout_twolink(arm, params, plant, g["rollout_q0"], g["rollout_dq0"],
+                                                 g["rollout_target"], T, every)
+    assert np.max(np.abs(qt - g["rollout_qD"])) < 1e-9
+    assert np.max(np.abs(dqt - g["rollout_dqD"])) < 1e-7
+    assert np.max(np.abs(ut - g["rollout_uD"])) / np.max(np.abs(g["rollout_uD"])) < 1e-8
+    assert np.array_equal(q, qt[:, -1])

@@ -78,3 +78,33 @@ def test_oracle_velocity_limiting_exact_values():
     assert np.allclose(vl([0.05] * 6), [kp * 0.05] * 3 + [ko * 0.05] * 3, atol=1e-5)
     assert np.allclose(vl([100.0] * 3 + [0.05] * 3), [kv * np.sqrt(vmax / 3)] * 3 + [ko * 0.05] * 3, atol=1e-5)
     assert np.allclose(vl([100.0] * 6), [kv * np.sqrt(vmax / 3)] * 6, atol=1e-5)
+
+
+def _rollout_setup():
+    from abr_control_amd import _abi
+    from abr_control_amd._abi import make_damping, make_osc_params, make_resting
+
+    g = golden("twojoint")
+    tab = _abi.load_table("twojoint")
+    L = np.array([np.asarray(tab["A0"])[:, 3]] + [np.asarray(m)[:, 3] for i in range(2) for m in (tab["AJ"][i], tab["B"][i])]
+                 + [np.asarray(tab["E"])[:, 3]])
+    M = [np.diag(tab["mdiag"][l]) for l in range(3)]
+    plant = _abi.make_twolink_plant(L, M, 0.001)
+    params = make_osc_params(2, kp=20, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 0], null_controllers=[
+        make_damping(10), make_resting([np.pi / 4, np.pi], kp=50, kv=np.sqrt(50))])
+    return g, tab, plant, params
+
+
+def test_oracle_closed_loop_matches_reference():
+    """300 steps of OSC.generate + ArmSim._step (examples/PyGame/force_osc_xy.py:57-78) vs the reference loop"""
+    from oracle import oracle as O
+
+    g, tab, plant, params = _rollout_setup()
+    assert np.allclose([plant.K1, plant.K2, plant.K3, plant.K4], [8.5536, 3.168, 0.6336, 1.584])
+    T, every = int(g["rollout_T"]), int(g["rollout_every"])
+    q, dq, qt, dqt, ut = O.rollout_twolink(tab, params, plant, g["rollout_q0"], g["rollout_dq0"], g["rollout_target"],
+                                           T, every)
+    assert np.max(np.abs(qt - g["rollout_qD"])) < 1e-9
+    assert np.max(np.abs(dqt - g["rollout_dqD"])) < 1e-8
+    assert np.max(np.abs(qt - g["rollout_qS"])) < 1e-3  # the shipped (float32-rounding) loop drifts ~4e-5
+    assert np.array_equal(q, qt[:, -1]) and np.array_equal(dq, dqt[:, -1])
