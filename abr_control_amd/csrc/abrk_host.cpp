@@ -157,6 +157,7 @@ extern "C" int abrk_arm_destroy(int arm_id) {
 }
 
 // ------------------------------------------------------------------------------- device plumbing
+static thread_local int t_current_device = -1;  // what this thread last hipSetDevice'd (plan launches skip the call)
 static int use_device(int device) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -167,6 +168,7 @@ static int use_device(int device) {
   }
   if (device < 0 || device >= n) return fail(ABRK_EINVAL, "device %d outside 0..%d", device, n - 1);
   HIPCHK(hipSetDevice(device));
+  t_current_device = device;
   return 0;
 }
 
@@ -745,4 +747,89 @@ extern "C" int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_
                 (long)B, (hipStream_t)stream};
   HIPCHK(a->ops->rollout(dtype, la, ra));
   return st.finish();
+}
+
+// ------------------------------------------------------------------------------- launch plans
+namespace {
+struct OscPlan {
+  bool live = false;
+  int dtype = 0, device = 0;
+  const ArmOps* ops = nullptr;
+  std::vector<unsigned char> rt;  // private copy of the user-arm table
+  OscP<double> p64;
+  OscP<float> p32;
+  OscArgs oa;
+  LaunchArgs la;
+};
+std::mutex g_plan_mu;
+std::vector<OscPlan*> g_plans;
+}  // namespace
+
+extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                                    const void* dq, const void* target, const void* target_velocity,
+                                    void* integrated_error, const void* u_null_ext, void* u,
+                                    void* training_signal, int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (P->ref_frame < 0 || P->ref_frame > 2 * n + 1)
+    return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", P->ref_frame);
+  if (P->n_null < 0 || P->n_null > ABRK_MAX_NULL) return fail(ABRK_EINVAL, "n_null=%d outside 0..%d", P->n_null, ABRK_MAX_NULL);
+  if (P->orientation_algorithm != 0 && P->orientation_algorithm != 1)
+    return fail(ABRK_EINVAL, "Invalid algorithm number %d for calculating orientation error", P->orientation_algorithm);
+  int k = 0;
+  for (int r = 0; r < 6; r++) k += P->ctrlr_dof[r] ? 1 : 0;
+  if (k == 0) return fail(ABRK_EINVAL, "ctrlr_dof selects no task-space dimension");
+  if (B <= 0) return fail(ABRK_EINVAL, "a plan needs a positive batch");
+  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
+  if (P->ki != 0 && !integrated_error) return fail(ABRK_EINVAL, "ki != 0 needs the integrated_error state array");
+  if (int rc = use_device(device)) return rc;
+  const void* ptrs[] = {q, dq, target, target_velocity, integrated_error, u_null_ext, u, training_signal};
+  for (const void* p : ptrs)
+    if (p && !is_device_ptr(p)) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
+  OscPlan* pl = new OscPlan;
+  pl->live = true;
+  pl->dtype = dtype;
+  pl->device = device;
+  pl->ops = a->ops;
+  if (!a->builtin) pl->rt = dtype == ABRK_F64 ? a->rt64 : a->rt32;
+  pl->p64 = make_oscp<double>(*P, n);
+  pl->p32 = make_oscp<float>(*P, n);
+  pl->oa.P = dtype == ABRK_F64 ? (const void*)&pl->p64 : (const void*)&pl->p32;
+  pl->oa.q = q;
+  pl->oa.dq = dq;
+  pl->oa.target = target;
+  pl->oa.tv = target_velocity;
+  pl->oa.ierr = (P->ki != 0) ? integrated_error : nullptr;
+  pl->oa.une = u_null_ext;
+  pl->oa.u = u;
+  pl->oa.ts = training_signal;
+  pl->oa.use_C = P->use_C ? 1 : 0;
+  pl->oa.fast = osc_is_fast(*P, n, u_null_ext != nullptr);
+  pl->la = LaunchArgs{a->builtin ? nullptr : (const void*)pl->rt.data(), (long)B, (hipStream_t)stream};
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  g_plans.push_back(pl);
+  return (int)g_plans.size() - 1;
+}
+
+extern "C" int abrk_plan_launch(int plan) {
+  // plans are append-only: reading the slot needs no lock once the id has been handed out
+  if (plan < 0 || plan >= (int)g_plans.size() || !g_plans[plan] || !g_plans[plan]->live)
+    return fail(ABRK_EINVAL, "unknown plan %d", plan);
+  OscPlan* pl = g_plans[plan];
+  if (t_current_device != pl->device) {
+    HIPCHK(hipSetDevice(pl->device));
+    t_current_device = pl->device;
+  }
+  HIPCHK(pl->ops->osc(pl->dtype, pl->la, pl->oa));
+  return 0;
+}
+
+extern "C" int abrk_plan_destroy(int plan) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  if (plan < 0 || plan >= (int)g_plans.size() || !g_plans[plan] || !g_plans[plan]->live)
+    return fail(ABRK_EINVAL, "unknown plan %d", plan);
+  g_plans[plan]->live = false;
+  return 0;
 }

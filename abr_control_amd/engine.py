@@ -249,3 +249,38 @@ def osc_rollout_twolink(arm_id, params, plant, q, dq, target, n_steps, every=0, 
                                                int(every), qp, dqp, tp, iep, ptrs[0], ptrs[1], ptrs[2], device,
                                                _sp(stream)))
     return outs if want_traj else None
+
+
+class OscPlan:
+    """A validated, pre-converted OSC launch on fixed device buffers (abrk_osc_plan_create): `launch()`
+    only enqueues the kernel on the plan's stream - the per-tick cost of a control loop whose state lives
+    on the GPU.  All arrays must be DeviceArrays; update their contents between launches."""
+
+    def __init__(self, arm_id, n, params, q, dq, target, u, target_velocity=None, integrated_error=None,
+                 u_null_ext=None, training_signal=None, dtype=np.float64, device=0, stream=None):
+        a = _Args(dtype)
+        B = q.shape[0]
+        arrs = dict(q=(q, (B, n)), dq=(dq, (B, n)), target=(target, (B, 6)), target_velocity=(target_velocity, (B, 6)),
+                    integrated_error=(integrated_error, (B, 6)), u_null_ext=(u_null_ext, (B, n)), u=(u, (B, n)),
+                    training_signal=(training_signal, (B, n)))
+        ptr = {}
+        for name, (arr, shape) in arrs.items():
+            if arr is not None and not isinstance(arr, DeviceArray):
+                raise TypeError(f"{name}: launch plans take DeviceArrays")
+            ptr[name] = a.inp(arr, shape, name)
+        self._keep = [v[0] for v in arrs.values()] + [params, stream]
+        self._launch = lib().abrk_plan_launch
+        self.id = check(lib().abrk_osc_plan_create(
+            arm_id, a.code, C.byref(params), B, ptr["q"], ptr["dq"], ptr["target"], ptr["target_velocity"],
+            ptr["integrated_error"], ptr["u_null_ext"], ptr["u"], ptr["training_signal"], device, _sp(stream)))
+
+    def launch(self):
+        rc = self._launch(self.id)
+        if rc < 0:
+            check(rc)
+
+    def __del__(self):
+        try:
+            lib().abrk_plan_destroy(self.id)
+        except Exception:
+            pass

@@ -114,11 +114,18 @@ class Runner:
         else:
             nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
             self.params = _abi.make_osc_params(self.n, null_controllers=nulls, **kw)
+        self.plan = None
+        if kind in ("osc", "osc_damp"):
+            # the per-tick launch of a control loop on fixed device buffers: arguments validated once
+            self.plan = engine.OscPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
+                                       dtype=self.dt, device=device, stream=stream)
         self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
         self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else 1)
 
     def step(self):
-        if self.kind == "rollout":
+        if self.plan is not None:
+            self.plan.launch()
+        elif self.kind == "rollout":
             self.engine.osc_rollout_twolink(self.arm_id, self.params, self.plant, self.q, self.dq, self.t,
                                             ROLLOUT_STEPS, dtype=self.dt, device=self.device, stream=self.stream)
         elif self.kind == "dyn":

@@ -202,6 +202,18 @@ int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params* params, i
                        void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
                        int device, void* stream);
 
+/* Launch plans for control loops that call the same law on the same device buffers every tick (the
+ * shape of every example loop, examples/PyGame/force_osc_xy.py:57-78): all arguments of
+ * abrk_osc_generate_batch are validated and converted ONCE; abrk_plan_launch then only enqueues the
+ * kernel on the plan's stream (no pointer classification, no locks, no staging).  Every array must be a
+ * device pointer.  Returns a plan id >= 0.                                                       */
+int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params* params, int64_t B, const void* q,
+                         const void* dq, const void* target, const void* target_velocity,
+                         void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
+                         int device, void* stream);
+int abrk_plan_launch(int plan);
+int abrk_plan_destroy(int plan);
+
 /* Sliding.generate (controllers/sliding.py:34-99), cartesian=True or False.
  *   target [B,3] (cartesian) or [B,n]; target_velocity / target_acc same shape or NULL
  *   (== 0); u [B,n] out; s [B,n] out or NULL (Sliding.s, sliding.py:89).              */

@@ -402,3 +402,29 @@ def test_gpu_closed_loop_rollout_and_plant():
         from abr_control_amd.arms import ur5
         engine.osc_rollout_twolink(ur5.Config().arm_id, _abi.make_osc_params(6), a._plant, np.zeros((1, 2)),
                                    np.zeros((1, 2)), np.zeros((1, 6)), 1)
+
+
+def test_gpu_launch_plan_equals_direct_call():
+    import abr_control_amd as a
+    from abr_control_amd import engine
+
+    be = cases.GpuBackend("ur5")
+    p = _abi.make_osc_params(6, kp=200, use_C=True, null_controllers=[_abi.make_damping(5)])
+    q, dq, t = draw(31, 3000, 6)
+    dq_, q_, t_ = a.DeviceArray.from_numpy(dq), a.DeviceArray.from_numpy(q), a.DeviceArray.from_numpy(t)
+    u_ = a.DeviceArray((3000, 6))
+    s = a.Stream(0)
+    plan = engine.OscPlan(be.arm_id, 6, p, q_, dq_, t_, u_, stream=s)
+    plan.launch()
+    s.sync()
+    ref, _ = be.osc(p, q, dq, t)
+    assert np.array_equal(u_.numpy(), ref)
+    # new state in the same buffers, relaunch
+    q2, dq2, t2 = draw(32, 3000, 6)
+    for d, h in ((q_, q2), (dq_, dq2), (t_, t2)):
+        a._lib.check(a._lib.lib().abrk_memcpy_h2d(0, d.ptr, h.ctypes.data, h.nbytes, None))
+    plan.launch()
+    s.sync()
+    assert np.array_equal(u_.numpy(), be.osc(p, q2, dq2, t2)[0])
+    with pytest.raises(TypeError):
+        engine.OscPlan(be.arm_id, 6, p, q, dq_, t_, u_)
