@@ -183,7 +183,10 @@ class GpuBackend:
         from abr_control_amd._lib import check, lib
 
         self.e = engine
-        self.tab = _abi.load_table(arm)
+        if isinstance(arm, dict):  # a user arm table -> runtime-table kernels
+            self.tab, variant = arm, "rt"
+        else:
+            self.tab = _abi.load_table(arm)
         self.n = self.tab["n_joints"]
         self.device = device
         if variant == "static":

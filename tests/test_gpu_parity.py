@@ -428,3 +428,33 @@ def test_gpu_launch_plan_equals_direct_call():
     assert np.array_equal(u_.numpy(), be.osc(p, q2, dq2, t2)[0])
     with pytest.raises(TypeError):
         engine.OscPlan(be.arm_id, 6, p, q, dq_, t_, u_)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
+def test_gpu_user_arms_all_joint_counts(n):
+    """runtime-table kernels for every joint count 1..ABRK_MAX_JOINTS on synthetic arms vs the oracle"""
+    from abr_control_amd._abi import make_damping, make_osc_params as P
+    from oracle.oracle import Oracle
+    from tests.synthetic_arms import make_arm
+
+    for nonorth in (False, True):
+        tab = make_arm(n, 200 + n, nonorth)
+        be, o = cases.GpuBackend(tab), Oracle(tab)
+        rng = np.random.RandomState(n)
+        B = 200
+        q, dq, t = rng.uniform(-3, 3, (B, n)), rng.uniform(-2, 2, (B, n)), rng.uniform(-0.5, 0.5, (B, 6))
+        r = be.dynamics(q, dq, "EE", [0.05, -0.02, 0.03], ("Tx", "J", "dJ", "M", "g", "C", "R", "quat"))
+        for b in range(0, B, 9):
+            assert np.allclose(r["Tx"][b], o.Tx("EE", q[b], [0.05, -0.02, 0.03]), atol=1e-12)
+            assert np.allclose(r["J"][b], o.J("EE", q[b], [0.05, -0.02, 0.03]), atol=1e-12)
+            assert np.allclose(r["dJ"][b], o.dJ("EE", q[b], dq[b], [0.05, -0.02, 0.03]), atol=1e-11)
+            assert np.allclose(r["M"][b], o.M(q[b]), atol=1e-12) and np.allclose(r["g"][b], o.g(q[b]), atol=1e-12)
+            assert np.allclose(r["C"][b], o.C(q[b], dq[b]), atol=1e-11)
+            assert np.allclose(r["quat"][b], o.quaternion("EE", q[b]), atol=1e-10)
+        k = min(n, 3)
+        for p in (P(n, kp=30, ctrlr_dof=[1] * k + [0] * (6 - k)),
+                  P(n, kp=30, ctrlr_dof=[1] * k + [0] * (6 - k), use_C=True, null_controllers=[make_damping(3)])):
+            u, _ = be.osc(p, q, dq, t)
+            uo = o.osc_batch(p, q, dq, t)
+            ok = np.array([np.linalg.cond(o.M(q[b])) < 1e8 for b in range(B)])
+            assert cases.rel_err(u, uo)[ok].max() < 1e-6

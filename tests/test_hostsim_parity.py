@@ -158,3 +158,68 @@ def test_rows_closed_loop_rollout(variant):
     assert np.max(np.abs(dqt - g["rollout_dqD"])) < 1e-7
     assert np.max(np.abs(ut - g["rollout_uD"])) / np.max(np.abs(g["rollout_uD"])) < 1e-8
     assert np.array_equal(q, qt[:, -1])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
+def test_rows_user_arms_all_joint_counts(n):
+    """runtime-table kernels for every supported joint count (1..ABRK_MAX_JOINTS) vs the oracle on
+    synthetic arms, orthogonal and Jaco2-like non-orthogonal statics"""
+    from abr_control_amd._abi import make_damping, make_joint, make_osc_params as P, make_sliding_params
+    from oracle.oracle import Oracle
+    from tests import hostsim
+    from tests.synthetic_arms import make_arm
+
+    for nonorth in (False, True):
+        tab = make_arm(n, 100 + n, nonorth)
+        o = Oracle(tab)
+        if n == 5:  # N_LINKS short of the last link (the reference's jaco2 / onejoint quirk): M, g, C only
+            tq = make_arm(n, 100 + n, nonorth, n_links_dyn=4)
+            oq = Oracle(tq)
+            rngq = np.random.RandomState(9)
+            qq, dqq = rngq.uniform(-3, 3, (8, n)), rngq.uniform(-2, 2, (8, n))
+            rq = hostsim.dynamics(tq, qq, dqq, None, None, ("M", "g", "C"))
+            for b in range(8):
+                assert np.allclose(rq["M"][b], oq.M(qq[b]), atol=1e-12)
+                assert np.allclose(rq["g"][b], oq.g(qq[b]), atol=1e-12)
+                assert np.allclose(rq["C"][b], oq.C(qq[b], dqq[b]), atol=1e-11)
+        rng = np.random.RandomState(n)
+        B = 24
+        q, dq = rng.uniform(-3, 3, (B, n)), rng.uniform(-2, 2, (B, n))
+        for frame in ("EE", f"link{n}", f"joint{n - 1}", "link0"):
+            fid = _abi_frame(frame, n)
+            r = hostsim.dynamics(tab, q, dq, fid, [0.05, -0.02, 0.03], ("Tx", "J", "dJ", "R", "T", "Tinv", "quat"))
+            for b in range(B):
+                assert np.allclose(r["Tx"][b], o.Tx(frame, q[b], [0.05, -0.02, 0.03]), atol=1e-12)
+                assert np.allclose(r["J"][b], o.J(frame, q[b], [0.05, -0.02, 0.03]), atol=1e-12)
+                assert np.allclose(r["dJ"][b], o.dJ(frame, q[b], dq[b], [0.05, -0.02, 0.03]), atol=1e-11)
+                assert np.allclose(r["R"][b], o.R(frame, q[b]), atol=1e-13)
+                assert np.allclose(r["Tinv"][b], o.T_inv(frame, q[b]), atol=1e-12)
+        r = hostsim.dynamics(tab, q, dq, None, None, ("M", "g", "C"))
+        for b in range(B):
+            assert np.allclose(r["M"][b], o.M(q[b]), atol=1e-12)
+            assert np.allclose(r["g"][b], o.g(q[b]), atol=1e-12)
+            assert np.allclose(r["C"][b], o.C(q[b], dq[b]), atol=1e-11)
+        t = rng.uniform(-0.5, 0.5, (B, 6))
+        k = min(n, 3)
+        dof = [1] * k + [0] * (6 - k)
+        for p in (P(n, kp=30, ctrlr_dof=dof), P(n, kp=30, ctrlr_dof=dof, use_C=True, null_controllers=[make_damping(3)])):
+            u = hostsim.osc_generate(tab, p, q, dq, t)
+            uo = o.osc_batch(p, q, dq, t)
+            cond_ok = np.array([np.linalg.cond(o.M(q[b])) < 1e8 for b in range(B)])
+            assert cases.rel_err(u, uo)[cond_ok].max() < 1e-6
+        if n >= 6:
+            p = P(n, kp=30, ko=20, ctrlr_dof=[1] * 6, orientation_algorithm=1)
+            assert cases.rel_err(hostsim.osc_generate(tab, p, q, dq, t), o.osc_batch(p, q, dq, t)).max() < 1e-6
+        u = hostsim.joint_generate(tab, make_joint(10, 3), True, q, dq, q * 0.5)
+        assert cases.rel_err(u, o.joint_batch(make_joint(10, 3), True, q, dq, q * 0.5)).max() < 1e-9
+        if n >= 3:
+            ps = make_sliding_params(n)
+            u = hostsim.sliding_generate(tab, ps, q, dq, t[:, :3])
+            uo, _ = o.sliding_batch(ps, q, dq, t[:, :3])
+            assert cases.rel_err(u, uo).max() < 1e-6
+
+
+def _abi_frame(name, n):
+    from abr_control_amd import _abi
+
+    return _abi.frame_id(name, n)
