@@ -417,7 +417,7 @@ ABRK_INL void null_command(const NullP<T>& c, const T (&q)[N], const T (&dq)[N],
 // kinematics, and by the law-only kernel for robot_configs whose J/M/g come from elsewhere
 // (the reference's duck-typed boundary, e.g. MujocoConfig).  The gravity torque is gscale * gz
 // (fused path: 9.81 * gz accumulators; law-only path: -1 * g).
-template <int N, class T, int KM, bool USE_C, bool FEAT>
+template <int N, class T, int KM, bool USE_C, int FEAT>
 ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
                       const T (&cvec)[N], const T (&Jv)[N][3], const T (&Jw)[N][3], const T (&p)[3],
                       const T (&RF)[9], const T (&q)[N], const T (&dq)[N], const T (&tgt)[6], bool tv_given,
@@ -460,8 +460,8 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   T det = T(1);
   sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
   // FEAT = false needs Mx only once (Mx u_task): solved with the factor instead of forming the inverse
-  bool mx_explicit = FEAT;
-  if constexpr (FEAT) chol_inverse<KM>(LA, ila, Mx);
+  bool mx_explicit = FEAT != 0;
+  if constexpr (FEAT != 0) chol_inverse<KM>(LA, ila, Mx);
   const T thr = T(1e-3), rcond = T(1e-3) * T(0.1);
   if (!(okA && det >= thr)) {
     // pinv branch (osc.py:142-145).  pinv == inv unless some singular value is below
@@ -505,7 +505,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     }
   }
   // integral term (osc.py:262-264)
-  if (FEAT && have_ierr) {
+  if (FEAT >= 2 && have_ierr) {
     sfor<6>([&](auto r) ABRK_LAMBDA {
       ierr[r()] += ut[r()];
       ut[r()] += P.ki * ierr[r()];
@@ -531,7 +531,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   }
   // velocity compensation (osc.py:274-282)
   bool tv_zero = true;
-  if (FEAT && tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
+  if (FEAT >= 2 && tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
   T Mdq[N];
   symv<N>(Ms, dq, Mdq);
   if (tv_zero) {
@@ -567,13 +567,13 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
 
   // secondary controllers through the null-space filter I - J^T Jbar^T (osc.py:310-318).
   // With u_null = M v the filtered signal is M v - J^T Mx (J v) (Jbar^T M = Mx J).
-  if (FEAT && (P.n_null > 0 || have_ext)) {
+  if (FEAT >= 1 && (P.n_null > 0 || (FEAT >= 2 && have_ext))) {
     T v[N];
     sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = T(0); });
     for (int c = 0; c < P.n_null; c++) null_command<N>(P.nul[c], q, dq, v);
     T un[N];
     symv<N>(Ms, v, un);
-    if (have_ext) {
+    if (FEAT >= 2 && have_ext) {
       // caller-evaluated u_null: v_ext = M^-1 u_ext
       T y[N], w[N];
       chol_fwd<N>(L, il, une, y);
@@ -600,9 +600,10 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
 
 // `late()` loads the inputs that are not needed by the kinematics (target, velocities, state; dq
 // too unless the Coriolis term is on) - it is invoked after the register-pressure peak.
-// FEAT = false compiles out the optional inputs (target velocity, integral state, secondary
-// controllers): the plain law needs ~70 registers fewer and fits two waves per SIMD.
-template <class A, class T, int KM, bool USE_C, bool FEAT, class Late>
+// FEAT selects which optional inputs are compiled in: 0 = none (the plain law: ~70 registers fewer,
+// two waves per SIMD), 1 = fused secondary controllers only (Damping / RestingConfig, BASELINE config 3),
+// 2 = everything (target velocity, integral state, caller-evaluated null signal).
+template <class A, class T, int KM, bool USE_C, int FEAT, class Late>
 ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
                       bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
                       const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late) {

@@ -22,7 +22,8 @@ constexpr int kBlock = ABRK_BLOCK;  // rows are independent, no LDS sharing: one
 // row stride -> conflict-free ds_write), then the 64 lanes stream the slab out in linear order,
 // 512 contiguous bytes per store instruction.  The row-per-lane alternative writes 64 separate
 // 8-byte pieces per instruction and is what makes the full-output mode HBM-inefficient.
-constexpr int kMaxRow = 6 * 7;  // widest output row (J / dJ of a 7-joint arm = ABRK_MAX_JOINTS)
+// widest output row of an N-joint arm: J/dJ (6N), M/C (N*N), T (16)
+constexpr int max_row(int n) { return (6 * n > n * n ? 6 * n : n * n) > 16 ? (6 * n > n * n ? 6 * n : n * n) : 16; }
 template <class T>
 struct LdsStore {
   T* buf;
@@ -51,15 +52,23 @@ template <class A, class T, bool WITH_DQ>
 __global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, const T* __restrict__ qg,
            const T* __restrict__ dqg, DynOutP<T> out) {
-  __shared__ T slab[kBlock * (kMaxRow | 1)];
+  __shared__ T slab[kBlock * (max_row(A::N) | 1)];
   const long row0 = (long)blockIdx.x * kBlock;
   const long b = row0 + threadIdx.x;
   LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
   dyn_body<A, T, WITH_DQ>(b, b < B, st, arm, frame, m, ox, oy, oz, want, B, qg, dqg, out);
 }
 
-template <class A, class T, int KM, bool USE_C, bool FEAT>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+// Register budget: the law without Coriolis vector and without the rarely used optional inputs is
+// (xyz kernel) asked to fit two waves per SIMD (<= 256 VGPRs; measured +6 % on Jaco2 whose general-chain state would
+// otherwise take 256 + 18 parked registers); the heavier variants keep the full budget - forcing them
+// under 256 spills hundreds of bytes per lane and loses 2-3x (measured).
+constexpr int osc_min_waves(int km, bool use_c, int feat) {
+  return (km == 3 && !use_c && feat <= 1) ? 2 : ABRK_MIN_WAVES;
+}
+
+template <class A, class T, int KM, bool USE_C, int FEAT>
+__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
@@ -186,7 +195,7 @@ struct Launch {
                          T(a.off[0]), T(a.off[1]), T(a.off[2]), a.want, la.B, (const T*)a.q, (const T*)a.dq, o);
     return hipGetLastError();
   }
-  template <int KM, bool UC, bool FEAT>
+  template <int KM, bool UC, int FEAT>
   static void osc_launch(const LaunchArgs& la, const OscArgs& a) {
     hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
                        *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
@@ -194,10 +203,12 @@ struct Launch {
   }
   template <int KM, bool UC>
   static void osc_launch_feat(const LaunchArgs& la, const OscArgs& a) {
-    // optional inputs present?  (target velocity, integral state, fused / external null signals)
-    const bool feat = a.tv || a.ierr || a.une || static_cast<const OscP<T>*>(a.P)->n_null > 0;
-    if (feat) osc_launch<KM, UC, true>(la, a);
-    else osc_launch<KM, UC, false>(la, a);
+    // which optional inputs are present?  0: none, 1: fused null controllers only, 2: anything else
+    const bool other = a.tv || a.ierr || a.une;
+    const bool nulls = static_cast<const OscP<T>*>(a.P)->n_null > 0;
+    if (other) osc_launch<KM, UC, 2>(la, a);
+    else if (nulls) osc_launch<KM, UC, 1>(la, a);
+    else osc_launch<KM, UC, 0>(la, a);
   }
   static hipError_t osc(const LaunchArgs& la, const OscArgs& a) {
     if (a.fast) {

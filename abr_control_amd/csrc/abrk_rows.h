@@ -137,19 +137,19 @@ ABRK_INL void dyn_body(long b, bool active, St& st, const A& arm, int frame, int
 }
 
 // ---- OSC.generate for B states (osc.py:217-320)
-template <class A, class T, int KM, bool USE_C, bool FEAT>
+template <class A, class T, int KM, bool USE_C, int FEAT>
 ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
   constexpr int N = A::N;
   T q[N], dq[N], tgt[6], tv[6], ierr[6], une[N], u[N], ts[N];
-  const bool tv_given = FEAT && tvg != nullptr, have_ierr = FEAT && ierrg != nullptr,
-             have_ext = FEAT && uneg != nullptr;
+  const bool tv_given = FEAT >= 2 && tvg != nullptr, have_ierr = FEAT >= 2 && ierrg != nullptr,
+             have_ext = FEAT >= 2 && uneg != nullptr;
   load_row<N>(qg, b, q);
   // FEAT=false: every input is requested up front (one HBM round trip; 36 extra registers still
   // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
   // kinematics to keep that kernel's register peak down.
-  constexpr bool EARLY = !FEAT;
+  constexpr bool EARLY = FEAT < 2;
   if constexpr (USE_C || EARLY) load_row<N>(dqg, b, dq);
   if constexpr (EARLY) load_row<6>(tg, b, tgt);
   auto late = [&]() ABRK_LAMBDA {
@@ -204,7 +204,7 @@ ABRK_INL void osc_law_body(long b, const OscP<T>& P, long B, const T* __restrict
   opt(tvg, tv, ic<6>{}, T(0));
   opt(ierrg, ierr, ic<6>{}, T(0));
   opt(uneg, une, ic<N>{}, T(0));
-  osc_law<N, T, 6, true, true>(P, Ms, gv, T(-1), cv, Jv, Jw, p, RF, q, dq, tgt, tvg != nullptr, tv, ierrg != nullptr,
+  osc_law<N, T, 6, true, 2>(P, Ms, gv, T(-1), cv, Jv, Jw, p, RF, q, dq, tgt, tvg != nullptr, tv, ierrg != nullptr,
                                ierr, uneg != nullptr, une, u, ts);
   store_row<N>(ug, b, u);
   if (tsg) store_row<N>(tsg, b, ts);
@@ -268,7 +268,7 @@ ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLink
   const int n_chk = every > 0 ? n_steps / every : 0;
   int chk = 0, until = every;
   for (int t = 0; t < n_steps; t++) {
-    osc_row<A, T, 6, USE_C, true>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {});
+    osc_row<A, T, 6, USE_C, 2>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {});
     twolink_step(K, q, dq, u);
     if (every > 0 && --until == 0) {
       until = every;

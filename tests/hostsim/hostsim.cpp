@@ -39,16 +39,16 @@ int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void
   OscP<T> p = make_oscp<T>(*P, n);
   bool fast = osc_is_fast(*P, n, une != nullptr);
   if (P->ki == 0) ie = nullptr;
-  const bool feat = tv || ie || une || p.n_null > 0;  // same dispatch rule as Launch::osc_launch_feat
+  const int feat = (tv || ie || une) ? 2 : (p.n_null > 0 ? 1 : 0);  // same dispatch rule as Launch::osc_launch_feat
   for (long b = 0; b < B; b++) {
-#define CALL(KM, UC)                                                                                          \
-  do {                                                                                                        \
-    if (feat)                                                                                                 \
-      osc_body<A, T, KM, UC, true>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, \
-                                   (T*)ie, (const T*)une, (T*)u, (T*)ts);                                     \
-    else                                                                                                      \
-      osc_body<A, T, KM, UC, false>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg,              \
-                                    (const T*)tv, (T*)ie, (const T*)une, (T*)u, (T*)ts);                      \
+#define CALL1(KM, UC, FT)                                                                                  \
+  osc_body<A, T, KM, UC, FT>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, (T*)ie, \
+                             (const T*)une, (T*)u, (T*)ts)
+#define CALL(KM, UC)                      \
+  do {                                    \
+    if (feat == 2) CALL1(KM, UC, 2);      \
+    else if (feat == 1) CALL1(KM, UC, 1); \
+    else CALL1(KM, UC, 0);                \
   } while (0)
     if (fast) {
       if (P->use_C) CALL(3, true); else CALL(3, false);
@@ -56,6 +56,7 @@ int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void
       if (P->use_C) CALL(6, true); else CALL(6, false);
     }
 #undef CALL
+#undef CALL1
   }
   return 0;
 }
