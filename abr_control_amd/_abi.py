@@ -87,6 +87,20 @@ class SlidingParams(C.Structure):
     ]
 
 
+class IkParams(C.Structure):
+    _fields_ = [("max_dx", C.c_double), ("max_dr", C.c_double), ("max_dq", C.c_double), ("dt", C.c_double),
+                ("n_timesteps", C.c_int32), ("method", C.c_int32)]
+
+
+def make_ik_params(max_dx=0.2, max_dr=2 * np.pi, max_dq=np.pi, n_timesteps=200, dt=0.001, method=3):
+    """InverseKinematics(max_dx, max_dr, max_dq).generate_path(n_timesteps, dt, method) defaults
+    (controllers/path_planners/inverse_kinematics.py:21-37)."""
+    p = IkParams()
+    p.max_dx, p.max_dr, p.max_dq, p.dt = max_dx, max_dr, max_dq, dt
+    p.n_timesteps, p.method = int(n_timesteps), int(method)
+    return p
+
+
 class TwoLinkPlant(C.Structure):
     _fields_ = [("K1", C.c_double), ("K2", C.c_double), ("K3", C.c_double), ("K4", C.c_double), ("dt", C.c_double)]
 

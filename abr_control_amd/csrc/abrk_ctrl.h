@@ -44,6 +44,12 @@ struct TwoLinkP {  // ArmSim constants (arms/twojoint/arm_sim.py:33-41)
 };
 
 template <class T>
+struct IkP {  // InverseKinematics (inverse_kinematics.py:21-26, 65-71): step limits already scaled by dt
+  T max_dx, max_dr, max_dq;
+  int n_steps, method;
+};
+
+template <class T>
 struct JointP {
   NullP<T> c;  // kind 0: Joint; 1: Damping; 2: RestingConfig
   int account_for_gravity;
@@ -183,18 +189,20 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
   sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = S[tri(i(), i())]; });
 }
 
-// One-sided (Hestenes) Jacobi: orthogonalise the 3 columns G[:,0..2] (length N each),
-// accumulating the rotations in V (3x3).  Afterwards G = U diag(sig), so for J = G^T:
-//   pinv(J)[i][r] = sum_{sig_j > cutoff} G[i][j] V[r][j] / sig_j^2        (sliding.py:72)
-template <int N, class T>
-ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P)[N][3] /* P[i][r] */) {
-  T G[N][3];
-  T V[3][3];
-  sfor<N>([&](auto i) ABRK_LAMBDA { sfor<3>([&](auto r) ABRK_LAMBDA { G[i()][r()] = J[i()][r()]; }); });
-  sfor<3>([&](auto a) ABRK_LAMBDA { sfor<3>([&](auto b) ABRK_LAMBDA { V[a()][b()] = (a() == b()) ? T(1) : T(0); }); });
-  for (int sweep = 0; sweep < 30; sweep++) {
+// One-sided (Hestenes) Jacobi SVD: orthogonalise the K columns G[:,0..K-1] (length N each, G = J^T),
+// accumulating the rotations in V (K x K).  Afterwards G = U diag(sig), so for J = G^T (K x N):
+//   pinv(J)[i][r] = sum_{sig_j > rcond * sig_max} G[i][j] V[r][j] / sig_j^2
+// (numpy.linalg.pinv, default rcond 1e-15: sliding.py:72, inverse_kinematics.py:104-121).  Small singular
+// values keep their relative accuracy, which an eigen-decomposition of J J^T would lose.
+template <int K, int N, class T>
+ABRK_INL void pinv_KxN(const T (&J)[N][K] /* J[i][r] = J(r,i) */, T rcond, T (&P)[N][K] /* P[i][r] */) {
+  T G[N][K];
+  T V[K][K];
+  sfor<N>([&](auto i) ABRK_LAMBDA { sfor<K>([&](auto r) ABRK_LAMBDA { G[i()][r()] = J[i()][r()]; }); });
+  sfor<K>([&](auto a) ABRK_LAMBDA { sfor<K>([&](auto b) ABRK_LAMBDA { V[a()][b()] = (a() == b()) ? T(1) : T(0); }); });
+  for (int sweep = 0; sweep < 40; sweep++) {
     T worst = T(0);
-    sfor<3>([&](auto qq) ABRK_LAMBDA {
+    sfor<K>([&](auto qq) ABRK_LAMBDA {
       sfor<qq()>([&](auto pp) ABRK_LAMBDA {
         constexpr int p = pp(), q = qq();
         T alpha = T(-0.0), beta = T(-0.0), gamma = T(-0.0);
@@ -215,7 +223,7 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P
             G[i()][p] = c * gp - s * gq;
             G[i()][q] = s * gp + c * gq;
           });
-          sfor<3>([&](auto a) ABRK_LAMBDA {
+          sfor<K>([&](auto a) ABRK_LAMBDA {
             T vp = V[a()][p], vq = V[a()][q];
             V[a()][p] = c * vp - s * vq;
             V[a()][q] = s * vp + c * vq;
@@ -225,23 +233,27 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3] /* J[i][r] = J(r,i) */, T rcond, T (&P
     });
     if (!(worst > T(0))) break;
   }
-  T sig2[3], smax2 = T(0);
-  sfor<3>([&](auto j) ABRK_LAMBDA {
+  T sig2[K], smax2 = T(0);
+  sfor<K>([&](auto j) ABRK_LAMBDA {
     T acc = T(-0.0);
     sfor<N>([&](auto i) ABRK_LAMBDA { acc += G[i()][j()] * G[i()][j()]; });
     sig2[j()] = acc;
     smax2 = Rm<T>::fmax(smax2, acc);
   });
-  T w[3];
+  T w[K];
   T cut = rcond * Rm<T>::sqrt(smax2);
-  sfor<3>([&](auto j) ABRK_LAMBDA { w[j()] = (Rm<T>::sqrt(sig2[j()]) > cut) ? rcp(sig2[j()]) : T(0); });
+  sfor<K>([&](auto j) ABRK_LAMBDA { w[j()] = (Rm<T>::sqrt(sig2[j()]) > cut) ? rcp(sig2[j()]) : T(0); });
   sfor<N>([&](auto i) ABRK_LAMBDA {
-    sfor<3>([&](auto r) ABRK_LAMBDA {
+    sfor<K>([&](auto r) ABRK_LAMBDA {
       T acc = T(-0.0);
-      sfor<3>([&](auto j) ABRK_LAMBDA { acc += G[i()][j()] * V[r()][j()] * w[j()]; });
+      sfor<K>([&](auto j) ABRK_LAMBDA { acc += G[i()][j()] * V[r()][j()] * w[j()]; });
       P[i()][r()] = acc;
     });
   });
+}
+template <int N, class T>
+ABRK_INL void pinv_3xN(const T (&J)[N][3], T rcond, T (&P)[N][3]) {
+  pinv_KxN<3, N, T>(J, rcond, P);
 }
 
 // ---------------------------------------------------------------- quaternions (utils/transformations.py)
@@ -315,6 +327,23 @@ ABRK_INL void quat_from_euler_rxyz(T ai, T aj, T ak, T (&q)[4]) {
   q[3] = cj * sc - sj * cs;
   q[2] = -(cj * ss + sj * cc);
   q[1] = cj * cs - sj * sc;
+  T inv = Rm<T>::rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  sfor<4>([&](auto i) ABRK_LAMBDA { q[i()] *= inv; });
+}
+
+// quaternion_from_euler(ai, aj, ak, 'sxyz') (transformations.py:1096-1150; axes tuple (0,0,0,0): i=1,j=2,k=3),
+// then unit_vector - the target orientation of inverse_kinematics.py:73-82
+template <class T>
+ABRK_INL void quat_from_euler_sxyz(T ai, T aj, T ak, T (&q)[4]) {
+  T si, ci, sj, cj, sk, ck;
+  Rm<T>::sincos(ai / T(2), si, ci);
+  Rm<T>::sincos(aj / T(2), sj, cj);
+  Rm<T>::sincos(ak / T(2), sk, ck);
+  T cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  q[0] = cj * cc + sj * ss;
+  q[1] = cj * sc - sj * cs;
+  q[2] = cj * ss + sj * cc;
+  q[3] = cj * cs - sj * sc;
   T inv = Rm<T>::rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   sfor<4>([&](auto i) ABRK_LAMBDA { q[i()] *= inv; });
 }
@@ -722,6 +751,95 @@ ABRK_INL void twolink_step(const TwoLinkP<T>& K, T (&q)[2], T (&dq)[2], const T 
   dq[1] += ddq1 * K.dt;
   q[0] += dq[0] * K.dt;
   q[1] += dq[1] * K.dt;
+}
+
+// ---------------------------------------------------------------- InverseKinematics.generate_path, one row
+// (controllers/path_planners/inverse_kinematics.py:84-135): n_steps sequential iterations, q in registers.
+template <class A, class T>
+ABRK_INL void ik_row(const A& arm, const IkP<T>& P, T (&q)[A::N], const T (&tgt)[6], T* __restrict__ ppath,
+                     T* __restrict__ vpath) {
+  constexpr int N = A::N;
+  T Qd[4];
+  quat_from_euler_sxyz(tgt[3], tgt[4], tgt[5], Qd);
+  for (int ii = 0; ii < P.n_steps; ii++) {
+    Joints<A, T> jt;
+    T XR[9], xo[3], RF[9], p[3];
+    NoCap nc;
+    fk_forward(arm, q, jt, XR, xo, nc, [](auto, const T(&)[3]) ABRK_LAMBDA {});
+    mulBE<A, T>(arm, XR, xo, RF, p);
+    T Jv[N][3], Jw[N][3];
+    jacobian(jt, p, N, Jv, Jw);
+    T dx[3], dr[3], Qe[4];
+    quat_from_R(RF, Qe);
+    sfor<3>([&](auto r) ABRK_LAMBDA { dx[r()] = tgt[r()] - p[r()]; });
+    {  // dr = Qe0 Qd[1:] - Qd0 Qe[1:] - Qd[1:] x Qe[1:]   (inverse_kinematics.py:92)
+      T a[3] = {Qd[1], Qd[2], Qd[3]}, b[3] = {Qe[1], Qe[2], Qe[3]}, c[3];
+      cross3(a, b, c);
+      sfor<3>([&](auto r) ABRK_LAMBDA { dr[r()] = Qe[0] * a[r()] - Qd[0] * b[r()] - c[r()]; });
+    }
+    T ndx = Rm<T>::sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+    T ndr = Rm<T>::sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+    if (ndx > P.max_dx) sfor<3>([&](auto r) ABRK_LAMBDA { dx[r()] = dx[r()] / ndx * P.max_dx; });
+    if (ndr > P.max_dr) sfor<3>([&](auto r) ABRK_LAMBDA { dr[r()] = dr[r()] / ndr * P.max_dr; });
+    T dq[N];
+    if (P.method == 3) {
+      // dq = pinv(Jx) dx + (I - pinv(Jx) Jx) pinv(Jw) dr   (inverse_kinematics.py:117-121)
+      T pJx[N][3], pJw[N][3], b[N], jb[3];
+      pinv_KxN<3, N, T>(Jv, T(1e-15), pJx);
+      pinv_KxN<3, N, T>(Jw, T(1e-15), pJw);
+      sfor<N>([&](auto i) ABRK_LAMBDA { b[i()] = pJw[i()][0] * dr[0] + pJw[i()][1] * dr[1] + pJw[i()][2] * dr[2]; });
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        T acc = T(-0.0);
+        sfor<N>([&](auto i) ABRK_LAMBDA { acc += Jv[i()][r()] * b[i()]; });
+        jb[r()] = acc;
+      });
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        dq[i()] = (pJx[i()][0] * dx[0] + pJx[i()][1] * dx[1] + pJx[i()][2] * dx[2]) +
+                  (b[i()] - (pJx[i()][0] * jb[0] + pJx[i()][1] * jb[1] + pJx[i()][2] * jb[2]));
+      });
+    } else {
+      T J6[N][6];
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        sfor<3>([&](auto r) ABRK_LAMBDA {
+          J6[i()][r()] = Jv[i()][r()];
+          J6[i()][3 + r()] = Jw[i()][r()];
+        });
+      });
+      if (P.method == 1) {  // dq = pinv(J) [dx, dr]   (inverse_kinematics.py:106-107)
+        T pJ[N][6];
+        pinv_KxN<6, N, T>(J6, T(1e-15), pJ);
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          dq[i()] = pJ[i()][0] * dx[0] + pJ[i()][1] * dx[1] + pJ[i()][2] * dx[2] + pJ[i()][3] * dr[0] +
+                    pJ[i()][4] * dr[1] + pJ[i()][5] * dr[2];
+        });
+      } else {  // dq = J^T solve(J J^T + 0.001 I, [dx, 0.3 dr])   (inverse_kinematics.py:108-115)
+        T Am[21], L[21], il[6], rhs[6] = {dx[0], dx[1], dx[2], dr[0] * T(0.3), dr[1] * T(0.3), dr[2] * T(0.3)}, y[6], x[6];
+        sfor<6>([&](auto r) ABRK_LAMBDA {
+          sfor<r() + 1>([&](auto c) ABRK_LAMBDA {
+            T acc = (r() == c()) ? T(0.001) : T(-0.0);
+            sfor<N>([&](auto i) ABRK_LAMBDA { acc += J6[i()][r()] * J6[i()][c()]; });
+            Am[tri(r(), c())] = acc;
+          });
+        });
+        chol<6>(Am, L, il);
+        chol_fwd<6>(L, il, rhs, y);
+        chol_bwd<6>(L, il, y, x);
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          T acc = T(-0.0);
+          sfor<6>([&](auto r) ABRK_LAMBDA { acc += J6[i()][r()] * x[r()]; });
+          dq[i()] = acc;
+        });
+      }
+    }
+    T m = T(0);
+    sfor<N>([&](auto i) ABRK_LAMBDA { m = Rm<T>::fmax(m, Rm<T>::fabs(dq[i()])); });
+    if (m > P.max_dq) sfor<N>([&](auto i) ABRK_LAMBDA { dq[i()] = dq[i()] / m * P.max_dq; });
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      ppath[ii * N + i()] = q[i()];
+      vpath[ii * N + i()] = dq[i()];
+      q[i()] += dq[i()];
+    });
+  }
 }
 
 // ---------------------------------------------------------------- Joint / Damping / RestingConfig, one row

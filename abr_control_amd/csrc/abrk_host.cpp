@@ -833,3 +833,40 @@ extern "C" int abrk_plan_destroy(int plan) {
   g_plans[plan]->live = false;
   return 0;
 }
+
+// ------------------------------------------------------------------------------- inverse kinematics
+extern "C" int abrk_ik_generate_path_batch(int arm_id, int dtype, const abrk_ik_params* P, int64_t B,
+                                           const void* position, const void* target, void* position_path,
+                                           void* velocity_path, int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (P->method < 1 || P->method > 3) return fail(ABRK_EINVAL, "method %d outside 1..3", P->method);
+  if (P->n_timesteps < 0) return fail(ABRK_EINVAL, "negative n_timesteps");
+  if (!position || !target || !position_path || !velocity_path)
+    return fail(ABRK_EINVAL, "position, target, position_path and velocity_path are required");
+  if (B == 0 || P->n_timesteps == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  const size_t T = (size_t)P->n_timesteps;
+  Stager st{device, (hipStream_t)stream};
+  const void* q_ = st.add(position, B * n * s, true, false);
+  const void* t_ = st.add(target, B * 6 * s, true, false);
+  void* pp_ = st.add(position_path, B * T * n * s, false, true);
+  void* vp_ = st.add(velocity_path, B * T * n * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  IkArgs ia;
+  ia.q = st.fix(q_, position);
+  ia.target = st.fix(t_, target);
+  ia.pp = st.fix(pp_, position_path);
+  ia.vp = st.fix(vp_, velocity_path);
+  IkP<double> p64{P->max_dx * P->dt, P->max_dr * P->dt, P->max_dq * P->dt, P->n_timesteps, P->method};
+  IkP<float> p32{(float)(P->max_dx * P->dt), (float)(P->max_dr * P->dt), (float)(P->max_dq * P->dt), P->n_timesteps,
+                 P->method};
+  ia.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->ik(dtype, la, ia));
+  return st.finish();
+}

@@ -127,6 +127,20 @@ twolink_step_kernel(TwoLinkP<T> K, long B, T* __restrict__ qg, T* __restrict__ d
   twolink_step_body<T>(b, K, qg, dqg, ug);
 }
 
+template <class A, class T>
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+ik_kernel(A arm, IkP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ tg, T* __restrict__ pp,
+          T* __restrict__ vp) {
+  ABRK_ROW_INDEX
+  ik_body<A, T>(b, arm, P, B, qg, tg, pp, vp);
+}
+
+struct IkArgs {
+  const void* P;  // IkP<T>
+  const void *q, *target;
+  void *pp, *vp;
+};
+
 struct RolloutArgs {
   const void *P, *K;  // OscP<T>, TwoLinkP<T>
   int use_C, n_steps, every;
@@ -172,6 +186,7 @@ struct ArmOps {
   hipError_t (*sliding)(int dtype, const LaunchArgs&, const SlidingArgs&);
   hipError_t (*joint)(int dtype, const LaunchArgs&, const JointArgs&);
   hipError_t (*rollout)(int dtype, const LaunchArgs&, const RolloutArgs&);  // two-joint arms only, else null
+  hipError_t (*ik)(int dtype, const LaunchArgs&, const IkArgs&);
 };
 hipError_t launch_twolink_step(int dtype, const LaunchArgs& la, const void* K, void* q, void* dq, const void* u);
 
@@ -269,8 +284,17 @@ struct OpsFor {
   static hipError_t rollout(int dt, const LaunchArgs& la, const RolloutArgs& a) {
     return dt == 0 ? rollout_t<AD, double>(la, a) : rollout_t<AF, float>(la, a);
   }
+  template <class A, class T>
+  static hipError_t ik_t(const LaunchArgs& la, const IkArgs& a) {
+    hipLaunchKernelGGL((ik_kernel<A, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la),
+                       *static_cast<const IkP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.target, (T*)a.pp, (T*)a.vp);
+    return hipGetLastError();
+  }
+  static hipError_t ik(int dt, const LaunchArgs& la, const IkArgs& a) {
+    return dt == 0 ? ik_t<AD, double>(la, a) : ik_t<AF, float>(la, a);
+  }
   static const ArmOps* ops() {
-    static const ArmOps o = {AD::N, &dyn, &osc, &sliding, &joint, AD::N == 2 ? &rollout : nullptr};
+    static const ArmOps o = {AD::N, &dyn, &osc, &sliding, &joint, AD::N == 2 ? &rollout : nullptr, &ik};
     return &o;
   }
 };

@@ -286,6 +286,17 @@ ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLink
   if (have_ierr) store_row<6>(ierrg, b, ierr);
 }
 
+// ---- InverseKinematics.generate_path for B independent paths (inverse_kinematics.py:28-135)
+template <class A, class T>
+ABRK_INL void ik_body(long b, const A& arm, const IkP<T>& P, long B, const T* __restrict__ qg,
+                      const T* __restrict__ tg, T* __restrict__ pp, T* __restrict__ vp) {
+  constexpr int N = A::N;
+  T q[N], tgt[6];
+  load_row<N>(qg, b, q);
+  load_row<6>(tg, b, tgt);
+  ik_row<A, T>(arm, P, q, tgt, pp + b * (long)P.n_steps * N, vp + b * (long)P.n_steps * N);
+}
+
 template <class T>
 ABRK_INL void twolink_step_body(long b, const TwoLinkP<T>& K, T* __restrict__ qg, T* __restrict__ dqg,
                                 const T* __restrict__ ug) {

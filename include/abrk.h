@@ -253,6 +253,25 @@ int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_osc_params*
                                    void* q, void* dq, const void* target, void* integrated_error,
                                    void* q_traj, void* dq_traj, void* u_traj, int device, void* stream);
 
+/* ---------------------------------------------------------------------------------
+ * Iterative inverse kinematics: InverseKinematics.generate_path
+ * (abr_control/controllers/path_planners/inverse_kinematics.py:28-135) for B independent paths, all
+ * n_timesteps iterations of a path inside one kernel (each iteration: Tx, J, quaternion of the EE, two
+ * pseudo-inverses).  max_dx / max_dr / max_dq are the constructor values (per second); they are scaled by
+ * dt exactly as generate_path does.  method 1: resolved motion, 2: damped least squares, 3: position with
+ * orientation in its null space (the reference default).  target [B,6] = xyz + Euler angles 'sxyz'.
+ * position [B,n] start joint angles; position_path, velocity_path [B, n_timesteps, n] out.
+ * --------------------------------------------------------------------------------- */
+typedef struct abrk_ik_params {
+  double max_dx, max_dr, max_dq, dt;
+  int32_t n_timesteps;
+  int32_t method;
+} abrk_ik_params;
+
+int abrk_ik_generate_path_batch(int arm_id, int dtype, const abrk_ik_params* params, int64_t B,
+                                const void* position, const void* target, void* position_path,
+                                void* velocity_path, int device, void* stream);
+
 /* Joint.generate (controllers/joint.py:104-131) / Damping / RestingConfig standalone.
  *   ctrl.kind == ABRK_NULL_DAMPING: u = M (-kv dq)            (damping.py:31-32)
  *   ctrl.kind == ABRK_NULL_RESTING: RestingConfig.generate     (resting_config.py:33-42)

@@ -287,6 +287,31 @@ def gen_arm(arm):
         run_simple("damping", 128, 33, lambda c: Damping(c, kv=10), 6,
                    lambda c, q, dq, t: c.generate(q, dq))
 
+    if arm in ("ur5", "jaco2"):
+        # iterative inverse kinematics (controllers/path_planners/inverse_kinematics.py:28-135)
+        from abr_control.controllers.path_planners.inverse_kinematics import InverseKinematics
+        from abr_control.utils import transformations as tf
+
+        rng = np.random.RandomState(50)
+        Bi, T = 6, 200
+        q0 = rng.uniform(0.3, 2.8, (Bi, n))
+        qg = q0 + rng.uniform(-0.8, 0.8, (Bi, n))  # reachable goals: pose of a nearby configuration
+        tgt = np.zeros((Bi, 6))
+        for b in range(Bi):
+            tgt[b, :3] = rc.Tx("EE", qg[b])
+            tgt[b, 3:] = tf.euler_from_quaternion(raw.quaternion("EE", qg[b]), axes="sxyz")
+        out["ik_q0"], out["ik_target"] = q0, tgt
+        for method in (1, 2, 3):
+            for label, cfg in (("S", rc), ("D", raw)):
+                pp = np.zeros((Bi, T, n))
+                vp = np.zeros((Bi, T, n))
+                for b in range(Bi):
+                    ik = InverseKinematics(cfg)
+                    pp[b], vp[b] = ik.generate_path(q0[b], tgt[b], n_timesteps=T, dt=0.001, method=method)
+                out[f"ik_m{method}_pos{label}"], out[f"ik_m{method}_vel{label}"] = pp, vp
+            d = np.max(np.abs(out[f"ik_m{method}_posS"] - out[f"ik_m{method}_posD"]))
+            print(f"  ik method {method}: max |q_S - q_D| over {T} steps = {d:.2e}", flush=True)
+
     np.savez_compressed(f"{OUT}/{arm}.npz", **out)
     print(f"  wrote {OUT}/{arm}.npz ({len(out)} arrays)", flush=True)
 

@@ -867,3 +867,92 @@ int abrk_oracle_rollout_twolink(const abrk_arm_desc* a, const abrk_osc_params* P
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------ InverseKinematics.generate_path
+ * controllers/path_planners/inverse_kinematics.py:28-135 */
+void abrk_oracle_quat_from_euler_sxyz(double ai, double aj, double ak, double q[4]) {
+  /* transformations.py:1096-1150 with axes 'sxyz' = (0,0,0,0): i=1, j=2, k=3, no swap, no negation */
+  ai /= 2.0; aj /= 2.0; ak /= 2.0;
+  double ci = cos(ai), si = sin(ai), cj = cos(aj), sj = sin(aj), ck = cos(ak), sk = sin(ak);
+  double cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
+  q[0] = cj * cc + sj * ss;
+  q[1] = cj * sc - sj * cs;
+  q[2] = cj * ss + sj * cc;
+  q[3] = cj * cs - sj * sc;
+}
+
+int abrk_oracle_ik_generate_path(const abrk_arm_desc* a, const abrk_ik_params* P, const double* position,
+                                 const double* target, double* position_path, double* velocity_path) {
+  int n = a->n_joints, EE = 2 * n + 1;
+  double max_dq = P->max_dq * P->dt, max_dx = P->max_dx * P->dt, max_dr = P->max_dr * P->dt;
+  double Qd[4], q[NJ];
+  abrk_oracle_quat_from_euler_sxyz(target[3], target[4], target[5], Qd);
+  tf_unit(Qd, 4);
+  for (int i = 0; i < n; i++) q[i] = position[i];
+  for (int ii = 0; ii < P->n_timesteps; ii++) {
+    double J[6 * NJ], Tx[3], Qe[4], dx[3], dr[3], dq[NJ];
+    abrk_oracle_J(a, EE, q, NULL, J);
+    abrk_oracle_Tx(a, EE, q, NULL, Tx);
+    for (int r = 0; r < 3; r++) dx[r] = target[r] - Tx[r];
+    abrk_oracle_quaternion(a, EE, q, Qe);
+    dr[0] = Qe[0] * Qd[1] - Qd[0] * Qe[1] - (Qd[2] * Qe[3] - Qd[3] * Qe[2]);
+    dr[1] = Qe[0] * Qd[2] - Qd[0] * Qe[2] - (Qd[3] * Qe[1] - Qd[1] * Qe[3]);
+    dr[2] = Qe[0] * Qd[3] - Qd[0] * Qe[3] - (Qd[1] * Qe[2] - Qd[2] * Qe[1]);
+    double ndx = sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
+    double ndr = sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
+    if (ndx > max_dx) for (int r = 0; r < 3; r++) dx[r] = dx[r] / ndx * max_dx;
+    if (ndr > max_dr) for (int r = 0; r < 3; r++) dr[r] = dr[r] / ndr * max_dr;
+    if (P->method == 1) {
+      double pJ[NJ * 6];
+      la_pinv(J, 6, n, 1e-15, pJ);
+      for (int i = 0; i < n; i++) {
+        double s = 0;
+        for (int r = 0; r < 3; r++) s += pJ[i * 6 + r] * dx[r] + pJ[i * 6 + 3 + r] * dr[r];
+        dq[i] = s;
+      }
+    } else if (P->method == 2) {
+      double A[36], Ai[36], b[6] = {dx[0], dx[1], dx[2], dr[0] * 0.3, dr[1] * 0.3, dr[2] * 0.3}, x[6];
+      for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) {
+          double s = (r == c) ? 0.001 : 0.0;
+          for (int i = 0; i < n; i++) s += J[r * n + i] * J[c * n + i];
+          A[r * 6 + c] = s;
+        }
+      la_inv(A, 6, Ai);
+      for (int r = 0; r < 6; r++) {
+        double s = 0;
+        for (int c = 0; c < 6; c++) s += Ai[r * 6 + c] * b[c];
+        x[r] = s;
+      }
+      for (int i = 0; i < n; i++) {
+        double s = 0;
+        for (int r = 0; r < 6; r++) s += J[r * n + i] * x[r];
+        dq[i] = s;
+      }
+    } else {
+      double pJx[NJ * 3], pJw[NJ * 3], b[NJ], jb[3];
+      la_pinv(J, 3, n, 1e-15, pJx);
+      la_pinv(J + 3 * n, 3, n, 1e-15, pJw);
+      for (int i = 0; i < n; i++) b[i] = pJw[i * 3] * dr[0] + pJw[i * 3 + 1] * dr[1] + pJw[i * 3 + 2] * dr[2];
+      for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += J[r * n + i] * b[i];
+        jb[r] = s;
+      }
+      for (int i = 0; i < n; i++) {
+        double a1 = pJx[i * 3] * dx[0] + pJx[i * 3 + 1] * dx[1] + pJx[i * 3 + 2] * dx[2];
+        double a2 = pJx[i * 3] * jb[0] + pJx[i * 3 + 1] * jb[1] + pJx[i * 3 + 2] * jb[2];
+        dq[i] = a1 + (b[i] - a2);
+      }
+    }
+    double m = 0;
+    for (int i = 0; i < n; i++) m = fmax(m, fabs(dq[i]));
+    if (m > max_dq) for (int i = 0; i < n; i++) dq[i] = dq[i] / m * max_dq;
+    for (int i = 0; i < n; i++) {
+      position_path[ii * n + i] = q[i];
+      velocity_path[ii * n + i] = dq[i];
+      q[i] += dq[i];
+    }
+  }
+  return 0;
+}

@@ -158,6 +158,18 @@ def rollout_twolink(table, params, plant, q0, dq0, target, n_steps, every):
     return q, dq, qt, dqt, ut
 
 
+def ik_paths(table, params, position, target):
+    """InverseKinematics.generate_path on the oracle, one path per row"""
+    o = Oracle(table)
+    position, target = _c(position), _c(target)
+    B, T = position.shape[0], int(params.n_timesteps)
+    pp, vp = np.zeros((B, T, o.n)), np.zeros((B, T, o.n))
+    for b in range(B):
+        rc = o.L.abrk_oracle_ik_generate_path(o._d, C.byref(params), _p(position[b]), _p(target[b]), _p(pp[b]), _p(vp[b]))
+        assert rc == 0
+    return pp, vp
+
+
 def quat_from_matrix(R):
     out = np.zeros(4)
     lib().abrk_oracle_quat_from_matrix(_p(_c(R)), _p(out))

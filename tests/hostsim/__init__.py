@@ -10,26 +10,57 @@ from abr_control_amd import _abi
 from abr_control_amd.engine import _OUT_SHAPES, _WANT_BITS, _dtype_code
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libabrk_hostsim.so")
-_lib = None
+_CSRC = os.path.join(_HERE, "..", "..", "abr_control_amd", "csrc")
+# built in parts, in parallel (a single translation unit takes minutes)
+PARTS = {
+    "static": ["-DHOSTSIM_STATIC=1"],
+    "rt13": ["-DHOSTSIM_RT_LO=1", "-DHOSTSIM_RT_HI=3"],
+    "rt45": ["-DHOSTSIM_RT_LO=4", "-DHOSTSIM_RT_HI=5"],
+    "rt6": ["-DHOSTSIM_RT_LO=6", "-DHOSTSIM_RT_HI=6"],
+    "rt7": ["-DHOSTSIM_RT_LO=7", "-DHOSTSIM_RT_HI=7"],
+    "law": ["-DHOSTSIM_LAW=1"],
+}
+_libs = {}
+
+
+def _so(part):
+    return os.path.join(_HERE, f"libabrk_hostsim_{part}.so")
 
 
 def build(force=False):
     srcs = [os.path.join(_HERE, "hostsim.cpp")] + [
-        os.path.join(_HERE, "..", "..", "abr_control_amd", "csrc", f)
+        os.path.join(_CSRC, f)
         for f in ("abrk_device.h", "abrk_ctrl.h", "abrk_rows.h", "abrk_params.h", "abrk_rt.h", "abrk_arms_builtin.h")]
-    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
-        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared", "-fno-signed-zeros", "-ffinite-math-only",
-                        "--cuda-host-only", "-o", _SO, srcs[0]], check=True)
-    return _SO
+    newest = max(os.path.getmtime(s) for s in srcs)
+    procs = []
+    for part, defs in PARTS.items():
+        so = _so(part)
+        if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
+            procs.append(subprocess.Popen(
+                ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-fPIC", "-shared",
+                 "-fno-signed-zeros", "-ffinite-math-only", "--cuda-host-only", *defs, "-o", so, srcs[0]],
+                stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+    for p in procs:
+        err = p.communicate()[1]
+        if p.returncode:
+            raise RuntimeError("hostsim build failed:\n" + err.decode()[-3000:])
+    return [_so(p) for p in PARTS]
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
-    return _lib
+def _lib_for(arm=None, law=False):
+    """the part holding the row programs of this arm"""
+    if law:
+        part = "law"
+    elif isinstance(arm, str):
+        part = "static"
+    else:
+        n = arm["n_joints"]
+        part = "rt13" if n <= 3 else "rt45" if n <= 5 else "rt6" if n == 6 else "rt7"
+    if part not in _libs:
+        if not os.path.exists(_so(part)):
+            build()
+        _libs[part] = C.CDLL(_so(part))
+    return _libs[part]
 
 
 def _arm(arm):
@@ -61,7 +92,7 @@ def dynamics(arm, q, dq=None, frame=None, x_off=None, want=("M",), dtype=np.floa
         res[w] = np.full((B,) + _OUT_SHAPES[w](n), np.nan, dt)
         setattr(do, w, res[w].ctypes.data)
     xo = None if x_off is None else (C.c_double * 3)(*[float(v) for v in x_off])
-    rc = lib().hostsim_dynamics(name, desc, _dtype_code(dt), C.c_int64(B), _p(q), _p(dq), frame, xo,
+    rc = _lib_for(arm).hostsim_dynamics(name, desc, _dtype_code(dt), C.c_int64(B), _p(q), _p(dq), frame, xo,
                                 C.c_uint32(bits), C.byref(do))
     assert rc == 0, rc
     return res
@@ -78,7 +109,7 @@ def osc_generate(arm, params, q, dq, target, target_velocity=None, integrated_er
     ts = np.full((B, n), np.nan, dt) if training_signal else None
     if integrated_error is not None:
         assert integrated_error.dtype == dt and integrated_error.flags.c_contiguous
-    rc = lib().hostsim_osc(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
+    rc = _lib_for(arm).hostsim_osc(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
                            _p(tv), _p(integrated_error), _p(une), _p(u), _p(ts))
     assert rc == 0, rc
     return (u, ts) if training_signal else u
@@ -93,7 +124,7 @@ def sliding_generate(arm, params, q, dq, target, target_velocity=None, target_ac
     B = q.shape[0]
     u = np.full((B, n), np.nan, dt)
     s = np.full((B, n), np.nan, dt)
-    rc = lib().hostsim_sliding(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
+    rc = _lib_for(arm).hostsim_sliding(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
                                _p(tv), _p(ta), _p(u), _p(s))
     assert rc == 0, rc
     return (u, s) if want_s else u
@@ -105,7 +136,7 @@ def joint_generate(arm, ctrl, account_for_gravity, q, dq, target=None, target_ve
     q, dq, target, tv = _in(q, dt), _in(dq, dt), _in(target, dt), _in(target_velocity, dt)
     B = q.shape[0]
     u = np.full((B, n), np.nan, dt)
-    rc = lib().hostsim_joint(name, desc, _dtype_code(dt), C.byref(ctrl), int(bool(account_for_gravity)),
+    rc = _lib_for(arm).hostsim_joint(name, desc, _dtype_code(dt), C.byref(ctrl), int(bool(account_for_gravity)),
                              C.c_int64(B), _p(q), _p(dq), _p(target), _p(tv), _p(u))
     assert rc == 0, rc
     return u
@@ -120,7 +151,7 @@ def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=N
     B = J.shape[0]
     u = np.full((B, n), np.nan, dt)
     ts = np.full((B, n), np.nan, dt)
-    rc = lib().hostsim_osc_law(n, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(J), _p(M), _p(g), _p(Cdq), _p(xyz),
+    rc = _lib_for(law=True).hostsim_osc_law(n, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(J), _p(M), _p(g), _p(Cdq), _p(xyz),
                                _p(R), _p(q), _p(dq), _p(target), _p(tv), _p(integrated_error), _p(une), _p(u), _p(ts))
     assert rc == 0, rc
     return u, ts
@@ -133,7 +164,18 @@ def rollout_twolink(arm, params, plant, q0, dq0, target, n_steps, every, dtype=n
     B = q.shape[0]
     n_chk = n_steps // every
     qt, dqt, ut = (np.full((B, n_chk, 2), np.nan, dt) for _ in range(3))
-    rc = lib().hostsim_rollout(name, desc, _dtype_code(dt), C.byref(params), C.byref(plant), C.c_int64(B), n_steps, every,
+    rc = _lib_for(arm).hostsim_rollout(name, desc, _dtype_code(dt), C.byref(params), C.byref(plant), C.c_int64(B), n_steps, every,
                                _p(q), _p(dq), _p(target), _p(qt), _p(dqt), _p(ut))
     assert rc == 0, rc
     return q, dq, qt, dqt, ut
+
+
+def ik_generate_path(arm, params, position, target, dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    position, target = _in(position, dt), _in(target, dt)
+    B, T = position.shape[0], int(params.n_timesteps)
+    pp, vp = np.full((B, T, n), np.nan, dt), np.full((B, T, n), np.nan, dt)
+    rc = _lib_for(arm).hostsim_ik(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(position), _p(target), _p(pp), _p(vp))
+    assert rc == 0, rc
+    return pp, vp

@@ -15,6 +15,21 @@
 
 using namespace abrk;
 
+// The library is built in parts (parallel compilation, see tests/hostsim/__init__.py):
+//   HOSTSIM_STATIC=1            the five built-in arms
+//   HOSTSIM_RT_LO / HOSTSIM_RT_HI   runtime-table arms with LO..HI joints
+//   HOSTSIM_LAW=1               the law-only row program
+#ifndef HOSTSIM_STATIC
+#define HOSTSIM_STATIC 0
+#endif
+#ifndef HOSTSIM_RT_LO
+#define HOSTSIM_RT_LO 1
+#define HOSTSIM_RT_HI 0
+#endif
+#ifndef HOSTSIM_LAW
+#define HOSTSIM_LAW 0
+#endif
+
 namespace {
 template <class A, class T>
 int run_dyn(const A& arm, int n, int64_t B, const void* q, const void* dq, int frame, const double* off,
@@ -86,7 +101,9 @@ int with_arm(const char* name, const abrk_arm_desc* d, int dtype, F&& f) {
     StaticArm<Tab_##NM> a;                                                                  \
     return dtype == 0 ? f(a, double(0), Tab_##NM::N) : f(a, float(0), Tab_##NM::N);         \
   }
+#if HOSTSIM_STATIC
   STATIC_CASE(ur5) STATIC_CASE(jaco2) STATIC_CASE(twojoint) STATIC_CASE(threejoint) STATIC_CASE(onejoint)
+#endif
 #undef STATIC_CASE
   if (!d) return -4;
 #define RT_CASE(NN)                                                           \
@@ -101,7 +118,27 @@ int with_arm(const char* name, const abrk_arm_desc* d, int dtype, F&& f) {
       return f(a, float(0), NN);                                              \
     }                                                                         \
   }
-  RT_CASE(1) RT_CASE(2) RT_CASE(3) RT_CASE(4) RT_CASE(5) RT_CASE(6) RT_CASE(7)
+#if HOSTSIM_RT_LO <= 1 && 1 <= HOSTSIM_RT_HI
+  RT_CASE(1)
+#endif
+#if HOSTSIM_RT_LO <= 2 && 2 <= HOSTSIM_RT_HI
+  RT_CASE(2)
+#endif
+#if HOSTSIM_RT_LO <= 3 && 3 <= HOSTSIM_RT_HI
+  RT_CASE(3)
+#endif
+#if HOSTSIM_RT_LO <= 4 && 4 <= HOSTSIM_RT_HI
+  RT_CASE(4)
+#endif
+#if HOSTSIM_RT_LO <= 5 && 5 <= HOSTSIM_RT_HI
+  RT_CASE(5)
+#endif
+#if HOSTSIM_RT_LO <= 6 && 6 <= HOSTSIM_RT_HI
+  RT_CASE(6)
+#endif
+#if HOSTSIM_RT_LO <= 7 && 7 <= HOSTSIM_RT_HI
+  RT_CASE(7)
+#endif
 #undef RT_CASE
   return -4;
 }
@@ -145,6 +182,7 @@ extern "C" int hostsim_joint(const char* builtin, const abrk_arm_desc* d, int dt
   });
 }
 
+#if HOSTSIM_LAW
 extern "C" int hostsim_osc_law(int n, int dtype, const abrk_osc_params* P, int64_t B, const void* J, const void* M,
                                const void* g, const void* c, const void* xyz, const void* R, const void* q,
                                const void* dq, const void* tg, const void* tv, void* ie, const void* une, void* u,
@@ -176,6 +214,8 @@ extern "C" int hostsim_osc_law(int n, int dtype, const abrk_osc_params* P, int64
   return -1;
 }
 
+#endif
+
 extern "C" int hostsim_rollout(const char* builtin, const abrk_arm_desc* d, int dtype, const abrk_osc_params* P,
                                const abrk_twolink_plant* plant, int64_t B, int n_steps, int every, void* q, void* dq,
                                const void* tg, void* qt, void* dqt, void* ut) {
@@ -197,5 +237,16 @@ extern "C" int hostsim_rollout(const char* builtin, const abrk_arm_desc* d, int 
     } else {
       return -1;
     }
+  });
+}
+
+extern "C" int hostsim_ik(const char* builtin, const abrk_arm_desc* d, int dtype, const abrk_ik_params* P, int64_t B,
+                          const void* q, const void* tg, void* pp, void* vp) {
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int n) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    IkP<T> p{T(P->max_dx * P->dt), T(P->max_dr * P->dt), T(P->max_dq * P->dt), P->n_timesteps, P->method};
+    for (long b = 0; b < B; b++) ik_body<A, T>(b, a, p, (long)B, (const T*)q, (const T*)tg, (T*)pp, (T*)vp);
+    return 0;
   });
 }

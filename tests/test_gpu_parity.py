@@ -458,3 +458,37 @@ def test_gpu_user_arms_all_joint_counts(n):
             uo = o.osc_batch(p, q, dq, t)
             ok = np.array([np.linalg.cond(o.M(q[b])) < 1e8 for b in range(B)])
             assert cases.rel_err(u, uo)[ok].max() < 1e-6
+
+
+def test_gpu_inverse_kinematics():
+    """InverseKinematics.generate_path, all three methods, against the reference's paths"""
+    from abr_control_amd.arms import jaco2, ur5
+    from abr_control_amd.controllers.path_planners import InverseKinematics
+
+    for mod, arm in ((ur5, "ur5"), (jaco2, "jaco2")):
+        g = golden(arm)
+        ik = InverseKinematics(mod.Config())
+        for method in (1, 2, 3):
+            pp, vp = ik.generate_path(g["ik_q0"], g["ik_target"], n_timesteps=200, dt=0.001, method=method)
+            assert pp.shape == (6, 200, 6)
+            assert np.max(np.abs(pp - g[f"ik_m{method}_posD"])) < 1e-9
+            assert np.max(np.abs(vp - g[f"ik_m{method}_velD"])) < 1e-9
+        p1, v1 = ik.generate_path(g["ik_q0"][2], g["ik_target"][2])  # one path, reference shapes
+        assert p1.shape == (200, 6) and np.allclose(p1, g["ik_m3_posD"][2], atol=1e-9)
+        pos, vel = ik.next()
+        assert pos.shape == (6,) and np.array_equal(pos, p1[0])
+    # many paths at once: each row equals its own single-path run
+    rng = np.random.RandomState(8)
+    B = 5000
+    q0 = rng.uniform(0.3, 2.8, (B, 6))
+    rc = ur5.Config()
+    tgt = np.hstack([rc.Tx("EE", q0 + rng.uniform(-0.5, 0.5, (B, 6))), rng.uniform(-1, 1, (B, 3))])
+    ik = InverseKinematics(rc)
+    pp, vp = ik.generate_path(q0, tgt, n_timesteps=100)
+    assert np.all(np.isfinite(pp))
+    p7, _ = ik.generate_path(q0[7], tgt[7], n_timesteps=100)
+    assert np.array_equal(p7, pp[7])
+    # the path makes progress towards the target position
+    e0 = np.linalg.norm(rc.Tx("EE", q0) - tgt[:, :3], axis=1)
+    e1 = np.linalg.norm(rc.Tx("EE", pp[:, -1]) - tgt[:, :3], axis=1)
+    assert np.median(e1) < np.median(e0)

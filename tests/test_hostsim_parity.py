@@ -223,3 +223,29 @@ def _abi_frame(name, n):
     from abr_control_amd import _abi
 
     return _abi.frame_id(name, n)
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("arm", ["ur5", "jaco2"])
+def test_rows_inverse_kinematics(arm, variant):
+    from abr_control_amd import _abi
+    from tests import hostsim
+
+    g = golden(arm)
+    a = arm if variant == "static" else _abi.load_table(arm)
+    for method in (1, 2, 3):
+        pp, vp = hostsim.ik_generate_path(a, _abi.make_ik_params(method=method), g["ik_q0"], g["ik_target"])
+        assert np.max(np.abs(pp - g[f"ik_m{method}_posD"])) < 1e-9
+        assert np.max(np.abs(vp - g[f"ik_m{method}_velD"])) < 1e-9
+    # fewer joints than task dimensions (pinv of a 6 x 3 Jacobian), synthetic arm vs oracle
+    from oracle import oracle as O
+    from tests.synthetic_arms import make_arm
+
+    tab = make_arm(3, 77)
+    rng = np.random.RandomState(5)
+    q0, tgt = rng.uniform(-1, 1, (4, 3)), rng.uniform(-0.4, 0.4, (4, 6))
+    for method in (1, 2, 3):
+        p = _abi.make_ik_params(method=method, n_timesteps=60)
+        pp, _ = hostsim.ik_generate_path(tab, p, q0, tgt)
+        po, _ = O.ik_paths(tab, p, q0, tgt)
+        assert np.max(np.abs(pp - po)) < 1e-8

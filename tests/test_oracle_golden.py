@@ -108,3 +108,17 @@ def test_oracle_closed_loop_matches_reference():
     assert np.max(np.abs(dqt - g["rollout_dqD"])) < 1e-8
     assert np.max(np.abs(qt - g["rollout_qS"])) < 1e-3  # the shipped (float32-rounding) loop drifts ~4e-5
     assert np.array_equal(q, qt[:, -1]) and np.array_equal(dq, dqt[:, -1])
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2"])
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_oracle_inverse_kinematics_matches_reference(arm, method):
+    """InverseKinematics.generate_path (path_planners/inverse_kinematics.py:28-135), 200 iterations"""
+    from abr_control_amd import _abi
+    from oracle import oracle as O
+
+    g = golden(arm)
+    pp, vp = O.ik_paths(_abi.load_table(arm), _abi.make_ik_params(method=method), g["ik_q0"], g["ik_target"])
+    assert np.max(np.abs(pp - g[f"ik_m{method}_posD"])) < 1e-9
+    assert np.max(np.abs(vp - g[f"ik_m{method}_velD"])) < 1e-9
+    assert np.max(np.abs(pp - g[f"ik_m{method}_posS"])) < 1e-5  # shipped float32-rounding path

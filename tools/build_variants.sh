@@ -4,12 +4,12 @@
 # ABRK_LIB_PATH).  Usage: tools/build_variants.sh "w1b64:-DABRK_MIN_WAVES=1 -DABRK_BLOCK=64" ...
 set -e
 cd "$(dirname "$0")/../abr_control_amd/csrc"
-mkdir -p build/variants
+mkdir -p variants
 OTHERS=$(ls build/*.o | grep -v abrk_arm_ur5.o)
 for spec in "$@"; do
   tag="${spec%%:*}"; flags="${spec#*:}"
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only $flags -c abrk_arm_ur5.hip -o build/variants/ur5_$tag.o \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libabrk_$tag.so build/variants/ur5_$tag.o $OTHERS \
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only $flags -c abrk_arm_ur5.hip -o variants/ur5_$tag.o \
+    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libabrk_$tag.so variants/ur5_$tag.o $OTHERS \
     && echo "built $tag" ) &
 done
 wait

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/ab
 mkdir -p $O
-V=$GRAFT_REPO_ROOT/abr_control_amd/csrc/build/variants
+V=$GRAFT_REPO_ROOT/abr_control_amd/csrc/variants
 for rep in 1 2 3 4; do
   for tag in "$@"; do
     ABRK_LIB_PATH=$V/libabrk_$tag.so python bench.py --workload ${ABW:-cfg2} --steps 200 --warmup 20 --roofline-steps 40 --no-cpu-baseline > $O/b_${tag}_$rep.json 2>/dev/null
