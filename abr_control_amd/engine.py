@@ -286,7 +286,8 @@ class OscPlan:
             pass
 
 
-def ik_generate_path(arm_id, n, params, position, target, dtype=np.float64, device=0, stream=None):
+def ik_generate_path(arm_id, n, params, position, target, dtype=np.float64, device=0, stream=None,
+                     position_path=None, velocity_path=None):
     """InverseKinematics.generate_path for B paths: position [B,n], target [B,6] (xyz + Euler 'sxyz').
     Returns (position_path, velocity_path), each [B, n_timesteps, n]."""
     a = _Args(dtype)
@@ -294,7 +295,7 @@ def ik_generate_path(arm_id, n, params, position, target, dtype=np.float64, devi
     T = int(params.n_timesteps)
     qp = a.inp(position, (B, n), "position")
     tp = a.inp(target, (B, 6), "target")
-    ppp, ppo = a.out(None, (B, T, n), device, "position_path")
-    vpp, vpo = a.out(None, (B, T, n), device, "velocity_path")
+    ppp, ppo = a.out(position_path, (B, T, n), device, "position_path")
+    vpp, vpo = a.out(velocity_path, (B, T, n), device, "velocity_path")
     check(lib().abrk_ik_generate_path_batch(arm_id, a.code, C.byref(params), B, qp, tp, ppp, vpp, device, _sp(stream)))
     return ppo, vpo

@@ -45,6 +45,8 @@ WORKLOADS = {
     # SURVEY 8f-1 (first "next" row): the examples' closed loop on the device - OSC.generate followed by the
     # two-link plant step (arms/twojoint/arm_sim.py:101-137), `rollout_steps` control steps per launch
     "rollout": ("twojoint", 4096, "f64", "rollout", dict(kp=20, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 0]), 600),
+    # InverseKinematics.generate_path, 200 iterations per path inside one launch (method 3)
+    "ik": ("ur5", 4096, "f64", "ik", dict(method=3, n_timesteps=200), 2500),
 }
 ROLLOUT_STEPS = 1000
 
@@ -54,6 +56,8 @@ def algorithmic_bytes(n, esz, kind):
     Full-output dynamics: read q [n], write Tx[3] + J[6,n] + M[n,n] + g[n]."""
     if kind == "dyn":
         return esz * n + esz * (3 + 6 * n + n * n + n)
+    if kind == "ik":  # per launch and row: q, target in; position + velocity paths out
+        return esz * (n + 6) + esz * 2 * 200 * n
     if kind == "rollout":  # per launch and row: q, dq in/out + target; amortised over ROLLOUT_STEPS
         return esz * (4 * n + 6)
     nt = 3 if kind == "sliding" else 6
@@ -91,7 +95,11 @@ class Runner:
         self.dq = a.DeviceArray.from_numpy(dq, device)
         self.t = a.DeviceArray.from_numpy(t, device)
         self.u = a.DeviceArray((B, self.n), self.dt, device)
-        if kind == "rollout":
+        if kind == "ik":
+            self.params = _abi.make_ik_params(**kw)
+            T = kw["n_timesteps"]
+            self.ik_out = (a.DeviceArray((B, T, self.n), self.dt, device), a.DeviceArray((B, T, self.n), self.dt, device))
+        elif kind == "rollout":
             rc_L = np.array([[0, 0, 0], [0, 0, 0], [1.0, 0, 0], [1.0, 0, 0], [0.6, 0, 0], [0.6, 0, 0]])
             M = [np.diag(tab["mdiag"][l]) for l in range(3)]
             self.plant = _abi.make_twolink_plant(rc_L, M, 0.001)
@@ -120,10 +128,14 @@ class Runner:
             self.plan = engine.OscPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
                                        dtype=self.dt, device=device, stream=stream)
         self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
-        self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else 1)
+        self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else kw["n_timesteps"] if kind == "ik" else 1)
 
     def step(self):
-        if self.plan is not None:
+        if self.kind == "ik":
+            self.engine.ik_generate_path(self.arm_id, self.n, self.params, self.q, self.t, dtype=self.dt,
+                                         device=self.device, stream=self.stream, position_path=self.ik_out[0],
+                                         velocity_path=self.ik_out[1])
+        elif self.plan is not None:
             self.plan.launch()
         elif self.kind == "rollout":
             self.engine.osc_rollout_twolink(self.arm_id, self.params, self.plant, self.q, self.dq, self.t,
