@@ -490,8 +490,14 @@ struct Dyn {
   T gz[N];                                // sum_l m_l,z * dp_l,z/dq_i    (g = -9.81 gz, base_config.py:417-468)
   T Cm[CMODE == CMODE_MAT ? N * N : 1];   // Christoffel matrix           (base_config.py:678-727)
   T cv[CMODE == CMODE_VEC ? N : 1];       // C(q,dq) dq
-  T om[CMODE != CMODE_NONE ? N : 1][3];   // omega_j = sum_{k<j} dq_k z_k  (orthogonal chains)
+  T om[CMODE != CMODE_NONE ? N : 1][3];   // omega_j = sum_{k<j} dq_k z_k  (orthogonal chains, matrix mode)
+  // CMODE_VEC on orthogonal chains: kinematic state of the body the current link belongs to -
+  // angular velocity, bias angular acceleration, bias acceleration of the last joint origin
+  T bw[3], bal[3], bao[3];
 };
+// the recursive Coriolis-vector path (below) replaces the omega prefix sums
+template <class A, int CM>
+constexpr bool kRecursiveC = (CM == CMODE_VEC) && A::kOrtho;
 
 // does link L carry linear / any mass?  (static arms: compile time; user arms: assume yes)
 template <class A, int L>
@@ -548,7 +554,18 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
     d.gz[i()] += me[2];
     sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = fdot3(d.Ms[tri(i(), j())], me, e[j()]); });
   });
-  if constexpr (CM != CMODE_NONE) {
+  if constexpr (kRecursiveC<A, CM>) {
+    // C(q,dq) dq, linear part = sum_l E_l^T D_l a_l with a_l the bias (qdd = 0) acceleration of the COM,
+    // from the body recursion instead of per-link suffix sums:
+    //   a(p) = a(o) + alpha x (p - o) + omega x (omega x (p - o)),   o = origin of the last joint
+    T dl[3] = {p[0] - jt.o[NJ - 1][0], p[1] - jt.o[NJ - 1][1], p[2] - jt.o[NJ - 1][2]};
+    T t[3], ad[3], wt[3];
+    cross3(d.bw, dl, t);
+    cross3(d.bal, dl, ad);
+    cross3(d.bw, t, wt);
+    T ma[3] = {m0 * (d.bao[0] + ad[0] + wt[0]), m1 * (d.bao[1] + ad[1] + wt[1]), m2 * (d.bao[2] + ad[2] + wt[2])};
+    sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], e[k()], ma); });
+  } else if constexpr (CM != CMODE_NONE) {
     T s[3] = {T(-0.0), T(-0.0), T(-0.0)};
     T a[3] = {T(-0.0), T(-0.0), T(-0.0)};  // COM bias acceleration  Edot dq
     T ed[CM == CMODE_MAT ? NJ : 1][3];
@@ -576,6 +593,57 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
   }
 }
 
+// Angular Coriolis vector of link L on orthogonal chains (CMODE_VEC): with the world-frame diagonal D_L
+// of the reference (base_config.py:628) the Christoffel form of M^w = sum_l Jw_l^T D_l Jw_l reduces to
+//   c^w_k = z_k . sum_{l>k} n_l,    n_l = D_l alpha_l + (D_l omega_l) x omega_l
+// (derivation in DESIGN.md; note the sign differs from Euler's equation because D_l is not rotated).
+template <int L, class A, class T, int CM>
+ABRK_INL void angular_link_coriolis(const A& arm, const Joints<A, T>& jt, Dyn<A, T, CM>& d) {
+  if constexpr (kRecursiveC<A, CM>) {
+    constexpr int NJ = (L < A::N ? L : A::N);
+    bool live = true;
+    if constexpr (A::kStatic) {
+      if constexpr (!(L < A::NL) || (A::MD(L, 3) == 0.0 && A::MD(L, 4) == 0.0 && A::MD(L, 5) == 0.0)) return;
+    } else {
+      live = (L < arm.NL);
+    }
+    if (!live) return;
+    T I0 = AccMD<A, T, L, 3>::get(arm), I1 = AccMD<A, T, L, 4>::get(arm), I2 = AccMD<A, T, L, 5>::get(arm);
+    T Lw[3] = {I0 * d.bw[0], I1 * d.bw[1], I2 * d.bw[2]};
+    T n[3];
+    cross3(Lw, d.bw, n);
+    n[0] = Rm<T>::fma(I0, d.bal[0], n[0]);
+    n[1] = Rm<T>::fma(I1, d.bal[1], n[1]);
+    n[2] = Rm<T>::fma(I2, d.bal[2], n[2]);
+    sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], jt.z[k()], n); });
+  }
+}
+
+// Advance the body state across joint L-1 (just recorded): first move the bias acceleration to the new
+// joint origin using the OLD body's (omega, alpha), then add the joint's contribution.
+template <int L, class A, class T, int CM>
+ABRK_INL void body_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
+  if constexpr (kRecursiveC<A, CM> && L - 1 < A::N) {
+    constexpr int i = L - 1;
+    if constexpr (i == 0) {
+      sfor<3>([&](auto r) ABRK_LAMBDA { d.bw[r()] = d.bal[r()] = d.bao[r()] = T(0); });
+    } else {
+      T d2[3] = {jt.o[i][0] - jt.o[i - 1][0], jt.o[i][1] - jt.o[i - 1][1], jt.o[i][2] - jt.o[i - 1][2]};
+      T t[3], ad[3], wt[3];
+      cross3(d.bw, d2, t);
+      cross3(d.bal, d2, ad);
+      cross3(d.bw, t, wt);
+      sfor<3>([&](auto r) ABRK_LAMBDA { d.bao[r()] += ad[r()] + wt[r()]; });
+    }
+    T zd[3];
+    cross3(d.bw, jt.z[i], zd);  // d/dt z_i = omega x z_i
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      d.bal[r()] = Rm<T>::fma(zd[r()], dq[i], d.bal[r()]);
+      d.bw[r()] = Rm<T>::fma(jt.z[i][r()], dq[i], d.bw[r()]);
+    });
+  }
+}
+
 template <class A, class T, int CM>
 ABRK_INL void dyn_init(Dyn<A, T, CM>& d) {
   constexpr int N = A::N;
@@ -600,38 +668,8 @@ ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)
   sfor<N>([&](auto i) ABRK_LAMBDA {
     sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = idot<i()>(arm, jt.z[i()], jt.z[j()], d.Ms[tri(i(), j())]); });
   });
-  if constexpr (CM == CMODE_VEC && A::kOrtho) {
-    // c^w_k = zdot_k.y_k + z_k.y'_k - sum_{i>k} dq_i (z_k x z_i).y_i        (zdot_i = omega_i x z_i)
-    //   y_k  = Ibar_k o (sum_{i<=k} z_i dq_i)    + sum_{i>k} Ibar_i o (z_i dq_i)
-    //   y'_k = Ibar_k o (sum_{i<=k} zdot_i dq_i) + sum_{i>k} Ibar_i o (zdot_i dq_i)
-    // evaluated in ONE backward sweep with four running 3-vectors (no per-joint arrays: this
-    // phase used to hold 54 extra doubles live), using (z_k x z_i).y_i = z_k.(z_i x y_i).
-    T pall[3] = {T(-0.0), T(-0.0), T(-0.0)};  // sum_i zdot_i dq_i
-    sfor<N>([&](auto i) ABRK_LAMBDA {
-      T zd[3];
-      cross3(d.om[i()], jt.z[i()], zd);
-      sfor<3>([&](auto r) ABRK_LAMBDA { pall[r()] += zd[r()] * dq[i()]; });
-    });
-    T Q[3] = {T(0), T(0), T(0)}, Qp[3] = {T(0), T(0), T(0)}, Sp[3] = {T(0), T(0), T(0)}, Rr[3] = {T(0), T(0), T(0)};
-    sfor<N>([&](auto kr) ABRK_LAMBDA {
-      constexpr int k = N - 1 - kr();
-      T zd[3], y[3], yp[3], zy[3];
-      cross3(d.om[k], jt.z[k], zd);
-      sfor<3>([&](auto r) ABRK_LAMBDA {
-        T pk = d.om[k][r()] + jt.z[k][r()] * dq[k];  // sum_{i<=k} z_i dq_i
-        y[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, pk, Q[r()]);
-        yp[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, pall[r()] - Sp[r()], Qp[r()]);
-      });
-      d.cv[k] += dot3(zd, y) + dot3(jt.z[k], yp) - dot3(jt.z[k], Rr);
-      cross3(jt.z[k], y, zy);
-      sfor<3>([&](auto r) ABRK_LAMBDA {
-        Q[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, jt.z[k][r()] * dq[k], Q[r()]);
-        Qp[r()] = cfma<AccIsuf<A, T, k, r()>>(arm, zd[r()] * dq[k], Qp[r()]);
-        Sp[r()] += zd[r()] * dq[k];
-        Rr[r()] += dq[k] * zy[r()];
-      });
-    });
-  }
+  // (orthogonal chains in CMODE_VEC: the angular Coriolis vector is accumulated link by link in
+  //  angular_link_coriolis during the forward pass)
   if constexpr (CM == CMODE_VEC && !A::kOrtho) {
     // general affine chain: c^w_k = zdot_k.y_k + z_k.y'_k - sum_{i>k} dq_i (W_k z_i).y_i
     //   y_k  = sum_i Ibar_max(k,i) o (z_i dq_i),   y'_k = sum_i Ibar_max(k,i) o (zdot_i dq_i)
@@ -692,7 +730,7 @@ ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)
 // link_accumulate<L> uses joints < L, so it is advanced inside the link visitor.
 template <int L, class A, class T, int CM>
 ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
-  if constexpr (CM != CMODE_NONE && A::kOrtho && L - 1 < A::N) {
+  if constexpr (CM != CMODE_NONE && !kRecursiveC<A, CM> && A::kOrtho && L - 1 < A::N) {
     constexpr int j = L - 1;  // joint that was just recorded
     if constexpr (j == 0) {
       d.om[0][0] = d.om[0][1] = d.om[0][2] = T(0);
@@ -710,7 +748,9 @@ ABRK_INL void kin_dyn(const A& arm, const T (&q)[A::N], const T (&dq)[A::N], Joi
   dyn_init(d);
   fk_forward(arm, q, jt, XR, xo, cap, [&](auto L, const T(&p)[3]) ABRK_LAMBDA {
     omega_advance<L()>(jt, dq, d);
+    body_advance<L()>(jt, dq, d);
     link_accumulate<L()>(arm, jt, dq, p, d);
+    angular_link_coriolis<L()>(arm, jt, d);
   });
   angular_finish(arm, jt, dq, d);
 }

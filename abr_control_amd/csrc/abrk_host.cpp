@@ -762,7 +762,11 @@ struct OscPlan {
   LaunchArgs la;
 };
 std::mutex g_plan_mu;
-std::vector<OscPlan*> g_plans;
+// fixed slot table: abrk_plan_launch reads a slot without taking the lock (hot path of a control loop),
+// so slots must never move; creation/destruction are serialised by g_plan_mu
+constexpr int kMaxPlans = 4096;
+OscPlan* g_plans[kMaxPlans] = {};
+int g_n_plans = 0;
 }  // namespace
 
 extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
@@ -809,13 +813,18 @@ extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params
   pl->oa.fast = osc_is_fast(*P, n, u_null_ext != nullptr);
   pl->la = LaunchArgs{a->builtin ? nullptr : (const void*)pl->rt.data(), (long)B, (hipStream_t)stream};
   std::lock_guard<std::mutex> lk(g_plan_mu);
-  g_plans.push_back(pl);
-  return (int)g_plans.size() - 1;
+  if (g_n_plans >= kMaxPlans) {
+    delete pl;
+    return fail(ABRK_ENOMEM, "too many plans (max %d)", kMaxPlans);
+  }
+  g_plans[g_n_plans] = pl;
+  __atomic_thread_fence(__ATOMIC_RELEASE);
+  return g_n_plans++;
 }
 
 extern "C" int abrk_plan_launch(int plan) {
-  // plans are append-only: reading the slot needs no lock once the id has been handed out
-  if (plan < 0 || plan >= (int)g_plans.size() || !g_plans[plan] || !g_plans[plan]->live)
+  // slots are append-only and never move: reading one needs no lock once its id has been handed out
+  if (plan < 0 || plan >= kMaxPlans || !g_plans[plan] || !g_plans[plan]->live)
     return fail(ABRK_EINVAL, "unknown plan %d", plan);
   OscPlan* pl = g_plans[plan];
   if (t_current_device != pl->device) {
@@ -828,7 +837,7 @@ extern "C" int abrk_plan_launch(int plan) {
 
 extern "C" int abrk_plan_destroy(int plan) {
   std::lock_guard<std::mutex> lk(g_plan_mu);
-  if (plan < 0 || plan >= (int)g_plans.size() || !g_plans[plan] || !g_plans[plan]->live)
+  if (plan < 0 || plan >= kMaxPlans || !g_plans[plan] || !g_plans[plan]->live)
     return fail(ABRK_EINVAL, "unknown plan %d", plan);
   g_plans[plan]->live = false;
   return 0;
