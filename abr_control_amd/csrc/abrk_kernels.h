@@ -18,10 +18,11 @@ constexpr int kBlock = ABRK_BLOCK;  // rows are independent, no LDS sharing: one
   long b = (long)blockIdx.x * kBlock + threadIdx.x;        \
   if (b >= B) return;
 
-// Cooperative, coalesced row stores: each lane parks its row in the wavefront's LDS slab (odd
-// row stride -> conflict-free ds_write), then the 64 lanes stream the slab out in linear order,
-// 512 contiguous bytes per store instruction.  The row-per-lane alternative writes 64 separate
-// 8-byte pieces per instruction and is what makes the full-output mode HBM-inefficient.
+// Cooperative, coalesced row stores: each lane parks its row in the wavefront's LDS slab, laid out exactly
+// like the 64-row block of the output array, then the 64 lanes stream the slab out linearly with 16-byte
+// stores (1 KiB contiguous per instruction, no index arithmetic).  The row-per-lane alternative writes 64
+// separate 8-byte pieces per instruction and is what makes the full-output mode HBM-inefficient.  (The
+// parking writes have a 2-4-way bank conflict for even row lengths; LDS time is hidden behind HBM here.)
 // widest output row of an N-joint arm: J/dJ (6N), M/C (N*N), T (16)
 constexpr int max_row(int n) { return (6 * n > n * n ? 6 * n : n * n) > 16 ? (6 * n > n * n ? 6 * n : n * n) : 16; }
 template <class T>
@@ -31,17 +32,23 @@ struct LdsStore {
   int lane;
   template <int R>
   __device__ __forceinline__ void put(T* __restrict__ out, long, bool, const T (&v)[R]) {
-    constexpr int S = R | 1;
-    sfor<R>([&](auto k) ABRK_LAMBDA { buf[lane * S + k()] = v[k()]; });
+    constexpr int V = 16 / sizeof(T);  // elements per 16-byte store
+    sfor<R>([&](auto k) ABRK_LAMBDA { buf[lane * R + k()] = v[k()]; });
     __syncthreads();
     const long left = B - row0;
-    const int total = (int)(left < kBlock ? left : (long)kBlock) * R;
-    T* o = out + row0 * R;
-    sfor<R>([&](auto j) ABRK_LAMBDA {
-      const int e = lane + kBlock * j();
-      if (e < total) {
-        const int row = e / R, k = e - row * R;
-        o[e] = buf[row * S + k];
+    const int total = (int)(left < kBlock ? left : (long)kBlock) * R;  // elements of this block
+    T* o = out + row0 * R;                                            // 64*R*sizeof(T)-byte aligned
+    const bool aligned = (reinterpret_cast<unsigned long long>(o) & 15ull) == 0;  // caller pointers may not be
+    constexpr int iters = (kBlock * R / V + kBlock - 1) / kBlock;
+    sfor<iters>([&](auto j) ABRK_LAMBDA {
+      const int e = (lane + kBlock * j()) * V;
+      if (aligned && e + V <= total) {
+        using vec = T __attribute__((ext_vector_type(V)));
+        *reinterpret_cast<vec*>(o + e) = *reinterpret_cast<const vec*>(buf + e);
+      } else {
+        sfor<V>([&](auto c) ABRK_LAMBDA {
+          if (e + c() < total) o[e + c()] = buf[e + c()];
+        });
       }
     });
     __syncthreads();
@@ -52,7 +59,7 @@ template <class A, class T, bool WITH_DQ>
 __global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, const T* __restrict__ qg,
            const T* __restrict__ dqg, DynOutP<T> out) {
-  __shared__ T slab[kBlock * (max_row(A::N) | 1)];
+  __shared__ __attribute__((aligned(16))) T slab[kBlock * max_row(A::N)];
   const long row0 = (long)blockIdx.x * kBlock;
   const long b = row0 + threadIdx.x;
   LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
