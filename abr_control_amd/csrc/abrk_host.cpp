@@ -760,6 +760,9 @@ struct OscPlan {
   OscP<float> p32;
   OscArgs oa;
   LaunchArgs la;
+  int graph_repeat = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
 };
 std::mutex g_plan_mu;
 // fixed slot table: abrk_plan_launch reads a slot without taking the lock (hot path of a control loop),
@@ -832,6 +835,35 @@ extern "C" int abrk_plan_launch(int plan) {
     t_current_device = pl->device;
   }
   HIPCHK(pl->ops->osc(pl->dtype, pl->la, pl->oa));
+  return 0;
+}
+
+extern "C" int abrk_plan_launch_graph(int plan, int repeat) {
+  if (plan < 0 || plan >= kMaxPlans || !g_plans[plan] || !g_plans[plan]->live)
+    return fail(ABRK_EINVAL, "unknown plan %d", plan);
+  if (repeat < 1) return fail(ABRK_EINVAL, "repeat must be >= 1");
+  OscPlan* pl = g_plans[plan];
+  if (t_current_device != pl->device) {
+    HIPCHK(hipSetDevice(pl->device));
+    t_current_device = pl->device;
+  }
+  if (!pl->la.stream) return fail(ABRK_EINVAL, "graph launches need a plan created on an explicit stream");
+  if (pl->graph_repeat != repeat) {
+    if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
+    if (pl->graph) (void)hipGraphDestroy(pl->graph);
+    pl->graph_exec = nullptr;
+    pl->graph = nullptr;
+    pl->graph_repeat = 0;
+    HIPCHK(hipStreamBeginCapture(pl->la.stream, hipStreamCaptureModeThreadLocal));
+    hipError_t le = hipSuccess;
+    for (int i = 0; i < repeat && le == hipSuccess; i++) le = pl->ops->osc(pl->dtype, pl->la, pl->oa);
+    hipError_t ce = hipStreamEndCapture(pl->la.stream, &pl->graph);
+    if (le != hipSuccess || ce != hipSuccess)
+      return fail(ABRK_ENODEV, "graph capture failed: %s", hipGetErrorString(le != hipSuccess ? le : ce));
+    HIPCHK(hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0));
+    pl->graph_repeat = repeat;
+  }
+  HIPCHK(hipGraphLaunch(pl->graph_exec, pl->la.stream));
   return 0;
 }
 

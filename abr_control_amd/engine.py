@@ -279,6 +279,10 @@ class OscPlan:
         if rc < 0:
             check(rc)
 
+    def launch_graph(self, repeat):
+        """`repeat` consecutive launches as one hipGraph launch (needs a plan on an explicit stream)"""
+        check(lib().abrk_plan_launch_graph(self.id, int(repeat)))
+
     def __del__(self):
         try:
             lib().abrk_plan_destroy(self.id)

@@ -123,6 +123,7 @@ class Runner:
             nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
             self.params = _abi.make_osc_params(self.n, null_controllers=nulls, **kw)
         self.plan = None
+        self.graph_steps = int(os.environ.get("ABRK_BENCH_GRAPH", "0"))
         if kind in ("osc", "osc_damp"):
             # the per-tick launch of a control loop on fixed device buffers: arguments validated once
             self.plan = engine.OscPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
@@ -162,8 +163,15 @@ class Runner:
         self.stream.sync()
         t0 = time.perf_counter()
         ev0.record(self.stream)
-        for _ in range(steps):
-            self.step()
+        if self.plan is not None and self.graph_steps > 1:
+            # K steps as ceil(K/G) hipGraph launches of G kernel nodes each (+ a remainder of plain launches)
+            for _ in range(steps // self.graph_steps):
+                self.plan.launch_graph(self.graph_steps)
+            for _ in range(steps % self.graph_steps):
+                self.step()
+        else:
+            for _ in range(steps):
+                self.step()
         ev1.record(self.stream)
         self.stream.sync()
         if barrier:

@@ -212,6 +212,9 @@ int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params* params, i
                          void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
                          int device, void* stream);
 int abrk_plan_launch(int plan);
+/* `repeat` consecutive launches of the plan as ONE hipGraph launch (captured on first use and cached per
+ * repeat count): removes the per-launch host work and tightens the dependent-launch gaps of short kernels. */
+int abrk_plan_launch_graph(int plan, int repeat);
 int abrk_plan_destroy(int plan);
 
 /* Sliding.generate (controllers/sliding.py:34-99), cartesian=True or False.
