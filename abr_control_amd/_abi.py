@@ -101,6 +101,72 @@ def make_ik_params(max_dx=0.2, max_dr=2 * np.pi, max_dq=np.pi, n_timesteps=200, 
     return p
 
 
+MAX_OBSTACLES = 16
+
+
+class LimitsParams(C.Structure):
+    _fields_ = [
+        ("min_joint_angles", C.c_double * MAX_JOINTS),
+        ("max_joint_angles", C.c_double * MAX_JOINTS),
+        ("max_torque", C.c_double * MAX_JOINTS),
+        ("cross_zero", C.c_int32 * MAX_JOINTS),
+        ("gradient", C.c_int32 * MAX_JOINTS),
+        ("no_limits_min", C.c_int32 * MAX_JOINTS),
+        ("no_limits_max", C.c_int32 * MAX_JOINTS),
+    ]
+
+
+class ObstaclesParams(C.Structure):
+    _fields_ = [
+        ("n_obstacles", C.c_int32),
+        ("reserved", C.c_int32),
+        ("threshold", C.c_double),
+        ("gain", C.c_double),
+        ("maximum", C.c_double),
+        ("obstacles", (C.c_double * 4) * MAX_OBSTACLES),
+    ]
+
+
+def make_limits_params(n_joints, min_joint_angles, max_joint_angles, max_torque=None, cross_zero=None,
+                       gradient=None):
+    """AvoidJointLimits.__init__ (avoid_joint_limits.py:35-81) -> abrk_limits_params: limits shifted by
+    -pi (:45-50), swapped where cross_zero (:62-66), 'no limit' = NaN (or None) flagged (:74-75)."""
+    n = int(n_joints)
+    mn = np.array([np.nan if v is None else float(v) for v in min_joint_angles], dtype=float) - np.pi
+    mx = np.array([np.nan if v is None else float(v) for v in max_joint_angles], dtype=float) - np.pi
+    if mn.shape[0] != n or mx.shape[0] != n:
+        raise Exception("joint angles vector incorrect size")  # avoid_joint_limits.py:68-72
+    cz = np.zeros(n, bool) if cross_zero is None else np.array(cross_zero, dtype=bool)
+    gr = np.zeros(n, bool) if gradient is None else np.array(gradient, dtype=bool)
+    tmin, tmax = mn.copy(), mx.copy()
+    mx[cz], mn[cz] = tmin[cz], tmax[cz]
+    mt = np.ones(n) if max_torque is None else np.asarray(max_torque, dtype=float)
+    p = LimitsParams()
+    for i in range(n):
+        p.no_limits_min[i], p.no_limits_max[i] = int(np.isnan(mn[i])), int(np.isnan(mx[i]))
+        p.min_joint_angles[i] = 0.0 if np.isnan(mn[i]) else mn[i]
+        p.max_joint_angles[i] = 0.0 if np.isnan(mx[i]) else mx[i]
+        p.max_torque[i] = mt[i]
+        p.cross_zero[i], p.gradient[i] = int(cz[i]), int(gr[i])
+    return p
+
+
+def make_obstacles_params(obstacles=None, threshold=0.2, gain=1, maximum=500):
+    """AvoidObstacles.__init__ / set_obstacles (avoid_obstacles.py:26-36,122-133) -> abrk_obstacles_params."""
+    obs = np.zeros((0, 4)) if obstacles is None or len(obstacles) == 0 else np.asarray(obstacles, dtype=float)
+    if obs.ndim != 2 or obs.shape[1] != 4:
+        raise ValueError("obstacles must be a list of [x, y, z, radius]")
+    if obs.shape[0] > MAX_OBSTACLES:
+        raise ValueError(f"at most {MAX_OBSTACLES} obstacles")
+    p = ObstaclesParams()
+    p.n_obstacles = obs.shape[0]
+    p.threshold, p.gain, p.maximum = float(threshold), float(gain), float(maximum)
+    for i in range(obs.shape[0]):
+        for r in range(4):
+            p.obstacles[i][r] = obs[i, r]
+    return p
+
+
 class TwoLinkPlant(C.Structure):
     _fields_ = [("K1", C.c_double), ("K2", C.c_double), ("K3", C.c_double), ("K4", C.c_double), ("dt", C.c_double)]
 

@@ -286,6 +286,49 @@ int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_ctrl* ctrl,
                               void* u, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------
+ * The remaining secondary controllers.  Each writes u [B,n]; with accumulate != 0 it
+ * adds to u instead (several secondary controllers summed on device before OSC's null-space filter,
+ * abr_control/controllers/osc.py:310-318 - pass the sum as u_null_ext to abrk_osc_generate_batch).
+ * --------------------------------------------------------------------------------- */
+
+/* AvoidJointLimits (controllers/avoid_joint_limits.py:35-142).  The limit arrays are the ones the
+ * reference's constructor stores (avoid_joint_limits.py:45-75): shifted by -pi, min/max swapped where
+ * cross_zero, "no limit" (NaN there) flagged in no_limits_min / no_limits_max.                       */
+typedef struct abrk_limits_params {
+  double min_joint_angles[ABRK_MAX_JOINTS];
+  double max_joint_angles[ABRK_MAX_JOINTS];
+  double max_torque[ABRK_MAX_JOINTS];
+  int32_t cross_zero[ABRK_MAX_JOINTS];
+  int32_t gradient[ABRK_MAX_JOINTS];
+  int32_t no_limits_min[ABRK_MAX_JOINTS];
+  int32_t no_limits_max[ABRK_MAX_JOINTS];
+} abrk_limits_params;
+
+/* AvoidJointLimits.generate (avoid_joint_limits.py:83-142); depends on q only. */
+int abrk_avoid_joint_limits_generate_batch(int n_joints, int dtype, const abrk_limits_params* params, int64_t B,
+                                           const void* q, void* u, int accumulate, int device, void* stream);
+
+/* Floating.generate (controllers/floating.py:27-71): gravity compensation in joint space or through
+ * the task-space inertia of the EE (floating.py:42-62), minus M dq when dynamic (floating.py:66-69).
+ * dq [B,n] is read only when dynamic != 0.                                                          */
+int abrk_floating_generate_batch(int arm_id, int dtype, int dynamic, int task_space, int64_t B, const void* q,
+                                 const void* dq, void* u, int accumulate, int device, void* stream);
+
+/* AvoidObstacles.generate (controllers/avoid_obstacles.py:38-120): Khatib potential field between each
+ * arm segment (joint_i .. joint_i+1 / EE) and each obstacle [x, y, z, radius], mapped through the
+ * inertia of the closest point.  Obstacles are shared by all rows (set_obstacles, avoid_obstacles.py:122). */
+#define ABRK_MAX_OBSTACLES 16
+typedef struct abrk_obstacles_params {
+  int32_t n_obstacles;
+  int32_t reserved;
+  double threshold, gain, maximum;
+  double obstacles[ABRK_MAX_OBSTACLES][4];
+} abrk_obstacles_params;
+
+int abrk_avoid_obstacles_generate_batch(int arm_id, int dtype, const abrk_obstacles_params* params, int64_t B,
+                                        const void* q, void* u, int accumulate, int device, void* stream);
+
+/* ---------------------------------------------------------------------------------
  * Device plumbing (the host side is Python + ctypes; no PyTorch involved).
  * --------------------------------------------------------------------------------- */
 int abrk_device_count(void);

@@ -64,6 +64,9 @@ class RawConfig:
     def Tx(self, name, q, x=None):
         return self.rc.Tx(name, q, x)
 
+    def T_inv(self, name, q, x=None):  # base_config.py:394-415 returns the generated fp64 matrix as is
+        return self.rc.T_inv(name, q, x)
+
 
 def frames_of(rc):
     fr = []
@@ -362,7 +365,98 @@ def gen_known():
     print(f"  wrote {OUT}/known_answers.npz", flush=True)
 
 
+# ----------------------------------------------------------------------------------------
+def limit_sets(n):
+    """two AvoidJointLimits parameterisations covering walls / gradients / zero-crossing ranges / no limits"""
+    nan = np.nan
+    a = dict(mn=[], mx=[], cz=[], gr=[], mt=[])
+    b = dict(mn=[], mx=[], cz=[], gr=[], mt=[])
+    for i in range(n):
+        k = i % 4
+        a["mn"].append([np.pi / 5.0, 1.0, 5.5, nan][k])
+        a["mx"].append([np.pi / 2.0, 4.0, 0.8, nan][k])
+        a["cz"].append([False, False, True, False][k])
+        a["gr"].append([False, True, False, False][k])
+        a["mt"].append([100.0, 7.5, 3.0, 1.0][k])
+        b["mn"].append([5.0, nan, 0.4, 2.0][k])
+        b["mx"].append([1.2, 3.0, nan, 2.5][k])
+        b["cz"].append([True, False, False, False][k])
+        b["gr"].append([True, True, False, True][k])
+        b["mt"].append([2.0, 0.5, 4.0, 1e9][k])
+    return {"limA": a, "limB": b}
+
+
+OBSTACLES = {
+    # [x, y, z, radius] inside each arm's workspace; threshold / gain as in examples/PyGame/avoid_obstacles.py:17
+    "twojoint": dict(obstacles=[[1.0, 1.0, 0, 0.2], [-0.5, 1.5, 0, 0.2], [0.5, -1.0, 0, 0.3]], threshold=1, gain=30),
+    "threejoint": dict(obstacles=[[1.0, 1.0, 0, 0.2], [-0.5, 1.5, 0, 0.2], [0.5, -1.0, 0, 0.3]], threshold=1, gain=30),
+    "ur5": dict(obstacles=[[0.3, 0.2, 0.4, 0.1], [-0.2, 0.4, 0.3, 0.05], [0.1, -0.3, 0.6, 0.15]], threshold=0.3,
+                gain=30),
+    "jaco2": dict(obstacles=[[0.3, 0.2, 0.4, 0.1], [-0.2, 0.4, 0.3, 0.05], [0.1, -0.3, 0.6, 0.15]], threshold=0.3,
+                  gain=30),
+}
+
+
+def gen_secondary(arm):
+    """AvoidJointLimits / Floating / AvoidObstacles of the reference on seeded states."""
+    mod = importlib.import_module(f"abr_control.arms.{arm}")
+    from abr_control.controllers import AvoidJointLimits, AvoidObstacles, Floating
+
+    rc = mod.Config(use_cython=True)
+    raw = RawConfig(rc)
+    n = rc.N_JOINTS
+    out = {}
+    rng = np.random.RandomState(70)
+    B = 256
+    q, dq, _ = draw(rng, B, n)
+    out["lim_q"] = q
+    for key, ps in limit_sets(n).items():
+        c = AvoidJointLimits(rc, min_joint_angles=list(ps["mn"]), max_joint_angles=list(ps["mx"]),
+                             max_torque=list(ps["mt"]), cross_zero=list(ps["cz"]), gradient=list(ps["gr"]))
+        with np.errstate(all="ignore"):
+            out[f"{key}_u"] = np.array([c.generate(q[b], dq[b]) for b in range(B)])
+        for f in ("mn", "mx", "mt", "cz", "gr"):
+            out[f"{key}_{f}"] = np.array(ps[f])
+        print(f"  {key}: nonzero rows {np.count_nonzero(np.any(out[f'{key}_u'] != 0, axis=1))}/{B}", flush=True)
+
+    Bf = 128
+    q, dq, _ = draw(np.random.RandomState(71), Bf, n)
+    out["float_q"], out["float_dq"] = q, dq
+    for dyn in (0, 1):
+        for ts in (0, 1):
+            for label, cfg in (("S", rc), ("D", raw)):
+                c = Floating(cfg, dynamic=bool(dyn), task_space=bool(ts))
+                out[f"float_d{dyn}t{ts}_u{label}"] = np.array(
+                    [np.asarray(c.generate(q[b], dq[b]), dtype=float) for b in range(Bf)])
+            d = np.max(np.abs(out[f"float_d{dyn}t{ts}_uS"] - out[f"float_d{dyn}t{ts}_uD"]), axis=1) / np.maximum(
+                np.max(np.abs(out[f"float_d{dyn}t{ts}_uD"]), axis=1), 1e-300)
+            print(f"  floating dynamic={dyn} task_space={ts}: S-vs-D rel median={np.median(d):.2e} "
+                  f"max={np.max(d):.2e}", flush=True)
+
+    Bo = 128
+    q, _, _ = draw(np.random.RandomState(72), Bo, n)
+    out["obs_q"] = q
+    kw = OBSTACLES[arm]
+    out["obs_obstacles"] = np.array(kw["obstacles"], dtype=float)
+    out["obs_threshold"], out["obs_gain"] = float(kw["threshold"]), float(kw["gain"])
+    for label, cfg in (("S", rc), ("D", raw)):
+        c = AvoidObstacles(cfg, **kw)
+        with np.errstate(all="ignore"):
+            out[f"obs_u{label}"] = np.array([c.generate(q[b]) for b in range(Bo)])
+            if label == "D":  # the same signal before np.clip (avoid_obstacles.py:121): the scale errors live on
+                c.maximum = 1e300
+                out["obs_uD_unclipped"] = np.array([c.generate(q[b]) for b in range(Bo)])
+    act = np.any(out["obs_uD"] != 0, axis=1)
+    d = np.max(np.abs(out["obs_uS"] - out["obs_uD"]), axis=1)[act] / np.max(np.abs(out["obs_uD"]), axis=1)[act]
+    print(f"  obstacles: active rows {act.sum()}/{Bo}; S-vs-D rel median={np.median(d):.2e} max={np.max(d):.2e}",
+          flush=True)
+    np.savez_compressed(f"{OUT}/sec_{arm}.npz", **out)
+    print(f"  wrote {OUT}/sec_{arm}.npz ({len(out)} arrays)", flush=True)
+
+
 if what == "known":
     gen_known()
+elif what.startswith("sec:"):
+    gen_secondary(what[4:])
 else:
     gen_arm(what)

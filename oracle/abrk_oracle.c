@@ -956,3 +956,202 @@ int abrk_oracle_ik_generate_path(const abrk_arm_desc* a, const abrk_ik_params* P
   }
   return 0;
 }
+
+/* ------------------------------------------------------------------ AvoidJointLimits.generate
+ * avoid_joint_limits.py:83-142, statement for statement (element i of every vector op).  The NaN
+ * comparisons of "no limit" entries are all false in numpy, and those entries are zeroed at
+ * :136,:139 - restated here with the flags so that no NaN arithmetic is needed.               */
+int abrk_oracle_avoid_joint_limits_generate(int n, const abrk_limits_params* P, const double* q_in, double* u) {
+  for (int i = 0; i < n; i++) {
+    double q = q_in[i] - 1.0 * M_PI; /* :91 */
+    double mn = P->min_joint_angles[i], mx = P->max_joint_angles[i];
+    int nomin = P->no_limits_min[i], nomax = P->no_limits_max[i];
+    int closer_to_min = (!nomin && !nomax) && (fabs(q - mn) >= fabs(q - mx)); /* :94-96 */
+    int closer_to_max = (!nomin && !nomax) && (fabs(q - mn) <= fabs(q - mx)); /* :97-99 */
+    double avoid_min = 0.0, avoid_max = 0.0;
+    if (P->gradient[i]) { /* :108-115 */
+      if (!nomin) avoid_min = fmin(exp(1.0 / (q - mn)), P->max_torque[i]);
+      if (!nomax) avoid_max = -fmin(exp(-1.0 / (q - mx)), P->max_torque[i]);
+    }
+    int min_index = !nomin && (q - mn) < 0; /* :118 */
+    int max_index = !nomax && (q - mx) > 0; /* :119 */
+    if (P->cross_zero[i]) {                 /* :124-134 */
+      int mi = min_index * (!nomax && (q - mx) > 0) * closer_to_max;
+      int xi = max_index * (!nomin && (q - mn) < 0) * closer_to_min;
+      min_index = mi;
+      max_index = xi;
+    }
+    if (min_index) avoid_min = P->max_torque[i]; /* :136 */
+    if (nomin) avoid_min = 0.0;                  /* :137 */
+    if (max_index) avoid_max = -P->max_torque[i];
+    if (nomax) avoid_max = 0.0;
+    u[i] = avoid_min + avoid_max; /* :142 */
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ Floating.generate, floating.py:27-71
+ * diag (may be NULL): [det(Mx_inv), s_min/s_max of Mx_inv] in task space - lets tests treat states at
+ * the det / rcond thresholds (floating.py:50-56) separately.                                       */
+int abrk_oracle_floating_generate(const abrk_arm_desc* a, int dynamic, int task_space, const double* q,
+                                  const double* dq, double* u, double* diag) {
+  int n = a->n_joints;
+  double g[NJ], M[NJ * NJ], Jf[6 * NJ];
+  int haveM = 0;
+  abrk_oracle_g(a, q, g); /* :38 */
+  if (task_space) {
+    double Minv[NJ * NJ], T1[3 * NJ], Mxinv[9], Mx[9], Jbar[NJ * 3], tmp[NJ * 3], u_task[3];
+    abrk_oracle_J(a, 2 * n + 1, q, NULL, Jf); /* J("EE")[:3], :42 */
+    abrk_oracle_M(a, q, M);
+    haveM = 1;
+    la_inv(M, n, Minv); /* :47 */
+    for (int r = 0; r < 3; r++)
+      for (int j = 0; j < n; j++) {
+        double s = 0;
+        for (int i = 0; i < n; i++) s += Jf[r * n + i] * Minv[i * n + j];
+        T1[r * n + j] = s;
+      }
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int j = 0; j < n; j++) s += T1[r * n + j] * Jf[c * n + j];
+        Mxinv[r * 3 + c] = s; /* :49 */
+      }
+    double det = la_inv(Mxinv, 3, Mx);
+    if (!(fabs(det) > 1e-3)) la_pinv(Mxinv, 3, 3, 1e-4, Mx); /* :50-56 */
+    if (diag) {
+      double w[3], V[9], lo = 1e300, hi = 0;
+      la_eigh(Mxinv, 3, w, V);
+      for (int r = 0; r < 3; r++) {
+        lo = fmin(lo, fabs(w[r]));
+        hi = fmax(hi, fabs(w[r]));
+      }
+      diag[0] = det;
+      diag[1] = hi > 0 ? lo / hi : 0.0;
+    }
+    /* Jbar = Minv J^T Mx  [n x 3], :59 */
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int r = 0; r < 3; r++) s += Jf[r * n + i] * Mx[r * 3 + c];
+        tmp[i * 3 + c] = s;
+      }
+    for (int i = 0; i < n; i++)
+      for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int j = 0; j < n; j++) s += Minv[i * n + j] * tmp[j * 3 + c];
+        Jbar[i * 3 + c] = s;
+      }
+    for (int c = 0; c < 3; c++) { /* u_task = -Jbar^T g, :60 */
+      double s = 0;
+      for (int i = 0; i < n; i++) s += Jbar[i * 3 + c] * g[i];
+      u_task[c] = -1 * s;
+    }
+    for (int i = 0; i < n; i++) { /* u = J^T u_task, :61 */
+      double s = 0;
+      for (int r = 0; r < 3; r++) s += Jf[r * n + i] * u_task[r];
+      u[i] = s;
+    }
+  } else {
+    for (int i = 0; i < n; i++) u[i] = -g[i]; /* :64 */
+    if (diag) diag[0] = diag[1] = 1.0;
+  }
+  if (dynamic) { /* :67-69 */
+    double Mdq[NJ];
+    if (!haveM) abrk_oracle_M(a, q, M);
+    matvec(M, n, dq, Mdq);
+    for (int i = 0; i < n; i++) u[i] -= Mdq[i];
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ AvoidObstacles.generate
+ * avoid_obstacles.py:38-120.  diag (may be NULL): the smallest |s_i/s_max - 0.01| over every pinv
+ * taken (:112; 1.0 if none) - the distance of the state from the pinv truncation threshold.      */
+int abrk_oracle_avoid_obstacles_generate(const abrk_arm_desc* a, const abrk_obstacles_params* P, const double* q,
+                                         double* u, double* diag) {
+  int n = a->n_joints;
+  double u_psp[NJ], M[NJ * NJ], Minv[NJ * NJ];
+  double margin = 1.0;
+  for (int i = 0; i < n; i++) u_psp[i] = 0.0;
+  abrk_oracle_M(a, q, M); /* :54 */
+  la_inv(M, n, Minv);
+  for (int ob = 0; ob < P->n_obstacles; ob++) {
+    const double* obstacle = P->obstacles[ob];
+    const double* v = obstacle; /* :59 */
+    for (int ii = 0; ii < n; ii++) {
+      double p1[3], p2[3], vec_line[3], vec_ob_line[3], closest[3];
+      abrk_oracle_Tx(a, 2 * ii + 1, q, NULL, p1); /* Tx("joint{ii}"), :64 */
+      if (ii == n - 1) abrk_oracle_Tx(a, 2 * n + 1, q, NULL, p2);
+      else abrk_oracle_Tx(a, 2 * (ii + 1) + 1, q, NULL, p2);
+      double dot = 0, len2 = 0;
+      for (int r = 0; r < 3; r++) {
+        vec_line[r] = p2[r] - p1[r];    /* :72 */
+        vec_ob_line[r] = v[r] - p1[r];  /* :74 */
+        dot += vec_ob_line[r] * vec_line[r];
+        len2 += vec_line[r] * vec_line[r];
+      }
+      /* :76; a zero-length segment gives 0/0 = NaN in numpy, every comparison below is then false
+       * (Python's max(nan, x) keeps the nan) and the segment contributes nothing */
+      if (len2 == 0.0) continue;
+      double projection = dot / len2;
+      for (int r = 0; r < 3; r++) {
+        if (projection < 0) closest[r] = p1[r];      /* :77-79 */
+        else if (projection > 1) closest[r] = p2[r]; /* :80-82 */
+        else closest[r] = p1[r] + projection * vec_line[r];
+      }
+      double d2 = 0;
+      for (int r = 0; r < 3; r++) d2 += (v[r] - closest[r]) * (v[r] - closest[r]);
+      double dist = sqrt(d2);                                    /* :86 */
+      double lo = P->threshold / 50, rho = dist - obstacle[3];  /* :90, Python max(a, b): b if b > a */
+      if (lo > rho) rho = lo;
+      if (rho < P->threshold) {
+        double eta = 0.02, Fpsp[3];
+        for (int r = 0; r < 3; r++) {
+          double drhodx = (v[r] - closest[r]) / rho;
+          Fpsp[r] = eta * (1.0 / rho - 1.0 / P->threshold) * 1.0 / pow(rho, 1.5) * drhodx; /* :96-102 */
+        }
+        /* :107-110: offset of the closest point in link ii+1's frame, Jacobian of that point */
+        double Ti[16], m[3], Jf[6 * NJ];
+        abrk_oracle_Tinv(a, 2 * (ii + 1), q, Ti);
+        for (int r = 0; r < 3; r++)
+          m[r] = Ti[r * 4] * closest[0] + Ti[r * 4 + 1] * closest[1] + Ti[r * 4 + 2] * closest[2] + Ti[r * 4 + 3];
+        abrk_oracle_J(a, 2 * (ii + 1), q, m, Jf);
+        /* :114-117 */
+        double T1[3 * NJ], Mxinv[9], Mxpsp[9], f[3];
+        for (int r = 0; r < 3; r++)
+          for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int i = 0; i < n; i++) s += Jf[r * n + i] * Minv[i * n + j];
+            T1[r * n + j] = s;
+          }
+        for (int r = 0; r < 3; r++)
+          for (int c = 0; c < 3; c++) {
+            double s = 0;
+            for (int j = 0; j < n; j++) s += T1[r * n + j] * Jf[c * n + j];
+            Mxinv[r * 3 + c] = s;
+          }
+        la_pinv(Mxinv, 3, 3, 0.01, Mxpsp);
+        if (diag) {
+          double w[3], V[9], hi = 0;
+          la_eigh(Mxinv, 3, w, V);
+          for (int r = 0; r < 3; r++) hi = fmax(hi, fabs(w[r]));
+          for (int r = 0; r < 3; r++)
+            if (hi > 0) margin = fmin(margin, fabs(fabs(w[r]) / hi - 0.01));
+        }
+        for (int r = 0; r < 3; r++) f[r] = Mxpsp[r * 3] * Fpsp[0] + Mxpsp[r * 3 + 1] * Fpsp[1] + Mxpsp[r * 3 + 2] * Fpsp[2];
+        for (int i = 0; i < n; i++) {
+          double s = 0;
+          for (int r = 0; r < 3; r++) s += Jf[r * n + i] * f[r];
+          u_psp[i] += -1 * s; /* :119 */
+        }
+      }
+    }
+  }
+  for (int i = 0; i < n; i++) { /* np.clip, :121 */
+    double x = u_psp[i] * P->gain;
+    u[i] = x < -P->maximum ? -P->maximum : (x > P->maximum ? P->maximum : x);
+  }
+  if (diag) diag[0] = margin;
+  return 0;
+}

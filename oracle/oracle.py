@@ -145,6 +145,39 @@ class Oracle:
         return u
 
 
+    def floating_batch(self, dynamic, task_space, q, dq=None):
+        """Floating.generate per row -> u [B,n], diag [B,2] (det, s_min/s_max of Mx_inv)"""
+        q = _c(q)
+        B = q.shape[0]
+        dq = np.zeros_like(q) if dq is None else _c(dq)
+        u, diag = np.zeros((B, self.n)), np.zeros((B, 2))
+        for b in range(B):
+            rc = self.L.abrk_oracle_floating_generate(self._d, int(dynamic), int(task_space), _p(q[b]), _p(dq[b]),
+                                                      _p(u[b]), _p(diag[b]))
+            assert rc == 0
+        return u, diag
+
+    def avoid_obstacles_batch(self, params, q):
+        """AvoidObstacles.generate per row -> u [B,n], margin [B] (distance from the pinv threshold)"""
+        q = _c(q)
+        B = q.shape[0]
+        u, diag = np.zeros((B, self.n)), np.zeros((B, 1))
+        for b in range(B):
+            rc = self.L.abrk_oracle_avoid_obstacles_generate(self._d, C.byref(params), _p(q[b]), _p(u[b]), _p(diag[b]))
+            assert rc == 0
+        return u, diag[:, 0]
+
+
+def avoid_joint_limits_batch(n, params, q):
+    """AvoidJointLimits.generate per row"""
+    q = _c(q)
+    u = np.zeros_like(q)
+    for b in range(q.shape[0]):
+        rc = lib().abrk_oracle_avoid_joint_limits_generate(int(n), C.byref(params), _p(q[b]), _p(u[b]))
+        assert rc == 0
+    return u
+
+
 def rollout_twolink(table, params, plant, q0, dq0, target, n_steps, every):
     """closed loop OSC.generate + ArmSim._step (examples/PyGame/force_osc_xy.py:57-78) on the oracle"""
     o = Oracle(table)

@@ -138,6 +138,17 @@ class OracleBackend:
     def joint(self, ctrl, grav, q, dq, t=None, tv=None, dtype=np.float64):
         return self.o.joint_batch(ctrl, grav, q, dq, t, tv)
 
+    def limits(self, params, q, dtype=np.float64):
+        from oracle.oracle import avoid_joint_limits_batch
+
+        return avoid_joint_limits_batch(self.n, params, q)
+
+    def floating(self, dynamic, task_space, q, dq, dtype=np.float64):
+        return self.o.floating_batch(dynamic, task_space, q, dq)[0]
+
+    def obstacles(self, params, q, dtype=np.float64):
+        return self.o.avoid_obstacles_batch(params, q)[0]
+
     def dynamics(self, q, dq=None, frame="EE", x_off=None, want=("M",), dtype=np.float64):
         o, B = self.o, len(q)
         f = {"Tx": lambda i: o.Tx(frame, q[i], x_off), "J": lambda i: o.J(frame, q[i], x_off),
@@ -255,6 +266,59 @@ def check_case_against_golden(backend, case_id, g, dtype=np.float64, rows=None):
         assert rT[ok].max() <= tol, f"{case_id}: training_signal {rT[ok].max():.3e}"
     return dict(case=case_id, worst_vs_D=float(worst), median_vs_D=float(np.median(rD)),
                 median_vs_S=float(np.median(rel_err(np.asarray(u, float), uS))), n_band=int((~ok).sum()))
+
+
+# ---- AvoidJointLimits / Floating / AvoidObstacles against tests/golden/sec_<arm>.npz
+def secondary_limit_params(g, key, n):
+    return _abi.make_limits_params(n, g[f"{key}_mn"], g[f"{key}_mx"], g[f"{key}_mt"], g[f"{key}_cz"], g[f"{key}_gr"])
+
+
+def secondary_obstacle_params(g):
+    return _abi.make_obstacles_params(g["obs_obstacles"], float(g["obs_threshold"]), float(g["obs_gain"]))
+
+
+def check_secondary_against_golden(backend, arm, g, dtype=np.float64):
+    """the reference's own outputs (fp64 formulas, `*_uD`); rows at the pinv truncation thresholds
+    (floating.py:50-56, avoid_obstacles.py:112) are identified with the oracle's diagnostics."""
+    from oracle.oracle import Oracle
+
+    n = backend.n
+    o = Oracle(_abi.load_table(arm))
+    tol = TOL_D if dtype == np.float64 else TOL_F32
+    if arm == "threejoint" and dtype == np.float64:
+        tol = TOL_THREEJOINT
+    report = {}
+    for key in ("limA", "limB"):  # pure function of q: exact up to exp() rounding
+        u = np.asarray(backend.limits(secondary_limit_params(g, key, n), g["lim_q"], dtype=dtype), float)
+        err = np.max(np.abs(u - g[f"{key}_u"]) / np.maximum(np.abs(g[f"{key}_u"]), 1.0))
+        assert err <= (1e-12 if dtype == np.float64 else 1e-5), f"{arm} {key} [{backend.name}]: {err:.3e}"
+        report[key] = float(err)
+    q, dq = g["float_q"], g["float_dq"]
+    for dyn in (0, 1):
+        for ts in (0, 1):
+            ref = g[f"float_d{dyn}t{ts}_uD"]
+            u = np.asarray(backend.floating(dyn, ts, q, dq, dtype=dtype), float)
+            _, diag = o.floating_batch(dyn, ts, q, dq)
+            ok = (np.abs(np.abs(diag[:, 0]) - 1e-3) > 1e-9) & (np.abs(diag[:, 1] - 1e-4) > 1e-8)
+            if dtype != np.float64:
+                ok &= diag[:, 1] > 1e-3
+            scale = np.maximum(np.max(np.abs(ref), axis=1), 1e-9)  # planar arms: g == 0 exactly
+            err = (np.max(np.abs(u - ref), axis=1) / scale)[ok].max()
+            assert err <= tol, f"{arm} floating d{dyn} t{ts} [{backend.name}]: {err:.3e}"
+            report[f"float_d{dyn}t{ts}"] = float(err)
+    P = secondary_obstacle_params(g)
+    ref = g["obs_uD"]
+    u = np.asarray(backend.obstacles(P, g["obs_q"], dtype=dtype), float)
+    _, margin = o.avoid_obstacles_batch(P, g["obs_q"])
+    ok = margin > (1e-7 if dtype == np.float64 else 1e-3)
+    # error relative to the row's signal before np.clip (avoid_obstacles.py:121): clipping at +-maximum
+    # would otherwise hide the scale the rounding of the other components lives on
+    scale = np.maximum(np.max(np.abs(g["obs_uD_unclipped"]), axis=1), 1e-9)
+    err = (np.max(np.abs(u - ref), axis=1) / scale)[ok].max()
+    assert err <= tol, f"{arm} obstacles [{backend.name}]: {err:.3e}"
+    report["obstacles"] = float(err)
+    report["obstacles_band"] = int((~ok).sum())
+    return report
 
 
 DYN_WANTS = ("Tx", "J", "M", "g", "C", "dJ", "R", "T", "quat")

@@ -24,6 +24,13 @@ def test_oracle_controllers_match_reference(case_id):
     cases.check_case_against_golden(cases.OracleBackend(arm), case_id, golden(arm), rows=rows)
 
 
+@pytest.mark.parametrize("arm", ARMS)
+def test_oracle_secondary_controllers_match_reference(arm):
+    """AvoidJointLimits / Floating / AvoidObstacles vs the reference's own outputs"""
+    rep = cases.check_secondary_against_golden(cases.OracleBackend(arm), arm, golden(f"sec_{arm}"))
+    assert rep["obstacles_band"] <= 4
+
+
 def test_oracle_twojoint_closed_forms():
     """the reference's own analytic fixture (Spong et al.), grids as test_base_config.py:40-180"""
     k = golden("known_answers")
