@@ -60,6 +60,12 @@ def lib():
             C.c_int, _vp]
         L.abrk_joint_generate_batch.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.NullCtrl), C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
+        L.abrk_avoid_joint_limits_generate_batch.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.LimitsParams), _i64, _vp, _vp, C.c_int, C.c_int, _vp]
+        L.abrk_floating_generate_batch.argtypes = [
+            C.c_int, C.c_int, C.c_int, C.c_int, _i64, _vp, _vp, _vp, C.c_int, C.c_int, _vp]
+        L.abrk_avoid_obstacles_generate_batch.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.ObstaclesParams), _i64, _vp, _vp, C.c_int, C.c_int, _vp]
         L.abrk_device_name.argtypes = [C.c_int, C.c_char_p, C.c_size_t]
         L.abrk_malloc.restype = _vp
         L.abrk_malloc.argtypes = [C.c_int, C.c_size_t]

@@ -53,9 +53,11 @@ class OSC(Controller):
         self.IDENTITY_N_JOINTS = np.eye(self.robot_config.N_JOINTS)
         self.training_signal = None
 
-        # secondary controllers: Damping / RestingConfig are fused into the kernel; any other
-        # object with generate(q, dq) is evaluated by the caller's code and only projected
-        self._fused, self._foreign = [], []
+        # secondary controllers: Damping / RestingConfig are fused into the kernel; the package's other
+        # controllers (AvoidJointLimits, AvoidObstacles, Floating) are summed on the device by their own
+        # kernels and enter the null-space filter as u_null_ext; any other object with generate(q, dq)
+        # is evaluated by the caller's code per state and only projected
+        self._fused, self._device, self._foreign = [], [], []
         for nc in null_controllers or []:
             if not self._fused_config:
                 self._foreign.append(nc)  # evaluated with the foreign config's own M(q)
@@ -63,6 +65,8 @@ class OSC(Controller):
                 self._fused.append(_abi.make_damping(nc.kv))
             elif type(nc) is RestingConfig:
                 self._fused.append(_abi.make_resting(nc.rest_angles_list, nc.kp, nc.kv))
+            elif hasattr(nc, "_accumulate") and getattr(nc, "robot_config", None) is robot_config:
+                self._device.append(nc)
             else:
                 self._foreign.append(nc)
 
@@ -109,6 +113,12 @@ class OSC(Controller):
             for nc in self._foreign:
                 for b in range(B):
                     une[b] += nc.generate(q2[b], dq2[b])
+        if self._device:
+            if une is None:
+                une = (DeviceArray((B, rc.N_JOINTS), rc.dtype, rc.device).zero_() if on_device
+                       else np.zeros((B, rc.N_JOINTS), rc.dtype))
+            for nc in self._device:
+                nc._accumulate(q2, dq2, une)
         u, ts = engine.osc_generate(rc.arm_id, rc.N_JOINTS, params, q2, dq2, t2, tv2, ie, une,
                                     training_signal=True, dtype=rc.dtype, device=rc.device)
         if on_device:

@@ -55,6 +55,19 @@ struct JointP {
   int account_for_gravity;
 };
 
+template <class T>
+struct LimitsP {  // AvoidJointLimits, as its constructor stores them (avoid_joint_limits.py:45-81)
+  T mn[7], mx[7], mt[7];
+  int cz[7], gr[7], nomin[7], nomax[7];
+};
+
+template <class T>
+struct ObsP {  // AvoidObstacles (avoid_obstacles.py:26-36)
+  int n;
+  T threshold, gain, maximum;
+  T obs[16][4];
+};
+
 // ---------------------------------------------------------------- small dense algebra
 template <class T>
 ABRK_INL T rcp(T x) {
@@ -840,6 +853,239 @@ ABRK_INL void ik_row(const A& arm, const IkP<T>& P, T (&q)[A::N], const T (&tgt)
       q[i()] += dq[i()];
     });
   }
+}
+
+// ---------------------------------------------------------------- the other secondary controllers
+// Task-space inertia of a point: Mx = inv or pinv(rcond) of Jv M^-1 Jv^T (3x3), from the Cholesky factor
+// of M.  GATED: inv when |det| > det_thr (floating.py:50-56), else pinv; !GATED: always pinv
+// (avoid_obstacles.py:112).  pinv == inv unless a singular value is below rcond * max, and
+// det > rcond * trace^3 proves none is - the eigen-decomposition runs only for the rest.
+// `floor`: a trace of Mx_inv at or below it is rounding noise of a point sitting on the joint axes it
+// depends on (the reference then inverts noise, pinv being relative to the largest singular value, and
+// returns +-maximum at random); such a point is treated as having no mobility: Mx = 0.
+template <int N, class T, bool GATED>
+ABRK_INL void point_inertia(const T (&L)[N * (N + 1) / 2], const T (&il)[N], const T (&Jv)[N][3], T det_thr,
+                            T rcond, T floor, T (&Mx)[6]) {
+  T Y[N][3];
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    T b[N], x[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { b[i()] = Jv[i()][r()]; });
+    chol_fwd<N>(L, il, b, x);
+    sfor<N>([&](auto i) ABRK_LAMBDA { Y[i()][r()] = x[i()]; });
+  });
+  T Am[6], trace = T(0);
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    sfor<r() + 1>([&](auto c) ABRK_LAMBDA {
+      T acc = T(-0.0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { acc += Y[i()][r()] * Y[i()][c()]; });
+      Am[tri(r(), c())] = acc;
+    });
+    trace += Am[tri(r(), r())];
+  });
+  T LA[6], ila[3];
+  bool okA = chol<3>(Am, LA, ila);
+  T det = T(1);
+  sfor<3>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
+  if (!GATED && !(trace > floor)) {
+    sfor<6>([&](auto e) ABRK_LAMBDA { Mx[e()] = T(0); });
+    return;
+  }
+  bool direct = okA && (GATED ? det > det_thr : false);
+  if (!direct) direct = okA && det > rcond * trace * trace * trace;
+  if (direct) {
+    chol_inverse<3>(LA, ila, Mx);
+  } else {
+    T S[6], V[3][3], lam[3];
+    sfor<6>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
+    jacobi_eig<3>(S, V, lam);
+    T smax = T(0);
+    sfor<3>([&](auto r) ABRK_LAMBDA { smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()])); });
+    T cut = rcond * smax, wv[3];
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      bool keep = Rm<T>::fabs(lam[r()]) > cut;
+      wv[r()] = keep ? rcp(keep ? lam[r()] : T(1)) : T(0);
+    });
+    sfor<3>([&](auto a) ABRK_LAMBDA {
+      sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
+        T acc = T(-0.0);
+        sfor<3>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
+        Mx[tri(a(), b())] = acc;
+      });
+    });
+  }
+}
+
+// AvoidJointLimits.generate (avoid_joint_limits.py:83-142), one row; q only
+template <int N, class T>
+ABRK_INL void limits_row(const LimitsP<T>& P, const T (&qin)[N], T (&u)[N]) {
+  const T pi = T(3.141592653589793238462643383279502884);
+  sfor<N>([&](auto ii) ABRK_LAMBDA {
+    constexpr int i = ii();
+    const T q = qin[i] - pi;  // :91
+    const T mn = P.mn[i], mx = P.mx[i], mt = P.mt[i];
+    const bool hmin = !P.nomin[i], hmax = !P.nomax[i];  // NaN limits compare false everywhere (:74-75)
+    const T dmn = q - mn, dmx = q - mx;
+    const bool both = hmin && hmax;
+    const bool closer_to_min = both && Rm<T>::fabs(dmn) >= Rm<T>::fabs(dmx);  // :94-99
+    const bool closer_to_max = both && Rm<T>::fabs(dmn) <= Rm<T>::fabs(dmx);
+    T amin = T(0), amax = T(0);
+    if (P.gr[i]) {  // :108-115.  1/0 -> +-inf in the reference: exp(+inf) is capped by max_torque, exp(-inf) = 0
+      if (hmin) amin = dmn == T(0) ? mt : Rm<T>::fmin(Rm<T>::exp(T(1) / dmn), mt);
+      if (hmax) amax = dmx == T(0) ? -mt : -Rm<T>::fmin(Rm<T>::exp(T(-1) / dmx), mt);
+    }
+    bool min_index = hmin && dmn < T(0), max_index = hmax && dmx > T(0);  // :118-119
+    if (P.cz[i]) {  // :124-134
+      const bool mi = min_index && (hmax && dmx > T(0)) && closer_to_max;
+      const bool xi = max_index && (hmin && dmn < T(0)) && closer_to_min;
+      min_index = mi;
+      max_index = xi;
+    }
+    if (min_index) amin = mt;  // :136-140
+    if (max_index) amax = -mt;
+    u[i] = amin + amax;
+  });
+}
+
+// Floating.generate (floating.py:27-71), one row
+template <class A, class T>
+ABRK_INL void floating_row(const A& arm, int dynamic, int task_space, const T (&q)[A::N], const T (&dq)[A::N],
+                           T (&u)[A::N]) {
+  constexpr int N = A::N;
+  Joints<A, T> jt;
+  Dyn<A, T, CMODE_NONE> d;
+  T XR[9], xo[3];
+  NoCap nc;
+  T zero[N];
+  sfor<N>([&](auto i) ABRK_LAMBDA { zero[i()] = T(0); });
+  kin_dyn(arm, q, zero, jt, d, XR, xo, nc);
+  if (task_space) {
+    // u = J^T (-(M^-1 J^T Mx)^T g) = -J^T Mx J M^-1 g  (floating.py:42-61), g = -9.81 gz
+    T p[3], Jv[N][3], Jw[N][3], L[N * (N + 1) / 2], il[N], Mx[6];
+    mulBE_pt<A, T>(arm, XR, xo, p);
+    jacobian(jt, p, N, Jv, Jw);
+    chol<N>(d.Ms, L, il);
+    point_inertia<N, T, true>(L, il, Jv, T(1e-3), T(1e-4), T(0), Mx);
+    T gq[N], y[N], w[N], jw[3], f[3];
+    sfor<N>([&](auto i) ABRK_LAMBDA { gq[i()] = T(-9.81) * d.gz[i()]; });
+    chol_fwd<N>(L, il, gq, y);
+    chol_bwd<N>(L, il, y, w);
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      T acc = T(-0.0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { acc += Jv[i()][r()] * w[i()]; });
+      jw[r()] = acc;
+    });
+    symv<3>(Mx, jw, f);
+    sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = -(Jv[i()][0] * f[0] + Jv[i()][1] * f[1] + Jv[i()][2] * f[2]); });
+  } else {
+    sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(9.81) * d.gz[i()]; });  // u = -g (floating.py:64)
+  }
+  if (dynamic) {  // floating.py:66-69
+    T Mdq[N];
+    symv<N>(d.Ms, dq, Mdq);
+    sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= Mdq[i()]; });
+  }
+}
+
+// AvoidObstacles.generate (avoid_obstacles.py:38-120), one row.  Segment ii runs from the origin of
+// joint_ii to that of joint_ii+1 (the EE for the last one, :64-68); its closest point to the obstacle is a
+// point of link ii+1, so its Jacobian columns are W_i (closest - o_i), i <= ii  (the reference gets the
+// same through T_inv("link{ii+1}") and J("link{ii+1}", x=m), :107-110).
+template <class A, class T>
+ABRK_INL void obstacles_row(const A& arm, const ObsP<T>& P, const T (&q)[A::N], T (&u)[A::N]) {
+  constexpr int N = A::N;
+  Joints<A, T> jt;
+  Dyn<A, T, CMODE_NONE> d;
+  T XR[9], xo[3], pe[3];
+  NoCap nc;
+  T zero[N];
+  sfor<N>([&](auto i) ABRK_LAMBDA { zero[i()] = T(0); });
+  // General (non-orthogonal) chains: the reference's T_inv is [R^T | -R^T t] (base_config.py:791-837), not
+  // the inverse, so the point it differentiates is o_l + R_l R_l^T (closest - o_l) in link l's frame - up to
+  // 4e-4 away from `closest` on Jaco2, whose rotation constants are rounded.  Keep G_l = R_l R_l^T, o_l.
+  constexpr int NG = A::kOrtho ? 1 : N;
+  T G[NG][6], ol[NG][3];
+  kin_dyn_hook(arm, q, zero, jt, d, XR, xo, nc, [&](auto Lc, const T(&pl)[3]) ABRK_LAMBDA {
+    if constexpr (!A::kOrtho) {
+      constexpr int l = Lc() - 1;
+      T RL[9];
+      mulB_rot<A, T, l>(arm, XR, RL);
+      sfor<3>([&](auto a) ABRK_LAMBDA {
+        sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
+          G[l][tri(a(), b())] = RL[a() * 3] * RL[b() * 3] + RL[a() * 3 + 1] * RL[b() * 3 + 1] +
+                                RL[a() * 3 + 2] * RL[b() * 3 + 2];
+        });
+        ol[l][a()] = pl[a()];
+      });
+    }
+  });
+  mulBE_pt<A, T>(arm, XR, xo, pe);
+  T L[N * (N + 1) / 2], il[N];
+  chol<N>(d.Ms, L, il);
+  sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(0); });
+  const T lo = P.threshold / T(50), ithr = T(1) / P.threshold;
+  // Mx_inv of a point at distance d from the axes it hangs on is ~ d^2 |M^-1|; below (1e-12 segment
+  // lengths)^2 (fp32: 1e-5) it is rounding noise (see point_inertia)
+  T noise = T(0);
+  sfor<N>([&](auto i) ABRK_LAMBDA { noise += il[i()] * il[i()]; });
+  noise *= sizeof(T) == 8 ? T(1e-24) : T(1e-10);
+  for (int ob = 0; ob < P.n; ob++) {
+    const T v[3] = {P.obs[ob][0], P.obs[ob][1], P.obs[ob][2]};
+    const T radius = P.obs[ob][3];
+    sfor<N>([&](auto iic) ABRK_LAMBDA {
+      constexpr int ii = iic();
+      T p1[3], p2[3], vl[3], vo[3];
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        p1[r()] = jt.o[ii][r()];
+        if constexpr (ii == N - 1) p2[r()] = pe[r()];
+        else p2[r()] = jt.o[ii + 1 < N ? ii + 1 : ii][r()];
+        vl[r()] = p2[r()] - p1[r()];
+        vo[r()] = v[r()] - p1[r()];
+      });
+      const T len2 = dot3(vl, vl);
+      // a zero-length segment is 0/0 in the reference: every later comparison is false, no contribution
+      if (len2 > T(0)) {
+        T pr = dot3(vo, vl) / len2;  // :76
+        pr = pr < T(0) ? T(0) : (pr > T(1) ? T(1) : pr);  // :77-84 (closest = p1, p2 or in between)
+        T cl[3], dv[3];
+        sfor<3>([&](auto r) ABRK_LAMBDA {
+          cl[r()] = pr == T(1) ? p2[r()] : p1[r()] + pr * vl[r()];
+          dv[r()] = v[r()] - cl[r()];
+        });
+        const T dist = Rm<T>::sqrt(dot3(dv, dv));
+        const T rho = Rm<T>::fmax(dist - radius, lo);  // :90
+        if (rho < P.threshold) {
+          // Fpsp = eta (1/rho - 1/threshold) / rho^1.5 * (v - closest)/rho   (:94-102)
+          const T irho = T(1) / rho;
+          const T k = T(0.02) * (irho - ithr) * irho * irho / Rm<T>::sqrt(rho);
+          T F[3] = {k * dv[0], k * dv[1], k * dv[2]};
+          T Jp[N][3];
+          if constexpr (!A::kOrtho) {
+            T e[3] = {cl[0] - ol[ii][0], cl[1] - ol[ii][1], cl[2] - ol[ii][2]}, ge[3];
+            symv<3>(G[ii], e, ge);
+            sfor<3>([&](auto r) ABRK_LAMBDA { cl[r()] = ol[ii][r()] + ge[r()]; });
+          }
+          sfor<N>([&](auto i) ABRK_LAMBDA {
+            if constexpr (i() <= ii) {
+              T dl[3] = {cl[0] - jt.o[i()][0], cl[1] - jt.o[i()][1], cl[2] - jt.o[i()][2]};
+              wapply<i()>(jt, dl, Jp[i()]);
+            } else {
+              Jp[i()][0] = Jp[i()][1] = Jp[i()][2] = T(0);
+            }
+          });
+          T Mx[6], f[3];
+          point_inertia<N, T, false>(L, il, Jp, T(0), T(0.01), noise * len2, Mx);  // :114-117
+          symv<3>(Mx, F, f);
+          sfor<N>([&](auto i) ABRK_LAMBDA {
+            if constexpr (i() <= ii) u[i()] -= Jp[i()][0] * f[0] + Jp[i()][1] * f[1] + Jp[i()][2] * f[2];  // :119
+          });
+        }
+      }
+    });
+  }
+  sfor<N>([&](auto i) ABRK_LAMBDA {  // np.clip (:121)
+    T x = u[i()] * P.gain;
+    u[i()] = x < -P.maximum ? -P.maximum : (x > P.maximum ? P.maximum : x);
+  });
 }
 
 // ---------------------------------------------------------------- Joint / Damping / RestingConfig, one row

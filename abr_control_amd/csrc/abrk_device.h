@@ -111,6 +111,8 @@ struct Rm<double> {
   static ABRK_INL double fma(double a, double b, double c) { return ::fma(a, b, c); }
   static ABRK_INL double fmod(double a, double b) { return ::fmod(a, b); }
   static ABRK_INL double fmax(double a, double b) { return ::fmax(a, b); }
+  static ABRK_INL double fmin(double a, double b) { return ::fmin(a, b); }
+  static ABRK_INL double exp(double x) { return ::exp(x); }
   // 1/x and 1/sqrt(x) from the hardware seed (v_rcp_f64 / v_rsq_f64, ~2^-23 relative) plus two
   // Newton steps -> ~1-2 ulp in 5 / 9 instructions instead of the 11 + 12 of an IEEE divide and
   // sqrt.  x must be a normal positive number (pivots of SPD factorizations here).
@@ -145,6 +147,8 @@ struct Rm<float> {
   static ABRK_INL float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
   static ABRK_INL float fmod(float a, float b) { return ::fmodf(a, b); }
   static ABRK_INL float fmax(float a, float b) { return ::fmaxf(a, b); }
+  static ABRK_INL float fmin(float a, float b) { return ::fminf(a, b); }
+  static ABRK_INL float exp(float x) { return ::expf(x); }
   static ABRK_INL float rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     float y = __builtin_amdgcn_rcpf(x);
@@ -742,17 +746,25 @@ ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, 
 }
 
 // FK + M, g (+C).  Returns joint state for Jacobians; (XR, xo) = last rotated joint frame.
-template <class A, class T, int CM, class Cap>
-ABRK_INL void kin_dyn(const A& arm, const T (&q)[A::N], const T (&dq)[A::N], Joints<A, T>& jt, Dyn<A, T, CM>& d,
-                      T (&XR)[9], T (&xo)[3], Cap& cap) {
+// `extra(ic<l>, p)` runs once per link l = 1..N (p = origin of its frame) while XR still holds the
+// rotation of joint_{l-1} after its Rz - callers that need per-link frames hook in here.
+template <class A, class T, int CM, class Cap, class Extra>
+ABRK_INL void kin_dyn_hook(const A& arm, const T (&q)[A::N], const T (&dq)[A::N], Joints<A, T>& jt,
+                           Dyn<A, T, CM>& d, T (&XR)[9], T (&xo)[3], Cap& cap, Extra&& extra) {
   dyn_init(d);
   fk_forward(arm, q, jt, XR, xo, cap, [&](auto L, const T(&p)[3]) ABRK_LAMBDA {
     omega_advance<L()>(jt, dq, d);
     body_advance<L()>(jt, dq, d);
     link_accumulate<L()>(arm, jt, dq, p, d);
     angular_link_coriolis<L()>(arm, jt, d);
+    extra(L, p);
   });
   angular_finish(arm, jt, dq, d);
+}
+template <class A, class T, int CM, class Cap>
+ABRK_INL void kin_dyn(const A& arm, const T (&q)[A::N], const T (&dq)[A::N], Joints<A, T>& jt, Dyn<A, T, CM>& d,
+                      T (&XR)[9], T (&xo)[3], Cap& cap) {
+  kin_dyn_hook(arm, q, dq, jt, d, XR, xo, cap, [](auto, const T(&)[3]) ABRK_LAMBDA {});
 }
 
 // Jacobian of point p attached after joints 0..m-1 (m runtime, uniform):

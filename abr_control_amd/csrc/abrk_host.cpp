@@ -570,6 +570,104 @@ extern "C" int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_
   return st.finish();
 }
 
+// ------------------------------------------------------------------------------- AvoidJointLimits / Floating / AvoidObstacles
+extern "C" int abrk_avoid_joint_limits_generate_batch(int n_joints, int dtype, const abrk_limits_params* params,
+                                                      int64_t B, const void* q, void* u, int accumulate, int device,
+                                                      void* stream) {
+  if (n_joints < 1 || n_joints > ABRK_MAX_JOINTS) return fail(ABRK_EINVAL, "n_joints=%d outside 1..7", n_joints);
+  if (dtype != ABRK_F64 && dtype != ABRK_F32) return fail(ABRK_EINVAL, "unknown dtype %d", dtype);
+  if (B < 0) return fail(ABRK_EINVAL, "negative batch size");
+  if (!params) return fail(ABRK_EINVAL, "params is NULL");
+  if (!q || !u) return fail(ABRK_EINVAL, "q and u are required");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const int n = n_joints;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* q_ = st.add(q, B * n * s, true, false);
+  void* u_ = st.add(u, B * n * s, accumulate != 0, true);
+  if (int rc = st.reserve()) return rc;
+  LimitsP<double> p64;
+  LimitsP<float> p32;
+  const void* P;
+  if (dtype == ABRK_F64) {
+    p64 = make_limitsp<double>(*params);
+    P = &p64;
+  } else {
+    p32 = make_limitsp<float>(*params);
+    P = &p32;
+  }
+  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
+  HIPCHK(launch_limits(n, dtype, la, P, st.fix(q_, q), st.fix(u_, u), accumulate != 0));
+  return st.finish();
+}
+
+extern "C" int abrk_floating_generate_batch(int arm_id, int dtype, int dynamic, int task_space, int64_t B,
+                                            const void* q, const void* dq, void* u, int accumulate, int device,
+                                            void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!q || !u) return fail(ABRK_EINVAL, "q and u are required");
+  if (dynamic && !dq) return fail(ABRK_EINVAL, "Floating(dynamic=True) needs dq");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* q_ = st.add(q, B * n * s, true, false);
+  const void* dq_ = dynamic ? st.add(dq, B * n * s, true, false) : nullptr;
+  void* u_ = st.add(u, B * n * s, accumulate != 0, true);
+  if (int rc = st.reserve()) return rc;
+  FloatingArgs fa;
+  fa.dynamic = dynamic != 0;
+  fa.task_space = task_space != 0;
+  fa.acc = accumulate != 0;
+  fa.q = st.fix(q_, q);
+  fa.dq = dynamic ? st.fix(dq_, dq) : nullptr;
+  fa.u = st.fix(u_, u);
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->floating(dtype, la, fa));
+  return st.finish();
+}
+
+extern "C" int abrk_avoid_obstacles_generate_batch(int arm_id, int dtype, const abrk_obstacles_params* params,
+                                                   int64_t B, const void* q, void* u, int accumulate, int device,
+                                                   void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!params) return fail(ABRK_EINVAL, "params is NULL");
+  if (params->n_obstacles < 0 || params->n_obstacles > ABRK_MAX_OBSTACLES)
+    return fail(ABRK_EINVAL, "n_obstacles=%d outside 0..%d", params->n_obstacles, ABRK_MAX_OBSTACLES);
+  if (!(params->threshold > 0)) return fail(ABRK_EINVAL, "threshold must be positive");
+  if (!q || !u) return fail(ABRK_EINVAL, "q and u are required");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* q_ = st.add(q, B * n * s, true, false);
+  void* u_ = st.add(u, B * n * s, accumulate != 0, true);
+  if (int rc = st.reserve()) return rc;
+  ObstaclesArgs oa;
+  ObsP<double> p64;
+  ObsP<float> p32;
+  if (dtype == ABRK_F64) {
+    p64 = make_obsp<double>(*params);
+    oa.P = &p64;
+  } else {
+    p32 = make_obsp<float>(*params);
+    oa.P = &p32;
+  }
+  oa.acc = accumulate != 0;
+  oa.q = st.fix(q_, q);
+  oa.u = st.fix(u_, u);
+  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
+                (long)B, (hipStream_t)stream};
+  HIPCHK(a->ops->obstacles(dtype, la, oa));
+  return st.finish();
+}
+
 // ------------------------------------------------------------------------------- OSC law on supplied dynamics
 extern "C" int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params* P, int64_t B, const void* J,
                                   const void* M, const void* g, const void* Cdq, const void* xyz, const void* R,

@@ -142,6 +142,43 @@ ik_kernel(A arm, IkP<T> P, long B, const T* __restrict__ qg, const T* __restrict
   ik_body<A, T>(b, arm, P, B, qg, tg, pp, vp);
 }
 
+template <int N, class T>
+__global__ void __launch_bounds__(kBlock)
+limits_kernel(LimitsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
+  ABRK_ROW_INDEX
+  limits_body<N, T>(b, P, qg, ug, acc);
+}
+
+template <class A, class T>
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+floating_kernel(A arm, int dynamic, int task_space, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+                T* __restrict__ ug, int acc) {
+  ABRK_ROW_INDEX
+  floating_body<A, T>(b, arm, dynamic, task_space, qg, dqg, ug, acc);
+}
+
+template <class A, class T>
+__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+obstacles_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
+  ABRK_ROW_INDEX
+  obstacles_body<A, T>(b, arm, P, qg, ug, acc);
+}
+
+struct FloatingArgs {
+  int dynamic, task_space, acc;
+  const void *q, *dq;
+  void* u;
+};
+struct ObstaclesArgs {
+  const void* P;  // ObsP<T>
+  int acc;
+  const void* q;
+  void* u;
+};
+// AvoidJointLimits needs no arm, only the joint count (abrk_law.hip)
+hipError_t launch_limits(int n_joints, int dtype, const LaunchArgs& la, const void* P, const void* q, void* u,
+                         int acc);
+
 struct IkArgs {
   const void* P;  // IkP<T>
   const void *q, *target;
@@ -194,6 +231,8 @@ struct ArmOps {
   hipError_t (*joint)(int dtype, const LaunchArgs&, const JointArgs&);
   hipError_t (*rollout)(int dtype, const LaunchArgs&, const RolloutArgs&);  // two-joint arms only, else null
   hipError_t (*ik)(int dtype, const LaunchArgs&, const IkArgs&);
+  hipError_t (*floating)(int dtype, const LaunchArgs&, const FloatingArgs&);
+  hipError_t (*obstacles)(int dtype, const LaunchArgs&, const ObstaclesArgs&);
 };
 hipError_t launch_twolink_step(int dtype, const LaunchArgs& la, const void* K, void* q, void* dq, const void* u);
 
@@ -300,8 +339,27 @@ struct OpsFor {
   static hipError_t ik(int dt, const LaunchArgs& la, const IkArgs& a) {
     return dt == 0 ? ik_t<AD, double>(la, a) : ik_t<AF, float>(la, a);
   }
+  template <class A, class T>
+  static hipError_t floating_t(const LaunchArgs& la, const FloatingArgs& a) {
+    hipLaunchKernelGGL((floating_kernel<A, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la),
+                       a.dynamic, a.task_space, la.B, (const T*)a.q, (const T*)a.dq, (T*)a.u, a.acc);
+    return hipGetLastError();
+  }
+  static hipError_t floating(int dt, const LaunchArgs& la, const FloatingArgs& a) {
+    return dt == 0 ? floating_t<AD, double>(la, a) : floating_t<AF, float>(la, a);
+  }
+  template <class A, class T>
+  static hipError_t obstacles_t(const LaunchArgs& la, const ObstaclesArgs& a) {
+    hipLaunchKernelGGL((obstacles_kernel<A, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la),
+                       *static_cast<const ObsP<T>*>(a.P), la.B, (const T*)a.q, (T*)a.u, a.acc);
+    return hipGetLastError();
+  }
+  static hipError_t obstacles(int dt, const LaunchArgs& la, const ObstaclesArgs& a) {
+    return dt == 0 ? obstacles_t<AD, double>(la, a) : obstacles_t<AF, float>(la, a);
+  }
   static const ArmOps* ops() {
-    static const ArmOps o = {AD::N, &dyn, &osc, &sliding, &joint, AD::N == 2 ? &rollout : nullptr, &ik};
+    static const ArmOps o = {AD::N, &dyn, &osc, &sliding, &joint, AD::N == 2 ? &rollout : nullptr, &ik,
+                             &floating, &obstacles};
     return &o;
   }
 };

@@ -19,6 +19,22 @@ hipError_t launch_osc_law(int n, int dtype, const LaunchArgs& la, const LawArgs&
 #undef ABRK_CASE
   return hipErrorInvalidValue;
 }
+template <int N, class T>
+static hipError_t limits_launch(const LaunchArgs& la, const void* P, const void* q, void* u, int acc) {
+  hipLaunchKernelGGL((limits_kernel<N, T>), grid_for(la.B), dim3(kBlock), 0, la.stream,
+                     *static_cast<const LimitsP<T>*>(P), la.B, (const T*)q, (T*)u, acc);
+  return hipGetLastError();
+}
+hipError_t launch_limits(int n, int dtype, const LaunchArgs& la, const void* P, const void* q, void* u, int acc) {
+#define ABRK_CASE(NN) \
+  case NN:            \
+    return dtype == 0 ? limits_launch<NN, double>(la, P, q, u, acc) : limits_launch<NN, float>(la, P, q, u, acc);
+  switch (n) {
+    ABRK_CASE(1) ABRK_CASE(2) ABRK_CASE(3) ABRK_CASE(4) ABRK_CASE(5) ABRK_CASE(6) ABRK_CASE(7)
+  }
+#undef ABRK_CASE
+  return hipErrorInvalidValue;
+}
 hipError_t launch_twolink_step(int dtype, const LaunchArgs& la, const void* K, void* q, void* dq, const void* u) {
   if (dtype == 0)
     hipLaunchKernelGGL((twolink_step_kernel<double>), grid_for(la.B), dim3(kBlock), 0, la.stream,

@@ -73,6 +73,35 @@ inline JointP<T> make_jointp(const abrk_null_ctrl& c, int account_for_gravity) {
   return p;
 }
 
+template <class T>
+inline LimitsP<T> make_limitsp(const abrk_limits_params& s) {
+  LimitsP<T> p;
+  memset(&p, 0, sizeof p);
+  for (int i = 0; i < 7; i++) {
+    p.mn[i] = T(s.min_joint_angles[i]);
+    p.mx[i] = T(s.max_joint_angles[i]);
+    p.mt[i] = T(s.max_torque[i]);
+    p.cz[i] = s.cross_zero[i] ? 1 : 0;
+    p.gr[i] = s.gradient[i] ? 1 : 0;
+    p.nomin[i] = s.no_limits_min[i] ? 1 : 0;
+    p.nomax[i] = s.no_limits_max[i] ? 1 : 0;
+  }
+  return p;
+}
+
+template <class T>
+inline ObsP<T> make_obsp(const abrk_obstacles_params& s) {
+  ObsP<T> p;
+  memset(&p, 0, sizeof p);
+  p.n = s.n_obstacles;
+  p.threshold = T(s.threshold);
+  p.gain = T(s.gain);
+  p.maximum = T(s.maximum);
+  for (int i = 0; i < s.n_obstacles && i < 16; i++)
+    for (int r = 0; r < 4; r++) p.obs[i][r] = T(s.obstacles[i][r]);
+  return p;
+}
+
 // the FAST OSC kernel applies when the task rows are exactly x,y,z of the end-effector
 inline bool osc_is_fast(const abrk_osc_params& P, int n, bool has_ext) {
   int k = 0;

@@ -249,6 +249,49 @@ ABRK_INL void joint_body(long b, const A& arm, const JointP<T>& P, long B, const
   store_row<N>(ug, b, u);
 }
 
+// ---- AvoidJointLimits / Floating / AvoidObstacles for B states; acc: u += instead of u =
+template <int N, class T>
+ABRK_INL void put_row(T* __restrict__ ug, long b, const T (&u)[N], int acc) {
+  if (acc) {
+    T old[N];
+    load_row<N>(ug, b, old);
+    sfor<N>([&](auto i) ABRK_LAMBDA { old[i()] += u[i()]; });
+    store_row<N>(ug, b, old);
+  } else {
+    store_row<N>(ug, b, u);
+  }
+}
+
+template <int N, class T>
+ABRK_INL void limits_body(long b, const LimitsP<T>& P, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
+  T q[N], u[N];
+  load_row<N>(qg, b, q);
+  limits_row<N, T>(P, q, u);
+  put_row<N>(ug, b, u, acc);
+}
+
+template <class A, class T>
+ABRK_INL void floating_body(long b, const A& arm, int dynamic, int task_space, const T* __restrict__ qg,
+                            const T* __restrict__ dqg, T* __restrict__ ug, int acc) {
+  constexpr int N = A::N;
+  T q[N], dq[N], u[N];
+  load_row<N>(qg, b, q);
+  if (dynamic) load_row<N>(dqg, b, dq);
+  else sfor<N>([&](auto i) ABRK_LAMBDA { dq[i()] = T(0); });
+  floating_row<A, T>(arm, dynamic, task_space, q, dq, u);
+  put_row<N>(ug, b, u, acc);
+}
+
+template <class A, class T>
+ABRK_INL void obstacles_body(long b, const A& arm, const ObsP<T>& P, const T* __restrict__ qg, T* __restrict__ ug,
+                             int acc) {
+  constexpr int N = A::N;
+  T q[N], u[N];
+  load_row<N>(qg, b, q);
+  obstacles_row<A, T>(arm, P, q, u);
+  put_row<N>(ug, b, u, acc);
+}
+
 // ---- closed loop: n_steps x { OSC.generate ; ArmSim._step } with the state kept in registers
 // (examples/PyGame/force_osc_xy.py:57-78).  Two-joint arms only.
 template <class A, class T, bool USE_C>

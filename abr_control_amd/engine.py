@@ -211,6 +211,42 @@ def joint_generate(arm_id, n, ctrl, account_for_gravity, q, dq, target=None, tar
     return uo
 
 
+def avoid_joint_limits_generate(n, params, q, u=None, accumulate=False, dtype=np.float64, device=0, stream=None):
+    """AvoidJointLimits.generate for B states; accumulate: u += signal (u must then be given)."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp = a.inp(q, (B, n), "q")
+    up, uo = a.out(u, (B, n), device, "u")
+    check(lib().abrk_avoid_joint_limits_generate_batch(n, a.code, C.byref(params), B, qp, up,
+                                                       int(bool(accumulate and u is not None)), device, _sp(stream)))
+    return uo
+
+
+def floating_generate(arm_id, n, dynamic, task_space, q, dq=None, u=None, accumulate=False, dtype=np.float64,
+                      device=0, stream=None):
+    """Floating.generate for B states."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq") if dynamic else None
+    up, uo = a.out(u, (B, n), device, "u")
+    check(lib().abrk_floating_generate_batch(arm_id, a.code, int(bool(dynamic)), int(bool(task_space)), B, qp, dqp,
+                                             up, int(bool(accumulate and u is not None)), device, _sp(stream)))
+    return uo
+
+
+def avoid_obstacles_generate(arm_id, n, params, q, u=None, accumulate=False, dtype=np.float64, device=0,
+                             stream=None):
+    """AvoidObstacles.generate for B states (obstacles shared by all rows)."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp = a.inp(q, (B, n), "q")
+    up, uo = a.out(u, (B, n), device, "u")
+    check(lib().abrk_avoid_obstacles_generate_batch(arm_id, a.code, C.byref(params), B, qp, up,
+                                                    int(bool(accumulate and u is not None)), device, _sp(stream)))
+    return uo
+
+
 def _inout(a, arr, shape, name):
     """in/out state array: DeviceArray, or a C-contiguous ndarray of the call dtype updated in place"""
     if isinstance(arr, DeviceArray):

@@ -47,6 +47,11 @@ WORKLOADS = {
     "rollout": ("twojoint", 4096, "f64", "rollout", dict(kp=20, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 0]), 600),
     # InverseKinematics.generate_path, 200 iterations per path inside one launch (method 3)
     "ik": ("ur5", 4096, "f64", "ik", dict(method=3, n_timesteps=200), 2500),
+    # the remaining secondary controllers as their own kernels (u [B,n] each)
+    "limits": ("ur5", 4096, "f64", "limits", dict(), 60),
+    "floating": ("ur5", 4096, "f64", "floating", dict(dynamic=True, task_space=True), 3300),
+    "obstacles": ("ur5", 4096, "f64", "obstacles", dict(threshold=0.3, gain=30, obstacles=[
+        [0.3, 0.2, 0.4, 0.1], [-0.2, 0.4, 0.3, 0.05], [0.1, -0.3, 0.6, 0.15]]), 6000),
 }
 ROLLOUT_STEPS = 1000
 
@@ -60,6 +65,10 @@ def algorithmic_bytes(n, esz, kind):
         return esz * (n + 6) + esz * 2 * 200 * n
     if kind == "rollout":  # per launch and row: q, dq in/out + target; amortised over ROLLOUT_STEPS
         return esz * (4 * n + 6)
+    if kind in ("limits", "obstacles"):  # q in, u out
+        return esz * 2 * n
+    if kind == "floating":  # q, dq in, u out
+        return esz * 3 * n
     nt = 3 if kind == "sliding" else 6
     return esz * (2 * n + nt) + esz * n
 
@@ -119,6 +128,15 @@ class Runner:
             self.dyn_out = {w: a.DeviceArray((B,) + shapes[w], self.dt, device) for w in self.want}
         elif kind == "sliding":
             self.params = _abi.make_sliding_params(self.n)
+        elif kind == "limits":
+            self.params = _abi.make_limits_params(
+                self.n, [np.pi / 5, 1.0, 5.5, None, 0.4, 2.0], [np.pi / 2, 4.0, 0.8, None, None, 2.5],
+                [100.0, 7.5, 3.0, 1.0, 4.0, 2.0], [False, False, True, False, False, False],
+                [False, True, False, False, False, True])
+        elif kind == "floating":
+            self.params = kw
+        elif kind == "obstacles":
+            self.params = _abi.make_obstacles_params(**kw)
         else:
             nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
             self.params = _abi.make_osc_params(self.n, null_controllers=nulls, **kw)
@@ -147,6 +165,16 @@ class Runner:
         elif self.kind == "sliding":
             self.engine.sliding_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
                                          dtype=self.dt, device=self.device, stream=self.stream)
+        elif self.kind == "limits":
+            self.engine.avoid_joint_limits_generate(self.n, self.params, self.q, u=self.u, dtype=self.dt,
+                                                    device=self.device, stream=self.stream)
+        elif self.kind == "floating":
+            self.engine.floating_generate(self.arm_id, self.n, self.params["dynamic"], self.params["task_space"],
+                                          self.q, self.dq, u=self.u, dtype=self.dt, device=self.device,
+                                          stream=self.stream)
+        elif self.kind == "obstacles":
+            self.engine.avoid_obstacles_generate(self.arm_id, self.n, self.params, self.q, u=self.u, dtype=self.dt,
+                                                 device=self.device, stream=self.stream)
         else:
             self.engine.osc_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
                                      dtype=self.dt, device=self.device, stream=self.stream)
@@ -194,7 +222,8 @@ def roofline(runner, ms_per_launch, label):
     evals_s = runner.evals_per_launch / (ms_per_launch * 1e-3)
     gbs = runner.B / (ms_per_launch * 1e-3) * runner.bytes_per_eval / 1e9
     tf = evals_s * runner.flops / 1e12
-    kname = {"sliding": "sliding_kernel", "dyn": "dyn_kernel"}.get(runner.kind, "osc_kernel")
+    kname = {"sliding": "sliding_kernel", "dyn": "dyn_kernel", "limits": "limits_kernel", "floating": "floating_kernel",
+             "obstacles": "obstacles_kernel", "ik": "ik_kernel", "rollout": "rollout_kernel"}.get(runner.kind, "osc_kernel")
     return {
         "kernel": kname,
         "workload": label, "batch": runner.B, "bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS,
@@ -264,6 +293,18 @@ def cpu_baseline(workload, budget_s=12.0):
     elif kind == "sliding":
         p = _abi.make_sliding_params(o.n)
         fn = lambda: o.sliding_batch(p, q, dq, t)
+    elif kind == "limits":
+        from oracle.oracle import avoid_joint_limits_batch
+
+        p = _abi.make_limits_params(o.n, [np.pi / 5, 1.0, 5.5, None, 0.4, 2.0], [np.pi / 2, 4.0, 0.8, None, None, 2.5],
+                                    [100.0, 7.5, 3.0, 1.0, 4.0, 2.0], [False, False, True, False, False, False],
+                                    [False, True, False, False, False, True])
+        fn = lambda: avoid_joint_limits_batch(o.n, p, q)
+    elif kind == "floating":
+        fn = lambda: o.floating_batch(kw["dynamic"], kw["task_space"], q, dq)
+    elif kind == "obstacles":
+        p = _abi.make_obstacles_params(**kw)
+        fn = lambda: o.avoid_obstacles_batch(p, q)
     else:
         nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
         p = _abi.make_osc_params(o.n, null_controllers=nulls, **kw)

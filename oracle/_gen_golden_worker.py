@@ -450,6 +450,32 @@ def gen_secondary(arm):
     d = np.max(np.abs(out["obs_uS"] - out["obs_uD"]), axis=1)[act] / np.max(np.abs(out["obs_uD"]), axis=1)[act]
     print(f"  obstacles: active rows {act.sum()}/{Bo}; S-vs-D rel median={np.median(d):.2e} max={np.max(d):.2e}",
           flush=True)
+    # the three of them (+ Damping) behind OSC's null-space filter, as in
+    # examples/PyGame/force_osc_xy_avoid_joint_limits.py:21-36 and avoid_obstacles.py:17-28
+    from abr_control.controllers import OSC, Damping
+
+    dof = [True, True, n > 3, False, False, False]
+    Bs = 128
+    q, dq, tgt = draw(np.random.RandomState(73), Bs, n)
+    out["oscsec_q"], out["oscsec_dq"], out["oscsec_target"] = q, dq, tgt
+    out["oscsec_dof"] = np.array(dof)
+    ps = limit_sets(n)["limA"]
+    for label, cfg in (("S", rc), ("D", raw)):
+        nulls = [
+            AvoidJointLimits(cfg, min_joint_angles=list(ps["mn"]), max_joint_angles=list(ps["mx"]),
+                             max_torque=list(ps["mt"]), cross_zero=list(ps["cz"]), gradient=list(ps["gr"])),
+            AvoidObstacles(cfg, **kw),
+            Damping(cfg, kv=10),
+        ]
+        c = OSC(cfg, kp=100, null_controllers=nulls, ctrlr_dof=dof)
+        with np.errstate(all="ignore"):
+            out[f"oscsec_u{label}"] = np.array([c.generate(q[b], dq[b], tgt[b]) for b in range(Bs)])
+    dets, svs = np.zeros(Bs), np.zeros((Bs, int(np.sum(dof))))
+    for b in range(Bs):
+        dets[b], svs[b] = mx_diag(raw, q[b], dof)
+    out["oscsec_det"], out["oscsec_sv"] = dets, svs
+    d = np.max(np.abs(out["oscsec_uS"] - out["oscsec_uD"]), axis=1) / np.max(np.abs(out["oscsec_uD"]), axis=1)
+    print(f"  OSC + [limits, obstacles, damping]: S-vs-D rel median={np.median(d):.2e} max={np.max(d):.2e}", flush=True)
     np.savez_compressed(f"{OUT}/sec_{arm}.npz", **out)
     print(f"  wrote {OUT}/sec_{arm}.npz ({len(out)} arrays)", flush=True)
 

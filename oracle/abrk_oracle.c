@@ -1067,15 +1067,18 @@ int abrk_oracle_floating_generate(const abrk_arm_desc* a, int dynamic, int task_
 
 /* ------------------------------------------------------------------ AvoidObstacles.generate
  * avoid_obstacles.py:38-120.  diag (may be NULL): the smallest |s_i/s_max - 0.01| over every pinv
- * taken (:112; 1.0 if none) - the distance of the state from the pinv truncation threshold.      */
+ * taken (:112; 1.0 if none) - the distance of the state from the pinv truncation threshold; diag[1]: the
+ * smallest s_max / (|segment|^2 trace(M^-1)) over them (1.0 if none) - at rounding-noise level the reference
+ * inverts noise (the closest point sits on the axes it depends on) and its output is arbitrary.            */
 int abrk_oracle_avoid_obstacles_generate(const abrk_arm_desc* a, const abrk_obstacles_params* P, const double* q,
                                          double* u, double* diag) {
   int n = a->n_joints;
   double u_psp[NJ], M[NJ * NJ], Minv[NJ * NJ];
-  double margin = 1.0;
+  double margin = 1.0, mobility = 1.0, trMinv = 0.0;
   for (int i = 0; i < n; i++) u_psp[i] = 0.0;
   abrk_oracle_M(a, q, M); /* :54 */
   la_inv(M, n, Minv);
+  for (int i = 0; i < n; i++) trMinv += Minv[i * n + i];
   for (int ob = 0; ob < P->n_obstacles; ob++) {
     const double* obstacle = P->obstacles[ob];
     const double* v = obstacle; /* :59 */
@@ -1138,6 +1141,7 @@ int abrk_oracle_avoid_obstacles_generate(const abrk_arm_desc* a, const abrk_obst
           for (int r = 0; r < 3; r++) hi = fmax(hi, fabs(w[r]));
           for (int r = 0; r < 3; r++)
             if (hi > 0) margin = fmin(margin, fabs(fabs(w[r]) / hi - 0.01));
+          if (hi > 0) mobility = fmin(mobility, hi / (len2 * trMinv)); /* exactly 0: pinv(0) = 0, well defined */
         }
         for (int r = 0; r < 3; r++) f[r] = Mxpsp[r * 3] * Fpsp[0] + Mxpsp[r * 3 + 1] * Fpsp[1] + Mxpsp[r * 3 + 2] * Fpsp[2];
         for (int i = 0; i < n; i++) {
@@ -1152,6 +1156,9 @@ int abrk_oracle_avoid_obstacles_generate(const abrk_arm_desc* a, const abrk_obst
     double x = u_psp[i] * P->gain;
     u[i] = x < -P->maximum ? -P->maximum : (x > P->maximum ? P->maximum : x);
   }
-  if (diag) diag[0] = margin;
+  if (diag) {
+    diag[0] = margin;
+    diag[1] = mobility;
+  }
   return 0;
 }

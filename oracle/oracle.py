@@ -158,14 +158,15 @@ class Oracle:
         return u, diag
 
     def avoid_obstacles_batch(self, params, q):
-        """AvoidObstacles.generate per row -> u [B,n], margin [B] (distance from the pinv threshold)"""
+        """AvoidObstacles.generate per row -> u [B,n], diag [B,2] (distance from the pinv threshold, smallest
+        relative mobility of a closest point)"""
         q = _c(q)
         B = q.shape[0]
-        u, diag = np.zeros((B, self.n)), np.zeros((B, 1))
+        u, diag = np.zeros((B, self.n)), np.zeros((B, 2))
         for b in range(B):
             rc = self.L.abrk_oracle_avoid_obstacles_generate(self._d, C.byref(params), _p(q[b]), _p(u[b]), _p(diag[b]))
             assert rc == 0
-        return u, diag[:, 0]
+        return u, diag
 
 
 def avoid_joint_limits_batch(n, params, q):

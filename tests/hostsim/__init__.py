@@ -142,6 +142,43 @@ def joint_generate(arm, ctrl, account_for_gravity, q, dq, target=None, target_ve
     return u
 
 
+def avoid_joint_limits_generate(n, params, q, u=None, dtype=np.float64):
+    dt = np.dtype(dtype)
+    q = _in(q, dt)
+    B = q.shape[0]
+    acc = u is not None
+    u = np.full((B, n), np.nan, dt) if u is None else u
+    rc = _lib_for(law=True).hostsim_limits(n, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(u), int(acc))
+    assert rc == 0, rc
+    return u
+
+
+def floating_generate(arm, dynamic, task_space, q, dq=None, u=None, dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q, dq = _in(q, dt), _in(dq, dt)
+    B = q.shape[0]
+    acc = u is not None
+    u = np.full((B, n), np.nan, dt) if u is None else u
+    rc = _lib_for(arm).hostsim_floating(name, desc, _dtype_code(dt), int(bool(dynamic)), int(bool(task_space)),
+                                        C.c_int64(B), _p(q), _p(dq), _p(u), int(acc))
+    assert rc == 0, rc
+    return u
+
+
+def avoid_obstacles_generate(arm, params, q, u=None, dtype=np.float64):
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q = _in(q, dt)
+    B = q.shape[0]
+    acc = u is not None
+    u = np.full((B, n), np.nan, dt) if u is None else u
+    rc = _lib_for(arm).hostsim_obstacles(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(u),
+                                         int(acc))
+    assert rc == 0, rc
+    return u
+
+
 def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=None, target_velocity=None,
             integrated_error=None, u_null_ext=None, dtype=np.float64):
     dt = np.dtype(dtype)

@@ -182,7 +182,45 @@ extern "C" int hostsim_joint(const char* builtin, const abrk_arm_desc* d, int dt
   });
 }
 
+extern "C" int hostsim_floating(const char* builtin, const abrk_arm_desc* d, int dtype, int dynamic, int task_space,
+                                int64_t B, const void* q, const void* dq, void* u, int acc) {
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    for (long b = 0; b < B; b++) floating_body<A, T>(b, a, dynamic, task_space, (const T*)q, (const T*)dq, (T*)u, acc);
+    return 0;
+  });
+}
+extern "C" int hostsim_obstacles(const char* builtin, const abrk_arm_desc* d, int dtype,
+                                 const abrk_obstacles_params* P, int64_t B, const void* q, void* u, int acc) {
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    ObsP<T> p = make_obsp<T>(*P);
+    for (long b = 0; b < B; b++) obstacles_body<A, T>(b, a, p, (const T*)q, (T*)u, acc);
+    return 0;
+  });
+}
+
 #if HOSTSIM_LAW
+extern "C" int hostsim_limits(int n, int dtype, const abrk_limits_params* P, int64_t B, const void* q, void* u,
+                              int acc) {
+#define LIM_CASE(NN)                                                                                      \
+  if (n == NN) {                                                                                          \
+    if (dtype == 0) {                                                                                     \
+      LimitsP<double> p = make_limitsp<double>(*P);                                                       \
+      for (long b = 0; b < B; b++) limits_body<NN, double>(b, p, (const double*)q, (double*)u, acc);      \
+    } else {                                                                                              \
+      LimitsP<float> p = make_limitsp<float>(*P);                                                         \
+      for (long b = 0; b < B; b++) limits_body<NN, float>(b, p, (const float*)q, (float*)u, acc);         \
+    }                                                                                                     \
+    return 0;                                                                                             \
+  }
+  LIM_CASE(1) LIM_CASE(2) LIM_CASE(3) LIM_CASE(4) LIM_CASE(5) LIM_CASE(6) LIM_CASE(7)
+#undef LIM_CASE
+  return -1;
+}
+
 extern "C" int hostsim_osc_law(int n, int dtype, const abrk_osc_params* P, int64_t B, const void* J, const void* M,
                                const void* g, const void* c, const void* xyz, const void* R, const void* q,
                                const void* dq, const void* tg, const void* tv, void* ie, const void* une, void* u,

@@ -35,14 +35,16 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "abrk.h"
-int main(){printf("%zu %zu %zu %zu %zu %zu\n", sizeof(abrk_arm_desc), sizeof(abrk_dyn_out),
-  sizeof(abrk_null_ctrl), sizeof(abrk_osc_params), sizeof(abrk_sliding_params), offsetof(abrk_osc_params, null_ctrl));return 0;}'''
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(abrk_arm_desc), sizeof(abrk_dyn_out),
+  sizeof(abrk_null_ctrl), sizeof(abrk_osc_params), sizeof(abrk_sliding_params), offsetof(abrk_osc_params, null_ctrl),
+  sizeof(abrk_limits_params), sizeof(abrk_obstacles_params), offsetof(abrk_obstacles_params, obstacles));return 0;}'''
     exe = "/tmp/abrk_layout_probe"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(REPO, "include"), "-o", exe], input=src.encode(),
                    check=True)
     sizes = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
     assert sizes == [C.sizeof(_abi.ArmDesc), C.sizeof(_abi.DynOut), C.sizeof(_abi.NullCtrl),
-                     C.sizeof(_abi.OSCParams), C.sizeof(_abi.SlidingParams), _abi.OSCParams.null_ctrl.offset]
+                     C.sizeof(_abi.OSCParams), C.sizeof(_abi.SlidingParams), _abi.OSCParams.null_ctrl.offset,
+                     C.sizeof(_abi.LimitsParams), C.sizeof(_abi.ObstaclesParams), _abi.ObstaclesParams.obstacles.offset]
 
 
 def test_builtin_arm_registry_matches_tables(L):
@@ -115,6 +117,27 @@ def test_python_surface_mirrors_reference():
     assert r.rest_indices == [False, True, False, False, False, False] and not r.account_for_gravity
     assert Damping(rc, 10).kv == 10
 
+    # the remaining secondary controllers (avoid_joint_limits.py:35-81, floating.py:22-26, avoid_obstacles.py:26-36)
+    from abr_control_amd.controllers import AvoidJointLimits, AvoidObstacles, Floating
+
+    a = AvoidJointLimits(rc, [np.pi / 5, None, 5.5, np.nan, 0.1, 0.2], [np.pi / 2, 3.0, 0.8, np.nan, 3.0, 3.0],
+                         cross_zero=[False, False, True, False, False, False])
+    assert np.allclose(a.min_joint_angles[[0, 2]], [np.pi / 5 - np.pi, 0.8 - np.pi])  # shifted, swapped
+    assert np.isclose(a.max_joint_angles[2], 5.5 - np.pi) and list(a.no_limits_min) == [0, 1, 0, 1, 0, 0]
+    assert list(a.max_torque) == [1.0] * 6 and not a.gradient.any()
+    with pytest.raises(Exception, match="incorrect size"):
+        AvoidJointLimits(rc, [0.0] * 5, [1.0] * 5)
+    f = Floating(rc)
+    assert f.dynamic is False and f.task_space is False
+    o = AvoidObstacles(rc)
+    assert (o.threshold, o.gain, o.maximum) == (0.2, 1, 500) and o.obstacles.shape == (0,)
+    o.set_obstacles([[0.1, 0.2, 0.3, 0.05]])
+    assert o.obstacles.shape == (1, 4) and o._params().n_obstacles == 1
+    with pytest.raises(ValueError):
+        AvoidObstacles(rc, obstacles=[[0, 0, 0, 0.1]] * 17)._params()
+    c = OSC(rc, kp=10, null_controllers=[a, Damping(rc, 10), o])
+    assert len(c._device) == 2 and len(c._fused) == 1 and not c._foreign
+
     class Foreign:  # any duck-typed robot_config (e.g. the reference's MujocoConfig) is accepted by OSC:
         N_JOINTS = 6  # its J/M/g/Tx come from its own code, the law runs on the GPU (abrk_osc_law_batch)
 
@@ -155,6 +178,13 @@ def test_argument_validation_before_device(L):
         engine.osc_generate(0, 6, _abi.make_osc_params(6), q, q, np.zeros((2, 5)))
     with pytest.raises(TypeError):
         engine.osc_generate(0, 6, _abi.make_osc_params(6), q, q, q, dtype=np.float16)
+    with pytest.raises(AbrkError, match="EINVAL"):
+        engine.avoid_joint_limits_generate(9, _abi.make_limits_params(6, [0.0] * 6, [1.0] * 6), np.zeros((2, 9)))
+    with pytest.raises(AbrkError, match="ENOARM"):
+        engine.floating_generate(999, 6, False, False, q)
+    with pytest.raises(AbrkError, match="EINVAL"):
+        engine.avoid_obstacles_generate(0, 6, _abi.make_obstacles_params([[0, 0, 0, 1]], threshold=0), q)
+    assert engine.floating_generate(0, 6, True, True, np.zeros((0, 6)), np.zeros((0, 6))).shape == (0, 6)
     # empty batch is a no-op even without a device
     u = engine.osc_generate(0, 6, _abi.make_osc_params(6), np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((0, 6)))
     assert u.shape == (0, 6)

@@ -492,3 +492,70 @@ def test_gpu_inverse_kinematics():
     e0 = np.linalg.norm(rc.Tx("EE", q0) - tgt[:, :3], axis=1)
     e1 = np.linalg.norm(rc.Tx("EE", pp[:, -1]) - tgt[:, :3], axis=1)
     assert np.median(e1) < np.median(e0)
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("arm", ARMS)
+def test_gpu_secondary_controllers_match_reference(arm, variant):
+    """AvoidJointLimits / Floating / AvoidObstacles kernels vs the reference's own outputs,
+    alone and summed behind OSC's null-space filter"""
+    g = golden(f"sec_{arm}")
+    be = cases.GpuBackend(arm, variant)
+    rep = cases.check_secondary_against_golden(be, arm, g)
+    assert rep["obstacles_band"] <= 16
+    cases.check_oscsec_against_golden(be, arm, g)
+
+
+def test_gpu_secondary_controllers_large_batch_vs_oracle_and_api():
+    """fresh seeded inputs vs the oracle; fp32; accumulate; DeviceArrays; the public classes inside OSC"""
+    from abr_control_amd import DeviceArray
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC, AvoidJointLimits, AvoidObstacles, Damping, Floating
+    from oracle.oracle import Oracle, avoid_joint_limits_batch
+
+    g = golden("sec_ur5")
+    tab = _abi.load_table("ur5")
+    o = Oracle(tab)
+    be = cases.GpuBackend("ur5")
+    B = 3000
+    q, dq, t = draw(11, B, 6)
+    PL = cases.secondary_limit_params(g, "limB", 6)
+    assert np.allclose(be.limits(PL, q), avoid_joint_limits_batch(6, PL, q), rtol=1e-13, atol=1e-13)  # exp() ulps
+    for dyn, ts in ((0, 0), (1, 1)):
+        uo, diag = o.floating_batch(dyn, ts, q[:600], dq[:600])
+        ok = (np.abs(np.abs(diag[:, 0]) - 1e-3) > 1e-9) & (np.abs(diag[:, 1] - 1e-4) > 1e-8)
+        assert cases.rel_err(be.floating(dyn, ts, q[:600], dq[:600]), uo)[ok].max() < 1e-9
+    PO = cases.secondary_obstacle_params(g)
+    uo, diag = o.avoid_obstacles_batch(PO, q[:600])
+    ok = (diag[:, 0] > 1e-7) & (diag[:, 1] > 1e-20)
+    ug = be.obstacles(PO, q)
+    assert np.max(np.abs(ug[:600] - uo)[ok]) < 1e-6 * 500
+    assert np.all(np.abs(ug) <= 500.0)  # np.clip(maximum), avoid_obstacles.py:121
+    cases.check_secondary_against_golden(be, "ur5", g, dtype=np.float32)
+    # public classes: single state, batch, device-resident, inside OSC
+    rc = ur5.Config()
+    ps = {k: g[f"limA_{k}"] for k in ("mn", "mx", "mt", "cz", "gr")}
+    avoid = AvoidJointLimits(rc, list(ps["mn"]), list(ps["mx"]), list(ps["mt"]), list(ps["cz"]), list(ps["gr"]))
+    assert np.allclose(avoid.generate(g["lim_q"][3], None), g["limA_u"][3], atol=1e-12)
+    assert np.allclose(avoid.generate(g["lim_q"], None), g["limA_u"], atol=1e-12)
+    obs = AvoidObstacles(rc, obstacles=g["obs_obstacles"], threshold=float(g["obs_threshold"]),
+                         gain=float(g["obs_gain"]))
+    fl = Floating(rc, dynamic=True, task_space=False)
+    u1 = fl.generate(g["float_q"][0], g["float_dq"][0])
+    assert u1.shape == (6,) and cases.rel_err(u1[None], g["float_d1t0_uD"][:1]).max() < 1e-9
+    with pytest.raises(TypeError):
+        fl.generate(g["float_q"][0])
+    c = OSC(rc, kp=100, null_controllers=[avoid, obs, Damping(rc, 10)])
+    qs, dqs, ts_ = g["oscsec_q"], g["oscsec_dq"], g["oscsec_target"]
+    u = c.generate(qs, dqs, ts_)
+    band = cases.threshold_band(g, "oscsec")
+    _, diag = o.avoid_obstacles_batch(PO, qs)
+    ok = ~band & (diag[:, 0] > 1e-7) & (diag[:, 1] > 1e-20)
+    assert cases.rel_err(u, g["oscsec_uD"])[ok].max() < 1e-6
+    qd, dqd, td = (DeviceArray.from_numpy(np.ascontiguousarray(a)) for a in (qs, dqs, ts_))
+    ud = c.generate(qd, dqd, td)
+    assert np.array_equal(ud.numpy(), u)
+    # accumulate on device: u += signal
+    base = DeviceArray.from_numpy(np.full((len(qs), 6), 0.5))
+    obs._accumulate(qd, dqd, base)
+    assert np.allclose(base.numpy() - 0.5, obs.generate(qs), atol=1e-9)

@@ -249,3 +249,26 @@ def test_rows_inverse_kinematics(arm, variant):
         pp, _ = hostsim.ik_generate_path(tab, p, q0, tgt)
         po, _ = O.ik_paths(tab, p, q0, tgt)
         assert np.max(np.abs(pp - po)) < 1e-8
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("arm", ARMS)
+def test_rows_secondary_controllers(arm, variant):
+    """AvoidJointLimits / Floating / AvoidObstacles row programs vs the reference's outputs"""
+    rep = cases.check_secondary_against_golden(cases.HostsimBackend(arm, variant), arm, golden(f"sec_{arm}"))
+    assert rep["obstacles_band"] <= 16  # of 128: pinv-threshold and noise-inversion rows
+    cases.check_oscsec_against_golden(cases.HostsimBackend(arm, variant), arm, golden(f"sec_{arm}"))
+
+
+def test_rows_secondary_fp32_and_accumulate():
+    from tests import hostsim
+
+    g = golden("sec_ur5")
+    be = cases.HostsimBackend("ur5")
+    cases.check_secondary_against_golden(be, "ur5", g, dtype=np.float32)
+    # accumulate: u += signal
+    P = cases.secondary_obstacle_params(g)
+    q = g["obs_q"]
+    base = np.full((len(q), 6), 0.25)
+    u = hostsim.avoid_obstacles_generate("ur5", P, q, u=base.copy())
+    assert np.allclose(u - base, hostsim.avoid_obstacles_generate("ur5", P, q), rtol=0, atol=1e-9)

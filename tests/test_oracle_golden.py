@@ -28,7 +28,8 @@ def test_oracle_controllers_match_reference(case_id):
 def test_oracle_secondary_controllers_match_reference(arm):
     """AvoidJointLimits / Floating / AvoidObstacles vs the reference's own outputs"""
     rep = cases.check_secondary_against_golden(cases.OracleBackend(arm), arm, golden(f"sec_{arm}"))
-    assert rep["obstacles_band"] <= 4
+    assert rep["obstacles_band"] <= 16  # of 128: pinv-threshold and noise-inversion rows
+    cases.check_oscsec_against_golden(cases.OracleBackend(arm), arm, golden(f"sec_{arm}"))
 
 
 def test_oracle_twojoint_closed_forms():
