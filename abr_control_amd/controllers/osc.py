@@ -52,6 +52,7 @@ class OSC(Controller):
         self.ZEROS_SIX = np.zeros(6)
         self.IDENTITY_N_JOINTS = np.eye(self.robot_config.N_JOINTS)
         self.training_signal = None
+        self._params_cache = {}
 
         # secondary controllers: Damping / RestingConfig are fused into the kernel; the package's other
         # controllers (AvoidJointLimits, AvoidObstacles, Floating) are summed on the device by their own
@@ -71,9 +72,22 @@ class OSC(Controller):
                 self._foreign.append(nc)
 
     def _params(self, ref_frame, xyz_offset):
+        """abrk_osc_params of the current attribute values (cached: a control loop calls generate() per tick)"""
         rc = self.robot_config
         if not self._fused_config:
             ref_frame, xyz_offset = "EE", None  # applied by the foreign config when it produced J/Tx/R
+        key = (ref_frame, None if xyz_offset is None else tuple(float(v) for v in xyz_offset), self.kp, self.ko,
+               self.kv, self.ki, None if self.vmax is None else tuple(self.vmax), tuple(self.ctrlr_dof), self.use_g,
+               self.use_C, self.orientation_algorithm)
+        hit = self._params_cache.get(key)
+        if hit is None:
+            if len(self._params_cache) > 64:
+                self._params_cache.clear()
+            hit = self._params_cache[key] = self._make_params(ref_frame, xyz_offset)
+        return hit
+
+    def _make_params(self, ref_frame, xyz_offset):
+        rc = self.robot_config
         return _abi.make_osc_params(
             rc.N_JOINTS, kp=self.kp, ko=self.ko, kv=self.kv, ki=self.ki, vmax=self.vmax,
             ctrlr_dof=self.ctrlr_dof, null_controllers=self._fused, use_g=self.use_g, use_C=self.use_C,

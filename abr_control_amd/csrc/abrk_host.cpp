@@ -282,15 +282,38 @@ struct Arena {
 };
 thread_local Arena t_arena;
 
-bool is_device_ptr(const void* p) {
+// Small host batches (a control loop calling with B = 1 .. a few thousand rows) skip the copy engine: the
+// arguments are packed by the CPU into a pinned, device-mapped arena that the kernel reads and writes directly
+// over PCIe - one launch and one stream sync instead of 3-4 hipMemcpyAsync calls of a few hundred bytes each.
+// Above ABRK_ZEROCOPY_MAX bytes (default 1 MiB) the copy engine + device scratch arena wins.
+struct PinArena {
+  char* base = nullptr;  // host address
+  char* dev = nullptr;   // the same memory as the device sees it
+  size_t cap = 0;
+};
+thread_local PinArena t_pin;
+size_t zero_copy_max() {
+  static const size_t v = [] {
+    const char* e = getenv("ABRK_ZEROCOPY_MAX");
+    return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1 << 20;
+  }();
+  return v;
+}
+
+// device-usable address of p, or nullptr for pageable host memory.  Pinned host memory (hipHostMalloc /
+// hipHostRegister) is device-visible: it is passed through and read in place.
+void* device_view(const void* p) {
   hipPointerAttribute_t at;
   hipError_t e = hipPointerGetAttributes(&at, p);
   if (e != hipSuccess) {
     (void)hipGetLastError();  // plain malloc'ed host memory is "invalid value" to HIP
-    return false;
+    return nullptr;
   }
-  return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+  if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) return const_cast<void*>(p);
+  if (at.type == hipMemoryTypeHost && at.devicePointer) return at.devicePointer;
+  return nullptr;
 }
+bool is_device_ptr(const void* p) { return device_view(p) == p && p; }
 
 struct Stager {
   int device;
@@ -303,12 +326,12 @@ struct Stager {
   };
   std::vector<Item> items;
   size_t need = 0;
-  bool staged = false;
+  bool staged = false, pinned = false;
 
   // first pass: register; second pass (after reserve()) resolve
   void* add(const void* p, size_t bytes, bool in, bool out) {
     if (!p) return nullptr;
-    if (is_device_ptr(p)) return const_cast<void*>(p);
+    if (void* d = device_view(p)) return d;
     items.push_back({const_cast<void*>(p), nullptr, bytes, out, in});
     need += (bytes + 255) & ~size_t(255);
     return (void*)(uintptr_t)(items.size());  // placeholder index+1, resolved by fix()
@@ -316,6 +339,35 @@ struct Stager {
   int reserve() {
     if (items.empty()) return 0;
     staged = true;
+    if (need <= zero_copy_max()) {
+      PinArena& pa = t_pin;
+      if (pa.cap < need) {
+        if (pa.base) (void)hipHostFree(pa.base);
+        pa.base = pa.dev = nullptr;
+        pa.cap = 0;
+        size_t cap = need < (64u << 10) ? (64u << 10) : need;
+        void* h = nullptr;
+        hipError_t e = hipHostMalloc(&h, cap, hipHostMallocMapped | hipHostMallocPortable);
+        void* d = nullptr;
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) {
+          (void)hipGetLastError();
+          if (h) (void)hipHostFree(h);
+          return fail(ABRK_ENOMEM, "pinned staging hipHostMalloc(%zu): %s", cap, hipGetErrorString(e));
+        }
+        pa.base = (char*)h;
+        pa.dev = (char*)d;
+        pa.cap = cap;
+      }
+      pinned = true;
+      size_t off = 0;
+      for (auto& it : items) {
+        it.dev = pa.dev + off;
+        if (it.in) memcpy(pa.base + off, it.host, it.bytes);
+        off += (it.bytes + 255) & ~size_t(255);
+      }
+      return 0;
+    }
     Arena& a = t_arena;
     if (a.device != device || a.cap < need) {
       if (a.base) {
@@ -355,6 +407,13 @@ struct Stager {
   }
   int finish() {
     if (!staged) return 0;
+    if (pinned) {
+      hipError_t e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) return fail(ABRK_ENODEV, "stream sync: %s", hipGetErrorString(e));
+      for (auto& it : items)
+        if (it.out) memcpy(it.host, t_pin.base + ((char*)it.dev - t_pin.dev), it.bytes);
+      return 0;
+    }
     for (auto& it : items)
       if (it.out) {
         hipError_t e = hipMemcpyAsync(it.host, it.dev, it.bytes, hipMemcpyDeviceToHost, stream);

@@ -559,3 +559,34 @@ def test_gpu_secondary_controllers_large_batch_vs_oracle_and_api():
     base = DeviceArray.from_numpy(np.full((len(qs), 6), 0.5))
     obs._accumulate(qd, dqd, base)
     assert np.allclose(base.numpy() - 0.5, obs.generate(qs), atol=1e-9)
+
+
+def test_gpu_concurrent_host_calls_from_threads():
+    """ctypes releases the GIL: host-array calls from several threads (each with its own staging arenas,
+    small batches through the pinned zero-copy arena, large ones through the copy engine) must not interfere"""
+    from concurrent.futures import ThreadPoolExecutor
+
+    be = cases.GpuBackend("ur5")
+    params = cases.P(6, kp=200)
+
+    def work(seed):
+        out = []
+        for k, B in enumerate((1, 37, 4096, 40000, 3)):
+            q, dq, t = draw(100 * seed + k, B, 6)
+            u, _ = be.osc(params, q, dq, t)
+            out.append((q, dq, t, u))
+        return out
+
+    with ThreadPoolExecutor(4) as ex:
+        results = list(ex.map(work, range(8)))
+    for res in results:
+        for q, dq, t, u in res:
+            ref, _ = be.osc(params, q, dq, t)  # same call, single-threaded
+            assert np.array_equal(u, ref)
+    # and against the oracle on a sample
+    from oracle.oracle import Oracle
+
+    o = Oracle(_abi.load_table("ur5"))
+    q, dq, t, u = results[3][1]
+    uo, _ = o.osc_batch(params, q, dq, t, want_training=True)
+    assert np.median(cases.rel_err(u, uo)) < 1e-9
