@@ -352,6 +352,8 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
+    ap.add_argument("--also", default="", help="comma-separated extra workloads: one HBM-sized roofline leg each "
+                                               "(same process, so one rocprofv3 session sees every kernel)")
     args = ap.parse_args()
 
     from abr_control_amd.sharding import dist_env
@@ -405,10 +407,12 @@ def main():
     # HBM-sized leg for the roofline (rank 0 only; every rank could, the figure is per GPU)
     if rank == 0 and not args.no_roofline_leg:
         del run
-        big = Runner(args.workload, args.roofline_batch, device, stream)
+        # the iterative workloads carry [B, T, n] trajectories (ik: 19 KB per row): keep their leg at 256 k rows
+        rb = min(args.roofline_batch, 1 << 18) if kind in ("ik", "rollout") else args.roofline_batch
+        big = Runner(args.workload, rb, device, stream)
         _, ms_big = big.timed(args.roofline_steps, 3)
-        out["roofline"] = roofline(big, ms_big, f"{args.workload} batch={args.roofline_batch} "
-                                                f"({args.roofline_batch * big.bytes_per_eval / 2**20:.0f} MiB algorithmic, "
+        out["roofline"] = roofline(big, ms_big, f"{args.workload} batch={rb} "
+                                                f"({rb * big.bytes_per_eval / 2**20:.0f} MiB algorithmic, "
                                                 f">> 256 MiB Infinity Cache)")
         del big
     elif rank == 0:
@@ -419,6 +423,15 @@ def main():
         _, ms_full = full.timed(args.roofline_steps, 3)
         out["roofline_full_outputs"] = roofline(full, ms_full, f"dynF batch={full.B}: Tx,J,M,g per row, 696 B/row")
         del full
+    if rank == 0 and args.also:
+        out["also"] = {}
+        for w in args.also.split(","):
+            # keep each leg in the ms range, and the (kernel name, rows) pairs of one session distinct
+            per_row = {"rollout": 32, "ik": 64, "obstacles": 4, "osc_damp": 3}.get(WORKLOADS[w][3], 2)
+            extra = Runner(w, max(args.roofline_batch // per_row, 4096), device, stream)
+            _, ms_x = extra.timed(max(args.roofline_steps // 3, 3), 2)
+            out["also"][w] = roofline(extra, ms_x, f"{w} batch={extra.B}")
+            del extra
     if rank == 0 and args.workload == "cfg2":
         out["parity"] = parity_vs_reference(device)
         out["host_staged"] = host_staged_rate(device)
