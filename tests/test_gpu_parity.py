@@ -590,3 +590,36 @@ def test_gpu_concurrent_host_calls_from_threads():
     q, dq, t, u = results[3][1]
     uo, _ = o.osc_batch(params, q, dq, t, want_training=True)
     assert np.median(cases.rel_err(u, uo)) < 1e-9
+
+
+def test_gpu_secondary_controllers_properties_full_size():
+    """size-independent properties at 2^20 rows (BASELINE config-4 size)"""
+    be = cases.GpuBackend("ur5")
+    B = 1 << 20
+    q, dq, _ = draw(21, B, 6)
+    # Floating(joint space) == -g of the dynamics kernel; dynamic adds -M dq (floating.py:64-69)
+    d = be.dynamics(q[:65536], None, "EE", None, ("g", "M"))
+    u = be.floating(0, 0, q, dq)
+    assert u.shape == (B, 6) and np.allclose(u[:65536], -d["g"], rtol=1e-13, atol=1e-13)
+    ud = be.floating(1, 0, q[:65536], dq[:65536])
+    assert np.allclose(ud, -d["g"] - np.einsum("bij,bj->bi", d["M"], dq[:65536]), rtol=1e-12, atol=1e-12)
+    # task space: u = J^T u_task lies in the row space of J[:3]: projecting it through pinv(J) J changes nothing
+    ut = be.floating(0, 1, q[:4096], dq[:4096])
+    J = be.dynamics(q[:4096], None, "EE", None, ("J",))["J"][:, :3]
+    res = ut - np.einsum("bij,bj->bi", np.linalg.pinv(J) @ J, ut)
+    assert np.max(np.abs(res)) < 1e-8 * max(1.0, np.max(np.abs(ut)))
+    # joint limits: walls only -> every entry is 0 or +-max_torque, 0 strictly inside the range
+    PL = _abi.make_limits_params(6, [1.0] * 6, [5.0] * 6, max_torque=[3.0] * 6)
+    ul = be.limits(PL, q)
+    assert set(np.unique(ul)) <= {-3.0, 0.0, 3.0}
+    assert np.array_equal(ul != 0, (q < 1.0) | (q > 5.0))
+    assert np.array_equal(ul > 0, q < 1.0)
+    # obstacles: none / out of reach -> exactly 0; always within +-maximum; rows independent of batch position
+    assert not be.obstacles(_abi.make_obstacles_params([]), q[:4096]).any()
+    assert not be.obstacles(_abi.make_obstacles_params([[50.0, 50.0, 50.0, 0.1]]), q[:4096]).any()
+    PO = _abi.make_obstacles_params([[0.3, 0.2, 0.4, 0.1], [-0.2, 0.4, 0.3, 0.05]], threshold=0.3, gain=30,
+                                    maximum=123.0)
+    uo = be.obstacles(PO, q)
+    assert np.all(np.isfinite(uo)) and np.max(np.abs(uo)) <= 123.0 and (uo != 0).any()
+    perm = np.random.RandomState(5).permutation(B)[:8192]
+    assert np.array_equal(be.obstacles(PO, q[perm]), uo[perm])
