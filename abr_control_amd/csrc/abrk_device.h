@@ -141,7 +141,7 @@ struct Rm<double> {
 };
 template <>
 struct Rm<float> {
-  static ABRK_INL void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+  static ABRK_INL void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }  // a custom routine measured no faster
   static ABRK_INL float sqrt(float x) { return ::sqrtf(x); }
   static ABRK_INL float fabs(float x) { return ::fabsf(x); }
   static ABRK_INL float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
@@ -211,7 +211,10 @@ constexpr bool aff_is_orthogonal(const double* X) {
       for (int k = 0; k < 3; k++) s += X[k * 4 + a] * X[k * 4 + b];
       if (s != (a == b ? 1.0 : 0.0)) return false;
     }
-  return true;
+  // proper rotation (det = +1): only then is P Zhat P^-1 the cross product with the joint axis
+  const double det = X[0] * (X[5] * X[10] - X[6] * X[9]) - X[1] * (X[4] * X[10] - X[6] * X[8]) +
+                     X[2] * (X[4] * X[9] - X[5] * X[8]);
+  return det > 0.0;
 }
 
 // Built-in arm: every constant is a constant expression.  Derived static transforms:
@@ -244,6 +247,17 @@ struct StaticArm {
     return true;
   }
   static constexpr bool kOrtho = compute_ortho();
+  // joint i's frame is an exact rotation iff every static block before it is (Jaco2: joints 0-2; its later
+  // rotation constants are rounded, arms/jaco2/config.py:189-273): W_i is then the cross product with z_i
+  // and needs no 3x3 matrix.
+  static constexpr bool ortho_joint(int i) {
+    if (!aff_is_orthogonal(Tab::A0)) return false;
+    for (int k = 0; k <= i; k++) {
+      if (!aff_is_orthogonal(Tab::AJ[k])) return false;
+      if (k < i && !aff_is_orthogonal(Tab::B[k])) return false;
+    }
+    return true;
+  }
 };
 
 // User arm: same derived tables, filled on the host (abrk_host.cpp) in the kernel's
@@ -253,6 +267,7 @@ struct RtArm {
   static constexpr int N = NJ;
   static constexpr bool kStatic = false;
   static constexpr bool kOrtho = false;  // always differentiate the general affine chain
+  static constexpr bool ortho_joint(int) { return false; }
   int NL;
   T J0v[12];
   T Sv[NJ][12];
@@ -386,7 +401,7 @@ struct Joints {
 // out = W_I v
 template <int I, class A, class T>
 ABRK_INL void wapply(const Joints<A, T>& jt, const T (&v)[3], T (&out)[3]) {
-  if constexpr (A::kOrtho)
+  if constexpr (A::ortho_joint(I))
     cross3(jt.z[I], v, out);
   else
     matvec3(jt.W[I], v, out);
@@ -429,7 +444,7 @@ ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (
       jt.z[I][r()] = Rj[r() * 3 + 2];
       jt.o[I][r()] = oj[r()];
     });
-    if constexpr (!A::kOrtho) {
+    if constexpr (!A::ortho_joint(I)) {
       // rows 0,1 of P^-1 via the dual basis: r0 = (c1 x c2)/det, r1 = (c2 x c0)/det
       T c0[3] = {Rj[0], Rj[3], Rj[6]}, c1[3] = {Rj[1], Rj[4], Rj[7]}, c2[3] = {Rj[2], Rj[5], Rj[8]};
       T r0[3], r1[3];

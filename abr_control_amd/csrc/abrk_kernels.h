@@ -70,8 +70,11 @@ dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, con
 // (xyz kernel) asked to fit two waves per SIMD (<= 256 VGPRs; measured +6 % on Jaco2 whose general-chain state would
 // otherwise take 256 + 18 parked registers); the heavier variants keep the full budget - forcing them
 // under 256 spills hundreds of bytes per lane and loses 2-3x (measured).
+#ifndef ABRK_FEAT1_TWO_WAVES
+#define ABRK_FEAT1_TWO_WAVES 1
+#endif
 constexpr int osc_min_waves(int km, bool use_c, int feat) {
-  return (km == 3 && !use_c && feat <= 1) ? 2 : ABRK_MIN_WAVES;
+  return (km == 3 && !use_c && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES))) ? 2 : ABRK_MIN_WAVES;
 }
 
 template <class A, class T, int KM, bool USE_C, int FEAT>

@@ -91,7 +91,7 @@ class Runner:
         from abr_control_amd._lib import check, lib
 
         arm, _, dts, kind, kw, self.flops = WORKLOADS[workload]
-        self.a, self.engine, self.kind = a, engine, kind
+        self.a, self.engine, self.kind, self.arm = a, engine, kind, arm
         self.dt = np.float64 if dts == "f64" else np.float32
         tab = _abi.load_table(arm)
         self.n = tab["n_joints"]
@@ -148,6 +148,25 @@ class Runner:
                                        dtype=self.dt, device=device, stream=stream)
         self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
         self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else kw["n_timesteps"] if kind == "ik" else 1)
+
+    def kernel_name(self):
+        """the instantiation this workload launches, spelled as rocprofv3 prints it (key of profiles/*/traffic.json)"""
+        t = "double" if self.dt == np.float64 else "float"
+        arm = f"abrk::StaticArm<abrk::Tab_{self.arm}>"
+        k = self.kind
+        if k in ("osc", "osc_damp"):
+            p = self.params
+            dof = list(p.ctrlr_dof)
+            fast = dof == [1, 1, 1, 0, 0, 0] and p.ref_frame == 2 * self.n + 1
+            b = lambda v: "true" if v else "false"
+            return f"osc_kernel<{arm}, {t}, {3 if fast else 6}, {b(p.use_C)}, {1 if p.n_null else 0}>"
+        if k == "dyn":
+            return f"dyn_kernel<{arm}, {t}, false>"
+        if k == "limits":
+            return f"limits_kernel<{self.n}, {t}>"
+        if k == "rollout":
+            return f"rollout_kernel<{arm}, {t}, {'true' if self.params.use_C else 'false'}>"
+        return f"{k}_kernel<{arm}, {t}>"
 
     def step(self):
         if self.kind == "ik":
@@ -212,7 +231,7 @@ def profiled_traffic(kernel, batch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     (profiles/round1/traffic.json, tools/gpu_profiles.sh); None when that (kernel, batch) was not profiled."""
     try:
-        t = json.load(open(os.path.join(REPO, "profiles", "round1", "traffic.json")))[f"{kernel}:{batch}"]
+        t = json.load(open(os.path.join(REPO, "profiles", "round1", "traffic.json")))[f"{kernel.replace(' ', '')}:{batch}"]
         return round(t["read_bytes"] + t["write_bytes"], 1)
     except (OSError, KeyError, ValueError):
         return None
@@ -222,8 +241,7 @@ def roofline(runner, ms_per_launch, label):
     evals_s = runner.evals_per_launch / (ms_per_launch * 1e-3)
     gbs = runner.B / (ms_per_launch * 1e-3) * runner.bytes_per_eval / 1e9
     tf = evals_s * runner.flops / 1e12
-    kname = {"sliding": "sliding_kernel", "dyn": "dyn_kernel", "limits": "limits_kernel", "floating": "floating_kernel",
-             "obstacles": "obstacles_kernel", "ik": "ik_kernel", "rollout": "rollout_kernel"}.get(runner.kind, "osc_kernel")
+    kname = runner.kernel_name()
     return {
         "kernel": kname,
         "workload": label, "batch": runner.B, "bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS,
@@ -286,13 +304,32 @@ def cpu_baseline(workload, budget_s=12.0):
     arm, _, _, kind, kw, _ = WORKLOADS[workload]
     o = Oracle(_abi.load_table(arm))
     nt = 3 if kind == "sliding" else 6
-    Bs = 2048
+    Bs, scale = 2048, 1
     q, dq, t = make_inputs(1, Bs, o.n, nt, np.float64)
     if kind == "dyn":
         fn = lambda: [(o.Tx("EE", q[i]), o.J("EE", q[i]), o.M(q[i]), o.g(q[i])) for i in range(Bs)]
     elif kind == "sliding":
         p = _abi.make_sliding_params(o.n)
         fn = lambda: o.sliding_batch(p, q, dq, t)
+    elif kind == "ik":
+        from oracle.oracle import ik_paths
+
+        Bs = 8
+        p = _abi.make_ik_params(**kw)
+        tab = _abi.load_table(arm)
+        fn = lambda: ik_paths(tab, p, q[:Bs], t[:Bs])
+        scale = kw["n_timesteps"]  # evals = iterations
+    elif kind == "rollout":
+        from oracle.oracle import rollout_twolink
+
+        Bs = 8
+        tab = _abi.load_table(arm)
+        L = np.array([[0, 0, 0], [0, 0, 0], [1.0, 0, 0], [1.0, 0, 0], [0.6, 0, 0], [0.6, 0, 0]])
+        plant = _abi.make_twolink_plant(L, [np.diag(tab["mdiag"][l]) for l in range(3)], 0.001)
+        nulls = [_abi.make_damping(10), _abi.make_resting([np.pi / 4, np.pi], kp=50, kv=np.sqrt(50))]
+        p = _abi.make_osc_params(2, null_controllers=nulls, **kw)
+        fn = lambda: rollout_twolink(tab, p, plant, q[:Bs], np.zeros((Bs, 2)), t[:Bs], ROLLOUT_STEPS, ROLLOUT_STEPS)
+        scale = ROLLOUT_STEPS  # evals = control steps
     elif kind == "limits":
         from oracle.oracle import avoid_joint_limits_batch
 
@@ -315,7 +352,7 @@ def cpu_baseline(workload, budget_s=12.0):
         fn()
         reps += 1
     dt1 = time.perf_counter() - t0
-    one = reps * Bs / dt1
+    one = reps * Bs * scale / dt1
     # all host cores: the C oracle is called through ctypes (GIL released), one thread per core, each on
     # its own copy of the sample - the reference itself has no multi-core path
     from concurrent.futures import ThreadPoolExecutor
@@ -334,11 +371,11 @@ def cpu_baseline(workload, budget_s=12.0):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(worker, range(cores)))
     dtc = time.perf_counter() - t0
-    return {"value": round(total * Bs / dtc, 1), "unit": "evals/s", "cores": cores, "kind": "port",
+    return {"value": round(total * Bs * scale / dtc, 1), "unit": "evals/s", "cores": cores, "kind": "port",
             "value_1core": round(one, 1),
             "sample": f"oracle/abrk_oracle.c (plain-C port of the reference path) on seeded rows of the same "
-                      f"workload: {reps} x {Bs} rows on 1 thread in {dt1:.1f} s; {total} x {Bs} rows on {cores} "
-                      f"threads in {dtc:.1f} s"}
+                      f"workload: {reps} x {Bs} rows{f' x {scale} steps' if scale > 1 else ''} on 1 thread in {dt1:.1f} s; "
+                      f"{total} x {Bs} rows on {cores} threads in {dtc:.1f} s"}
 
 
 def main():

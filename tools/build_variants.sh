@@ -5,11 +5,12 @@
 set -e
 cd "$(dirname "$0")/../abr_control_amd/csrc"
 mkdir -p variants
-OTHERS=$(ls build/*.o | grep -v abrk_arm_ur5.o)
+TU=${TU:-ur5}   # which arm translation unit to rebuild (TU=jaco2 tools/build_variants.sh ...)
+OTHERS=$(ls build/*.o | grep -v abrk_arm_$TU.o)
 for spec in "$@"; do
   tag="${spec%%:*}"; flags="${spec#*:}"
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only $flags -c abrk_arm_ur5.hip -o variants/ur5_$tag.o \
-    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libabrk_$tag.so variants/ur5_$tag.o $OTHERS \
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only $flags -c abrk_arm_$TU.hip -o variants/${TU}_$tag.o \
+    && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libabrk_$tag.so variants/${TU}_$tag.o $OTHERS \
     && echo "built $tag" ) &
 done
 wait

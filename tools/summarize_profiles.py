@@ -31,7 +31,7 @@ if os.path.exists(ks):
                      f"{r['MaxNs']} | {r['Percentage']} |")
     kt = pd.read_csv(os.path.join(src, "stats", "bench_kernel_trace.csv"))
     kt["dur"] = kt["End_Timestamp"] - kt["Start_Timestamp"]
-    kt["kernel"] = kt["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:60]
+    kt["kernel"] = kt["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:90]
     g = kt.groupby(["kernel", "Grid_Size_X"])["dur"].agg(["count", "mean", "min", "max"]).reset_index()
     lines += ["", "per (kernel, grid) from the kernel trace of the same run:", "",
               "| kernel | rows (grid) | launches | mean us | min us | max us |", "|---|---|---|---|---|---|"]
@@ -43,7 +43,7 @@ for d in sorted(os.listdir(src)):
     cc = os.path.join(src, d, "bench_counter_collection.csv")
     if d.startswith("pmc_") and os.path.exists(cc):
         df = pd.read_csv(cc)
-        df["kernel"] = df["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:60]
+        df["kernel"] = df["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:90]
         g = df.groupby(["kernel", "Grid_Size", "Counter_Name", "VGPR_Count", "Accum_VGPR_Count", "Scratch_Size",
                         "LDS_Block_Size"])["Counter_Value"].mean().reset_index()
         g.to_csv(os.path.join(dst, f"{d}_mean_per_launch.csv"), index=False)
@@ -58,7 +58,7 @@ if rows:
     traffic = {}
     for (k, gsz), r in piv.iterrows():
         if "FETCH_SIZE" in r and "WRITE_SIZE" in r and r["FETCH_SIZE"] == r["FETCH_SIZE"]:
-            traffic[f"{k.split('<')[0]}:{int(gsz)}"] = {
+            traffic[f"{k.replace(' ', '')}:{int(gsz)}"] = {
                 "read_bytes": float(r["FETCH_SIZE"] * 1024 * 2), "write_bytes": float(r["WRITE_SIZE"] * 1024),
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
