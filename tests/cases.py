@@ -166,7 +166,10 @@ class HostsimBackend:
         from tests import hostsim
 
         self.h = hostsim
-        self.tab = _abi.load_table(arm)
+        if isinstance(arm, dict):  # a user arm table -> runtime-table row programs
+            self.tab, variant = arm, "rt"
+        else:
+            self.tab = _abi.load_table(arm)
         self.n = self.tab["n_joints"]
         self.arm = arm if variant == "static" else self.tab
         self.name = f"hostsim-{variant}"
@@ -396,3 +399,76 @@ def check_dynamics_against_golden(backend, arm, g, dtype=np.float64):
             ref = g[f"{w}_{f}"]
             err = np.max(np.abs(np.asarray(r[w], float) - ref)) / scale(ref)
             assert err <= tol, f"{arm} {w}({f}) [{backend.name}]: {err:.3e}"
+
+
+# ---------------------------------------------------------------------------- seeded fuzz over OSC parameters
+def fuzz_osc_cases(seed, count):
+    """random (arm table, abrk_osc_params, optional inputs) combinations: joint counts 1..7, orthogonal and
+    rounded static transforms, any ctrlr_dof mask, frames, offsets, vmax, ki, target velocity, fused and external
+    secondary controllers, both orientation algorithms"""
+    from tests.synthetic_arms import make_arm
+
+    rng = np.random.RandomState(seed)
+    out = []
+    for c in range(count):
+        n = int(rng.randint(1, 8))
+        tab = make_arm(n, 1000 + seed * 100 + c, non_orthogonal=bool(rng.randint(2)))
+        k = int(rng.randint(1, min(n, 6) + 1))
+        dof = np.zeros(6, int)
+        dof[rng.permutation(6)[:k]] = 1
+        frames = ["EE"] + [f"link{i}" for i in range(1, n + 1)] + [f"joint{i}" for i in range(n)]
+        nulls = []
+        if rng.randint(2):
+            nulls.append(make_damping(float(rng.uniform(1, 10))))
+        if rng.randint(2):
+            rest = [None if rng.randint(2) else float(rng.uniform(0, 6)) for _ in range(n)]
+            nulls.append(make_resting(rest, kp=float(rng.uniform(5, 40)), kv=float(rng.uniform(1, 8))))
+        kw = dict(kp=float(rng.uniform(5, 200)), ko=float(rng.uniform(5, 150)), kv=float(rng.uniform(2, 25)),
+                  ki=float(rng.uniform(0.05, 0.5)) if rng.randint(3) == 0 else 0,
+                  vmax=[float(rng.uniform(0.2, 2)), float(rng.uniform(0.2, 2))] if rng.randint(3) == 0 else None,
+                  ctrlr_dof=dof.tolist(), null_controllers=nulls, use_g=bool(rng.randint(2)), use_C=bool(rng.randint(2)),
+                  orientation_algorithm=int(rng.randint(2)), ref_frame=frames[rng.randint(len(frames))],
+                  xyz_offset=rng.uniform(-0.2, 0.2, 3).tolist() if rng.randint(2) else None)
+        out.append(dict(tab=tab, n=n, kw=kw, tv=bool(rng.randint(3) == 0), ext=bool(rng.randint(3) == 0),
+                        seed=int(rng.randint(1 << 30))))
+    return out
+
+
+def check_fuzz_case(backend_factory, fc, B=96):
+    """one fuzz case on a backend vs the oracle; rows near the `_Mx` thresholds or with an ill-conditioned M /
+    Mx_inv (where 1e-6 is not attainable in fp64 by either side) are left out"""
+    from oracle.oracle import Oracle
+
+    n, tab = fc["n"], fc["tab"]
+    rng = np.random.RandomState(fc["seed"])
+    q, dq, t = rng.uniform(-3, 3, (B, n)), rng.uniform(-2, 2, (B, n)), rng.uniform(-0.6, 0.6, (B, 6))
+    tv = rng.uniform(-0.5, 0.5, (B, 6)) if fc["tv"] else None
+    une = rng.uniform(-2, 2, (B, n)) if fc["ext"] else None
+    params = P(n, **fc["kw"])
+    o = Oracle(tab)
+    ie_o = np.zeros((B, 6)) if params.ki != 0 else None
+    uo = o.osc_batch(params, q, dq, t, tv, ie_o, une)
+    be = backend_factory(tab)
+    ie = np.zeros((B, 6)) if params.ki != 0 else None
+    u, _ = be.osc(params, q, dq, t, tv, ie=ie, une=une)
+    dof = np.array(fc["kw"]["ctrlr_dof"], bool)
+    ok = np.ones(B, bool)
+    for b in range(B):
+        M = o.M(q[b])
+        J = o.J(fc["kw"]["ref_frame"], q[b], fc["kw"]["xyz_offset"])[dof]
+        if np.linalg.cond(M) > 1e7:
+            ok[b] = False
+            continue
+        A = J @ np.linalg.inv(M) @ J.T
+        sv = np.linalg.svd(A, compute_uv=False)
+        det = abs(np.linalg.det(A))
+        near = abs(det - 1e-3) < 1e-8 or (det < 1.001e-3 and np.any(np.abs(sv / sv.max() - 1e-4) < 1e-8))
+        # below the det threshold the law uses a truncated pinv: well-posed only if the kept part is well separated
+        if near or (sv.max() / max(sv.min(), 1e-300) > 1e7 and det >= 1e-3):
+            ok[b] = False
+    err = rel_err(np.asarray(u, float), uo)
+    assert ok.sum() >= B // 2, f"fuzz case filtered too hard ({ok.sum()}/{B})"
+    assert err[ok].max() <= TOL_D, f"fuzz n={n} {fc['kw']}: {err[ok].max():.3e} (row {int(np.argmax(np.where(ok, err, 0)))})"
+    if ie is not None:
+        assert np.allclose(ie[ok], ie_o[ok], rtol=1e-9, atol=1e-12)
+    return float(err[ok].max())

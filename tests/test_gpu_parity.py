@@ -623,3 +623,12 @@ def test_gpu_secondary_controllers_properties_full_size():
     assert np.all(np.isfinite(uo)) and np.max(np.abs(uo)) <= 123.0 and (uo != 0).any()
     perm = np.random.RandomState(5).permutation(B)[:8192]
     assert np.array_equal(be.obstacles(PO, q[perm]), uo[perm])
+
+
+def test_gpu_fuzz_osc_parameter_space():
+    """seeded random controller configurations (ctrlr_dof masks, frames, offsets, vmax, ki, target velocity,
+    fused + external secondary controllers, both orientation algorithms) on random 1..7-joint user arms"""
+    worst = 0.0
+    for fc in cases.fuzz_osc_cases(7, 24) + cases.fuzz_osc_cases(8, 24):
+        worst = max(worst, cases.check_fuzz_case(cases.GpuBackend, fc))
+    assert worst < 1e-6

@@ -272,3 +272,10 @@ def test_rows_secondary_fp32_and_accumulate():
     base = np.full((len(q), 6), 0.25)
     u = hostsim.avoid_obstacles_generate("ur5", P, q, u=base.copy())
     assert np.allclose(u - base, hostsim.avoid_obstacles_generate("ur5", P, q), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("idx", range(24))
+def test_rows_fuzz_osc_parameter_space(idx):
+    """seeded random controller configurations on random user arms (runtime-table row programs) vs the oracle"""
+    fc = cases.fuzz_osc_cases(7, 24)[idx]
+    cases.check_fuzz_case(cases.HostsimBackend, fc)
