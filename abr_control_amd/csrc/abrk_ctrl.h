@@ -209,6 +209,38 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
 // values keep their relative accuracy, which an eigen-decomposition of J J^T would lose.
 template <int K, int N, class T>
 ABRK_INL void pinv_KxN(const T (&J)[N][K] /* J[i][r] = J(r,i) */, T rcond, T (&P)[N][K] /* P[i][r] */) {
+  if constexpr (K <= N) {
+    // Well-conditioned full row rank (the common case along an IK path or a sliding-mode step): pinv(J) =
+    // J^T (J J^T)^-1 through a K x K Cholesky factor.  cond(J J^T) <= trace^K / det; below 1e6 (fp32: 1e2) the
+    // squared conditioning costs at most ~1e-10 (1e-5) relative and nothing is truncated at rcond = 1e-15.
+    T A[K * (K + 1) / 2], L[K * (K + 1) / 2], il[K], trace = T(0);
+    sfor<K>([&](auto r) ABRK_LAMBDA {
+      sfor<r() + 1>([&](auto c) ABRK_LAMBDA {
+        T acc = T(-0.0);
+        sfor<N>([&](auto i) ABRK_LAMBDA { acc += J[i()][r()] * J[i()][c()]; });
+        A[tri(r(), c())] = acc;
+      });
+      trace += A[tri(r(), r())];
+    });
+    bool ok = chol<K>(A, L, il);
+    T det = T(1), tk = T(1);
+    sfor<K>([&](auto r) ABRK_LAMBDA {
+      det *= L[tri(r(), r())] * L[tri(r(), r())];
+      tk *= trace;
+    });
+    if (ok && tk < det * (sizeof(T) == 8 ? T(1e6) : T(1e2))) {
+      T Ai[K * (K + 1) / 2];
+      chol_inverse<K>(L, il, Ai);
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        sfor<K>([&](auto r) ABRK_LAMBDA {
+          T acc = T(-0.0);
+          sfor<K>([&](auto c) ABRK_LAMBDA { acc += J[i()][c()] * Ai[tri(c(), r())]; });
+          P[i()][r()] = acc;
+        });
+      });
+      return;
+    }
+  }
   T G[N][K];
   T V[K][K];
   sfor<N>([&](auto i) ABRK_LAMBDA { sfor<K>([&](auto r) ABRK_LAMBDA { G[i()][r()] = J[i()][r()]; }); });
