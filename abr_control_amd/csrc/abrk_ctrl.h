@@ -482,7 +482,7 @@ ABRK_INL void null_command(const NullP<T>& c, const T (&q)[N], const T (&dq)[N],
 }
 
 // ---------------------------------------------------------------- OSC.generate, one row
-// KM = 3 (FAST: task rows are exactly x,y,z of the EE) or 6 (all six task rows, unselected
+// KM = 3 or 2 (FAST: task rows are exactly x,y,z / x,y of the EE) or 6 (all six task rows, unselected
 // rows masked: their Jacobian row is zeroed and Mx_inv gets a unit diagonal there, which
 // leaves det, the inverse and the singular values of the selected block unchanged).
 //
@@ -497,7 +497,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
                       const T (&RF)[9], const T (&q)[N], const T (&dq)[N], const T (&tgt)[6], bool tv_given,
                       const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext, const T (&une)[N],
                       T (&u)[N], T (&ts)[N]) {
-  constexpr bool FAST = (KM == 3);
+  constexpr bool FAST = (KM <= 3);
   T Jr[N][KM];
   bool sel[KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA {
@@ -682,7 +682,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
                       bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
                       const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late) {
   constexpr int N = A::N;
-  constexpr bool FAST = (KM == 3);
+  constexpr bool FAST = (KM <= 3);
   Joints<A, T> jt;
   Dyn<A, T, USE_C ? CMODE_VEC : CMODE_NONE> d;
   T XR[9], xo[3];

@@ -523,7 +523,7 @@ extern "C" int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_par
   oa.u = st.fix(u_, u);
   oa.ts = st.fix(ts_, training_signal);
   oa.use_C = P->use_C ? 1 : 0;
-  oa.fast = osc_is_fast(*P, n, u_null_ext != nullptr);
+  oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
   OscP<double> p64;
   OscP<float> p32;
   if (dtype == ABRK_F64) {
@@ -878,6 +878,7 @@ extern "C" int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_
   if (int rc = st.reserve()) return rc;
   RolloutArgs ra;
   ra.use_C = P->use_C ? 1 : 0;
+  ra.fast = osc_fast_rows(*P, n, false);
   ra.n_steps = n_steps;
   ra.every = every;
   ra.q = st.fix(q_, q);
@@ -970,7 +971,7 @@ extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params
   pl->oa.u = u;
   pl->oa.ts = training_signal;
   pl->oa.use_C = P->use_C ? 1 : 0;
-  pl->oa.fast = osc_is_fast(*P, n, u_null_ext != nullptr);
+  pl->oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
   pl->la = LaunchArgs{a->builtin ? nullptr : (const void*)pl->rt.data(), (long)B, (hipStream_t)stream};
   std::lock_guard<std::mutex> lk(g_plan_mu);
   if (g_n_plans >= kMaxPlans) {

@@ -74,7 +74,7 @@ dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, con
 #define ABRK_FEAT1_TWO_WAVES 1
 #endif
 constexpr int osc_min_waves(int km, bool use_c, int feat) {
-  return (km == 3 && !use_c && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES))) ? 2 : ABRK_MIN_WAVES;
+  return (km <= 3 && !use_c && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES))) ? 2 : ABRK_MIN_WAVES;
 }
 
 template <class A, class T, int KM, bool USE_C, int FEAT>
@@ -121,13 +121,13 @@ struct LaunchArgs {
   long B;
   hipStream_t stream;
 };
-template <class A, class T, bool USE_C>
+template <class A, class T, bool USE_C, int KM>
 __global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 rollout_kernel(A arm, OscP<T> P, TwoLinkP<T> K, long B, int n_steps, int every, T* __restrict__ qg,
                T* __restrict__ dqg, const T* __restrict__ tg, T* __restrict__ ierrg, T* __restrict__ qt,
                T* __restrict__ dqt, T* __restrict__ ut) {
   ABRK_ROW_INDEX
-  rollout_body<A, T, USE_C>(b, arm, P, K, B, n_steps, every, qg, dqg, tg, ierrg, qt, dqt, ut);
+  rollout_body<A, T, USE_C, KM>(b, arm, P, K, B, n_steps, every, qg, dqg, tg, ierrg, qt, dqt, ut);
 }
 
 template <class T>
@@ -190,7 +190,7 @@ struct IkArgs {
 
 struct RolloutArgs {
   const void *P, *K;  // OscP<T>, TwoLinkP<T>
-  int use_C, n_steps, every;
+  int use_C, fast, n_steps, every;
   void *q, *dq;
   const void* target;
   void *ierr, *qt, *dqt, *ut;
@@ -212,7 +212,7 @@ struct DynArgs {
 };
 struct OscArgs {
   const void* P;  // OscP<T>
-  int fast, use_C;
+  int fast, use_C;  // fast: 0 general six-row kernel, 2 / 3: first two / three position rows of the EE
   const void *q, *dq, *target, *tv, *une;
   void *ierr, *u, *ts;
 };
@@ -275,9 +275,14 @@ struct Launch {
     else osc_launch<KM, UC, 0>(la, a);
   }
   static hipError_t osc(const LaunchArgs& la, const OscArgs& a) {
-    if (a.fast) {
+    if (a.fast == 3) {
       if (a.use_C) osc_launch_feat<3, true>(la, a);
       else osc_launch_feat<3, false>(la, a);
+    } else if (a.fast == 2 && A::N <= 3) {
+      if constexpr (A::N <= 3) {
+        if (a.use_C) osc_launch_feat<2, true>(la, a);
+        else osc_launch_feat<2, false>(la, a);
+      }
     } else {
       if (a.use_C) osc_launch_feat<6, true>(la, a);
       else osc_launch_feat<6, false>(la, a);
@@ -317,14 +322,19 @@ struct OpsFor {
   static hipError_t rollout_t(const LaunchArgs& la, const RolloutArgs& a) {
     if constexpr (A::N == 2) {
       A arm = Launch<A, T>::arm_of(la);
-      if (a.use_C)
-        hipLaunchKernelGGL((rollout_kernel<A, T, true>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm,
+      auto go = [&](auto uc, auto km) {
+        hipLaunchKernelGGL((rollout_kernel<A, T, uc(), km()>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm,
                            *static_cast<const OscP<T>*>(a.P), *static_cast<const TwoLinkP<T>*>(a.K), la.B, a.n_steps,
                            a.every, (T*)a.q, (T*)a.dq, (const T*)a.target, (T*)a.ierr, (T*)a.qt, (T*)a.dqt, (T*)a.ut);
-      else
-        hipLaunchKernelGGL((rollout_kernel<A, T, false>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm,
-                           *static_cast<const OscP<T>*>(a.P), *static_cast<const TwoLinkP<T>*>(a.K), la.B, a.n_steps,
-                           a.every, (T*)a.q, (T*)a.dq, (const T*)a.target, (T*)a.ierr, (T*)a.qt, (T*)a.dqt, (T*)a.ut);
+      };
+      using std::integral_constant;
+      if (a.fast == 2) {
+        if (a.use_C) go(integral_constant<bool, true>{}, integral_constant<int, 2>{});
+        else go(integral_constant<bool, false>{}, integral_constant<int, 2>{});
+      } else {
+        if (a.use_C) go(integral_constant<bool, true>{}, integral_constant<int, 6>{});
+        else go(integral_constant<bool, false>{}, integral_constant<int, 6>{});
+      }
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;

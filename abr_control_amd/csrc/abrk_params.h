@@ -102,11 +102,16 @@ inline ObsP<T> make_obsp(const abrk_obstacles_params& s) {
   return p;
 }
 
-// the FAST OSC kernel applies when the task rows are exactly x,y,z of the end-effector
-inline bool osc_is_fast(const abrk_osc_params& P, int n, bool has_ext) {
+// The FAST OSC kernels apply when the task rows are exactly the first k position rows of the end-effector:
+// k = 3 (x,y,z) for every arm, k = 2 (x,y - the planar examples, examples/PyGame/force_osc_xy.py:36-41) for
+// arms of up to three joints.  Returns k, or 0 for the general (masked six-row) kernel.
+inline int osc_fast_rows(const abrk_osc_params& P, int n, bool has_ext) {
   int k = 0;
   for (int r = 0; r < 6; r++) k += P.ctrlr_dof[r] ? 1 : 0;
-  return P.ctrlr_dof[0] && P.ctrlr_dof[1] && P.ctrlr_dof[2] && k == 3 && P.ref_frame == 2 * n + 1 && !has_ext;
+  if (P.ref_frame != 2 * n + 1 || has_ext) return 0;
+  if (k == 3 && P.ctrlr_dof[0] && P.ctrlr_dof[1] && P.ctrlr_dof[2]) return 3;
+  if (k == 2 && P.ctrlr_dof[0] && P.ctrlr_dof[1] && n <= 3) return 2;
+  return 0;
 }
 
 }  // namespace abrk

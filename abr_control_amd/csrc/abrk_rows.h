@@ -294,7 +294,7 @@ ABRK_INL void obstacles_body(long b, const A& arm, const ObsP<T>& P, const T* __
 
 // ---- closed loop: n_steps x { OSC.generate ; ArmSim._step } with the state kept in registers
 // (examples/PyGame/force_osc_xy.py:57-78).  Two-joint arms only.
-template <class A, class T, bool USE_C>
+template <class A, class T, bool USE_C, int KM>
 ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLinkP<T>& K, long B, int n_steps, int every,
                            T* __restrict__ qg, T* __restrict__ dqg, const T* __restrict__ tg, T* __restrict__ ierrg,
                            T* __restrict__ qt, T* __restrict__ dqt, T* __restrict__ ut) {
@@ -311,7 +311,7 @@ ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLink
   const int n_chk = every > 0 ? n_steps / every : 0;
   int chk = 0, until = every;
   for (int t = 0; t < n_steps; t++) {
-    osc_row<A, T, 6, USE_C, 2>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {});
+    osc_row<A, T, KM, USE_C, 2>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {});
     twolink_step(K, q, dq, u);
     if (every > 0 && --until == 0) {
       until = every;

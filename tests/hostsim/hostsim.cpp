@@ -52,7 +52,7 @@ template <class A, class T>
 int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void* q, const void* dq,
             const void* tg, const void* tv, void* ie, const void* une, void* u, void* ts) {
   OscP<T> p = make_oscp<T>(*P, n);
-  bool fast = osc_is_fast(*P, n, une != nullptr);
+  int fast = osc_fast_rows(*P, n, une != nullptr);
   if (P->ki == 0) ie = nullptr;
   const int feat = (tv || ie || une) ? 2 : (p.n_null > 0 ? 1 : 0);  // same dispatch rule as Launch::osc_launch_feat
   for (long b = 0; b < B; b++) {
@@ -65,8 +65,12 @@ int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void
     else if (feat == 1) CALL1(KM, UC, 1); \
     else CALL1(KM, UC, 0);                \
   } while (0)
-    if (fast) {
+    if (fast == 3) {
       if (P->use_C) CALL(3, true); else CALL(3, false);
+    } else if (fast == 2) {
+      if constexpr (A::N <= 3) {
+        if (P->use_C) CALL(2, true); else CALL(2, false);
+      }
     } else {
       if (P->use_C) CALL(6, true); else CALL(6, false);
     }
@@ -264,12 +268,16 @@ extern "C" int hostsim_rollout(const char* builtin, const abrk_arm_desc* d, int 
       OscP<T> p = make_oscp<T>(*P, n);
       TwoLinkP<T> k{T(plant->K1), T(plant->K2), T(plant->K3), T(plant->K4), T(plant->dt)};
       for (long b = 0; b < B; b++) {
-        if (P->use_C)
-          rollout_body<A, T, true>(b, a, p, k, (long)B, n_steps, every, (T*)q, (T*)dq, (const T*)tg, (T*)nullptr, (T*)qt,
-                                   (T*)dqt, (T*)ut);
-        else
-          rollout_body<A, T, false>(b, a, p, k, (long)B, n_steps, every, (T*)q, (T*)dq, (const T*)tg, (T*)nullptr,
-                                    (T*)qt, (T*)dqt, (T*)ut);
+        const bool xy = osc_fast_rows(*P, n, false) == 2;
+#define ROLL(UC, KM)                                                                                            \
+  rollout_body<A, T, UC, KM>(b, a, p, k, (long)B, n_steps, every, (T*)q, (T*)dq, (const T*)tg, (T*)nullptr, (T*)qt, \
+                             (T*)dqt, (T*)ut)
+        if (xy) {
+          if (P->use_C) ROLL(true, 2); else ROLL(false, 2);
+        } else {
+          if (P->use_C) ROLL(true, 6); else ROLL(false, 6);
+        }
+#undef ROLL
       }
       return 0;
     } else {

@@ -632,3 +632,23 @@ def test_gpu_fuzz_osc_parameter_space():
     for fc in cases.fuzz_osc_cases(7, 24) + cases.fuzz_osc_cases(8, 24):
         worst = max(worst, cases.check_fuzz_case(cases.GpuBackend, fc))
     assert worst < 1e-6
+
+
+@pytest.mark.parametrize("arm", ["twojoint", "threejoint"])
+def test_gpu_xy_fast_kernel_equals_general_kernel(arm):
+    """x,y control on arms of <= 3 joints runs the two-row kernel; a zero external null signal forces the masked
+    six-row kernel on the same inputs"""
+    for variant in ("static", "rt"):
+        be = cases.GpuBackend(arm, variant)
+        n = be.n
+        rng = np.random.RandomState(3)
+        B = 3000
+        q, dq, t = rng.uniform(0, 6.28, (B, n)), rng.uniform(-3, 3, (B, n)), rng.uniform(-1, 1, (B, 6))
+        for kw in (dict(kp=20, kv=5), dict(kp=20, kv=5, vmax=[0.5, 0.5], use_C=True, xyz_offset=[0.1, -0.05, 0.0]),
+                   dict(kp=30, ki=0.2, null_controllers=[cases.make_damping(4)])):
+            p = cases.P(n, ctrlr_dof=cases.XY, **kw)
+            ie1 = np.zeros((B, 6)) if kw.get("ki") else None
+            ie2 = np.zeros((B, 6)) if kw.get("ki") else None
+            u1, ts1 = be.osc(p, q, dq, t, ie=ie1)
+            u2, ts2 = be.osc(p, q, dq, t, ie=ie2, une=np.zeros((B, n)))
+            assert np.allclose(u1, u2, rtol=1e-10, atol=1e-10) and np.allclose(ts1, ts2, rtol=1e-10, atol=1e-10)

@@ -279,3 +279,24 @@ def test_rows_fuzz_osc_parameter_space(idx):
     """seeded random controller configurations on random user arms (runtime-table row programs) vs the oracle"""
     fc = cases.fuzz_osc_cases(7, 24)[idx]
     cases.check_fuzz_case(cases.HostsimBackend, fc)
+
+
+@pytest.mark.parametrize("arm", ["twojoint", "threejoint"])
+def test_rows_xy_fast_kernel_equals_general_kernel(arm):
+    """ctrlr_dof = x,y on arms of <= 3 joints runs a two-row kernel; a zero external null signal forces the
+    masked six-row kernel on the same inputs (target z != 0 enters the vmax norm, osc.py:198-215, in both)"""
+    be = cases.HostsimBackend(arm)
+    n = be.n
+    rng = np.random.RandomState(3)
+    B = 200
+    q, dq, t = rng.uniform(0, 6.28, (B, n)), rng.uniform(-3, 3, (B, n)), rng.uniform(-1, 1, (B, 6))
+    for kw in (dict(kp=20, kv=5), dict(kp=20, kv=5, vmax=[0.5, 0.5], use_C=True, xyz_offset=[0.1, -0.05, 0.0]),
+               dict(kp=30, ki=0.2, null_controllers=[cases.make_damping(4)])):
+        p = cases.P(n, ctrlr_dof=cases.XY, **kw)
+        ie1 = np.zeros((B, 6)) if kw.get("ki") else None
+        ie2 = np.zeros((B, 6)) if kw.get("ki") else None
+        u1, ts1 = be.osc(p, q, dq, t, ie=ie1)
+        u2, ts2 = be.osc(p, q, dq, t, ie=ie2, une=np.zeros((B, n)))
+        assert np.allclose(u1, u2, rtol=1e-11, atol=1e-11) and np.allclose(ts1, ts2, rtol=1e-11, atol=1e-11)
+        if ie1 is not None:
+            assert np.allclose(ie1, ie2, rtol=0, atol=1e-14)
