@@ -6,6 +6,10 @@
 #pragma once
 #include "abrk_device.h"
 
+#ifndef ABRK_C_TWO_PASS
+#define ABRK_C_TWO_PASS 1
+#endif
+
 namespace abrk {
 
 // ---------------------------------------------------------------- device-side parameter blocks
@@ -481,6 +485,14 @@ ABRK_INL void null_command(const NullP<T>& c, const T (&q)[N], const T (&dq)[N],
   }
 }
 
+// value the optimiser must treat as unknown from here on (device code only; the host check build does not care)
+template <class T>
+ABRK_INL void opaque(T& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#endif
+}
+
 // ---------------------------------------------------------------- OSC.generate, one row
 // KM = 3 or 2 (FAST: task rows are exactly x,y,z / x,y of the EE) or 6 (all six task rows, unselected
 // rows masked: their Jacobian row is zeroed and Mx_inv gets a unit diagonal there, which
@@ -683,12 +695,46 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
                       const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late) {
   constexpr int N = A::N;
   constexpr bool FAST = (KM <= 3);
+  // OSC(use_C) on orthogonal chains in two passes over the same state (ABRK_C_TWO_PASS): first the Coriolis vector
+  // alone (body recursion; keeps sin/cos), then the plain dynamics pass from the kept sin/cos.  The second forward
+  // kinematics costs ~90 instructions; in exchange the register peak stays at the plain law's level (two waves per
+  // SIMD instead of one with 144 parked registers).
+  constexpr bool TWO_PASS = USE_C && A::kOrtho && FAST && (ABRK_C_TWO_PASS != 0);
   Joints<A, T> jt;
-  Dyn<A, T, USE_C ? CMODE_VEC : CMODE_NONE> d;
+  Dyn<A, T, (USE_C && !TWO_PASS) ? CMODE_VEC : CMODE_NONE> d;
   T XR[9], xo[3];
   T p[3], RF[9];
+  T cv2[TWO_PASS ? N : 1], sv[TWO_PASS ? N : 1][2];
   int m = N;
-  if constexpr (FAST) {
+  if constexpr (TWO_PASS) {
+    {
+      Joints<A, T> jt1;
+      Dyn<A, T, CMODE_CVONLY> d1;
+      T XR1[9], xo1[3];
+      NoCap nc1;
+      kin_dyn_hook(arm, q, dq, jt1, d1, XR1, xo1, nc1, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScSave<T, N>{sv});
+      sfor<N>([&](auto i) ABRK_LAMBDA { cv2[i()] = d1.cv[i()]; });
+    }
+    // the second pass must not be merged with the first (that would keep both register sets alive)
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      opaque(sv[i()][0]);
+      opaque(sv[i()][1]);
+      opaque(cv2[i()]);
+    });
+    NoCap nc;
+    T zero[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { zero[i()] = T(0); });
+    kin_dyn_hook(arm, q, zero, jt, d, XR, xo, nc, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScUse<T, N>{sv});
+    if (P.has_off) {
+      T oe[3];
+      mulBE<A, T>(arm, XR, xo, RF, oe);
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        p[r()] = oe[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
+      });
+    } else {
+      mulBE_pt<A, T>(arm, XR, xo, p);
+    }
+  } else if constexpr (FAST) {
     NoCap nc;
     kin_dyn(arm, q, dq, jt, d, XR, xo, nc);
     if (P.has_off) {
@@ -717,7 +763,10 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   jacobian(jt, p, m, Jv, Jw);
   ABRK_SCHED_FENCE();
   late();
-  if constexpr (USE_C)
+  if constexpr (TWO_PASS)
+    osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
+                                  ierr, have_ext, une, u, ts);
+  else if constexpr (USE_C)
     osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
                                   ierr, have_ext, une, u, ts);
   else  // no Coriolis vector: the slot is not read (d.gz stands in for the array type)

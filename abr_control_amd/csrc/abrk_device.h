@@ -420,9 +420,35 @@ struct NoCap {};
 // ur5/config.py:301-339).  For i = 0..N-1: records joint_i (z, o, W), rotates by q_i,
 // calls on_link(ic<i+1>, p) with the COM position of link_{i+1}.  Leaves in (XR, xo) the
 // rotation of joint_{N-1} after its Rz and its origin - the EE hangs off that.
-template <class A, class T, class Cap, class LinkFn>
+// Where sin/cos of the joint angles come from: computed (default), computed and kept, or taken from a
+// previous pass over the same state.
+struct ScCompute {
+  template <int I, class T>
+  ABRK_INL void get(T q, T& s, T& c) const { Rm<T>::sincos(q, s, c); }
+};
+template <class T, int N>
+struct ScSave {
+  T (&sv)[N][2];
+  template <int I>
+  ABRK_INL void get(T q, T& s, T& c) const {
+    Rm<T>::sincos(q, s, c);
+    sv[I][0] = s;
+    sv[I][1] = c;
+  }
+};
+template <class T, int N>
+struct ScUse {
+  const T (&sv)[N][2];
+  template <int I>
+  ABRK_INL void get(T, T& s, T& c) const {
+    s = sv[I][0];
+    c = sv[I][1];
+  }
+};
+
+template <class A, class T, class Cap, class LinkFn, class Sc = ScCompute>
 ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (&XR)[9], T (&xo)[3],
-                         Cap& cap, LinkFn&& on_link) {
+                         Cap& cap, LinkFn&& on_link, const Sc& scp = Sc{}) {
   constexpr int N = A::N;
   T Rj[9], oj[3];
   sfor<3>([&](auto r) ABRK_LAMBDA {
@@ -465,7 +491,7 @@ ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (
     }
     // ---- rotate about local z by q_I:  X = joint_I * Rz(q_I)
     T s, c;
-    Rm<T>::sincos(q[I], s, c);
+    scp.template get<I>(q[I], s, c);
     sfor<3>([&](auto r) ABRK_LAMBDA {
       T a0 = Rj[r() * 3 + 0], a1 = Rj[r() * 3 + 1];
       XR[r() * 3 + 0] = c * a0 + s * a1;
@@ -500,7 +526,9 @@ ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (
 // Lower-triangular index of a symmetric N x N matrix
 constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-enum { CMODE_NONE = 0, CMODE_VEC = 1, CMODE_MAT = 2 };
+// CMODE_CVONLY: only the Coriolis vector of an orthogonal chain (no M, no g) - the first of two passes of the
+// OSC(use_C) law, which keeps the register peak of the dynamics pass proper at the plain law's level
+enum { CMODE_NONE = 0, CMODE_VEC = 1, CMODE_MAT = 2, CMODE_CVONLY = 3 };
 
 template <class A, class T, int CMODE>
 struct Dyn {
@@ -508,7 +536,7 @@ struct Dyn {
   T Ms[N * (N + 1) / 2];                  // M, lower triangle            (base_config.py:594-645)
   T gz[N];                                // sum_l m_l,z * dp_l,z/dq_i    (g = -9.81 gz, base_config.py:417-468)
   T Cm[CMODE == CMODE_MAT ? N * N : 1];   // Christoffel matrix           (base_config.py:678-727)
-  T cv[CMODE == CMODE_VEC ? N : 1];       // C(q,dq) dq
+  T cv[(CMODE == CMODE_VEC || CMODE == CMODE_CVONLY) ? N : 1];  // C(q,dq) dq
   T om[CMODE != CMODE_NONE ? N : 1][3];   // omega_j = sum_{k<j} dq_k z_k  (orthogonal chains, matrix mode)
   // CMODE_VEC on orthogonal chains: kinematic state of the body the current link belongs to -
   // angular velocity, bias angular acceleration, bias acceleration of the last joint origin
@@ -516,7 +544,7 @@ struct Dyn {
 };
 // the recursive Coriolis-vector path (below) replaces the omega prefix sums
 template <class A, int CM>
-constexpr bool kRecursiveC = (CM == CMODE_VEC) && A::kOrtho;
+constexpr bool kRecursiveC = (CM == CMODE_VEC || CM == CMODE_CVONLY) && A::kOrtho;
 
 // does link L carry linear / any mass?  (static arms: compile time; user arms: assume yes)
 template <class A, int L>
@@ -568,11 +596,13 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
     wapply<i()>(jt, dlt, e[i()]);
   });
   T m0 = AccMD<A, T, L, 0>::get(arm), m1 = AccMD<A, T, L, 1>::get(arm), m2 = AccMD<A, T, L, 2>::get(arm);
-  sfor<NJ>([&](auto i) ABRK_LAMBDA {
-    T me[3] = {m0 * e[i()][0], m1 * e[i()][1], m2 * e[i()][2]};  // D_l e_i (transient)
-    d.gz[i()] += me[2];
-    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = fdot3(d.Ms[tri(i(), j())], me, e[j()]); });
-  });
+  if constexpr (CM != CMODE_CVONLY) {
+    sfor<NJ>([&](auto i) ABRK_LAMBDA {
+      T me[3] = {m0 * e[i()][0], m1 * e[i()][1], m2 * e[i()][2]};  // D_l e_i (transient)
+      d.gz[i()] += me[2];
+      sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = fdot3(d.Ms[tri(i(), j())], me, e[j()]); });
+    });
+  }
   if constexpr (kRecursiveC<A, CM>) {
     // C(q,dq) dq, linear part = sum_l E_l^T D_l a_l with a_l the bias (qdd = 0) acceleration of the COM,
     // from the body recursion instead of per-link suffix sums:
@@ -669,7 +699,7 @@ ABRK_INL void dyn_init(Dyn<A, T, CM>& d) {
   sfor<N*(N + 1) / 2>([&](auto e) ABRK_LAMBDA { d.Ms[e()] = T(-0.0); });  // -0.0: exact additive identity, lets the first fma fold to a mul
   sfor<N>([&](auto i) ABRK_LAMBDA { d.gz[i()] = T(-0.0); });
   if constexpr (CM == CMODE_MAT) sfor<N * N>([&](auto e) ABRK_LAMBDA { d.Cm[e()] = T(-0.0); });
-  if constexpr (CM == CMODE_VEC) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(-0.0); });
+  if constexpr (CM == CMODE_VEC || CM == CMODE_CVONLY) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(-0.0); });
 }
 
 // weighted dot  sum_r Isuf(m,r) a[r] b[r]
@@ -684,6 +714,7 @@ ABRK_INL T idot(const A& arm, const T (&a)[3], const T (&b)[3], T acc = T(-0.0))
 template <class A, class T, int CM>
 ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
   constexpr int N = A::N;
+  if constexpr (CM == CMODE_CVONLY) return;
   sfor<N>([&](auto i) ABRK_LAMBDA {
     sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = idot<i()>(arm, jt.z[i()], jt.z[j()], d.Ms[tri(i(), j())]); });
   });
@@ -763,9 +794,9 @@ ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, 
 // FK + M, g (+C).  Returns joint state for Jacobians; (XR, xo) = last rotated joint frame.
 // `extra(ic<l>, p)` runs once per link l = 1..N (p = origin of its frame) while XR still holds the
 // rotation of joint_{l-1} after its Rz - callers that need per-link frames hook in here.
-template <class A, class T, int CM, class Cap, class Extra>
+template <class A, class T, int CM, class Cap, class Extra, class Sc = ScCompute>
 ABRK_INL void kin_dyn_hook(const A& arm, const T (&q)[A::N], const T (&dq)[A::N], Joints<A, T>& jt,
-                           Dyn<A, T, CM>& d, T (&XR)[9], T (&xo)[3], Cap& cap, Extra&& extra) {
+                           Dyn<A, T, CM>& d, T (&XR)[9], T (&xo)[3], Cap& cap, Extra&& extra, const Sc& scp = Sc{}) {
   dyn_init(d);
   fk_forward(arm, q, jt, XR, xo, cap, [&](auto L, const T(&p)[3]) ABRK_LAMBDA {
     omega_advance<L()>(jt, dq, d);
@@ -773,7 +804,7 @@ ABRK_INL void kin_dyn_hook(const A& arm, const T (&q)[A::N], const T (&dq)[A::N]
     link_accumulate<L()>(arm, jt, dq, p, d);
     angular_link_coriolis<L()>(arm, jt, d);
     extra(L, p);
-  });
+  }, scp);
   angular_finish(arm, jt, dq, d);
 }
 template <class A, class T, int CM, class Cap>

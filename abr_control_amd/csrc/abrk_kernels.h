@@ -70,15 +70,21 @@ dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, con
 // (xyz kernel) asked to fit two waves per SIMD (<= 256 VGPRs; measured +6 % on Jaco2 whose general-chain state would
 // otherwise take 256 + 18 parked registers); the heavier variants keep the full budget - forcing them
 // under 256 spills hundreds of bytes per lane and loses 2-3x (measured).
+#ifndef ABRK_C_TWO_WAVES
+#define ABRK_C_TWO_WAVES ABRK_C_TWO_PASS
+#endif
 #ifndef ABRK_FEAT1_TWO_WAVES
 #define ABRK_FEAT1_TWO_WAVES 1
 #endif
-constexpr int osc_min_waves(int km, bool use_c, int feat) {
-  return (km <= 3 && !use_c && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES))) ? 2 : ABRK_MIN_WAVES;
+// (use_C: only the two-pass form of orthogonal chains, abrk_ctrl.h osc_row, fits the two-wave budget)
+constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho) {
+  return (km <= 3 && (!use_c || (ABRK_C_TWO_WAVES && ortho)) && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES)))
+             ? 2
+             : ABRK_MIN_WAVES;
 }
 
 template <class A, class T, int KM, bool USE_C, int FEAT>
-__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT))
+__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
