@@ -698,8 +698,8 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   // OSC(use_C) on orthogonal chains in two passes over the same state (ABRK_C_TWO_PASS): first the Coriolis vector
   // alone (body recursion; keeps sin/cos), then the plain dynamics pass from the kept sin/cos.  The second forward
   // kinematics costs ~90 instructions; in exchange the register peak stays at the plain law's level (two waves per
-  // SIMD instead of one with 144 parked registers).
-  constexpr bool TWO_PASS = USE_C && A::kOrtho && FAST && (ABRK_C_TWO_PASS != 0);
+  // SIMD instead of one with 144 parked registers; the six-row kernels stop spilling).
+  constexpr bool TWO_PASS = USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0);
   Joints<A, T> jt;
   Dyn<A, T, (USE_C && !TWO_PASS) ? CMODE_VEC : CMODE_NONE> d;
   T XR[9], xo[3];
@@ -721,22 +721,16 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
       opaque(sv[i()][1]);
       opaque(cv2[i()]);
     });
+  }
+  auto dynamics_pass = [&](auto& cap_) ABRK_LAMBDA {
+    if constexpr (TWO_PASS)
+      kin_dyn_hook(arm, q, dq, jt, d, XR, xo, cap_, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScUse<T, N>{sv});
+    else
+      kin_dyn(arm, q, dq, jt, d, XR, xo, cap_);
+  };
+  if constexpr (FAST) {
     NoCap nc;
-    T zero[N];
-    sfor<N>([&](auto i) ABRK_LAMBDA { zero[i()] = T(0); });
-    kin_dyn_hook(arm, q, zero, jt, d, XR, xo, nc, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScUse<T, N>{sv});
-    if (P.has_off) {
-      T oe[3];
-      mulBE<A, T>(arm, XR, xo, RF, oe);
-      sfor<3>([&](auto r) ABRK_LAMBDA {
-        p[r()] = oe[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
-      });
-    } else {
-      mulBE_pt<A, T>(arm, XR, xo, p);
-    }
-  } else if constexpr (FAST) {
-    NoCap nc;
-    kin_dyn(arm, q, dq, jt, d, XR, xo, nc);
+    dynamics_pass(nc);
     if (P.has_off) {
       T oe[3];
       mulBE<A, T>(arm, XR, xo, RF, oe);
@@ -751,7 +745,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     cap.frame = P.ref_frame;
     sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = T(0); });
     sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = T(0); });
-    kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
+    dynamics_pass(cap);
     sfor<9>([&](auto e) ABRK_LAMBDA { RF[e()] = cap.R[e()]; });
     sfor<3>([&](auto r) ABRK_LAMBDA {
       p[r()] = cap.o[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];

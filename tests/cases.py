@@ -472,3 +472,41 @@ def check_fuzz_case(backend_factory, fc, B=96):
     if ie is not None:
         assert np.allclose(ie[ok], ie_o[ok], rtol=1e-9, atol=1e-12)
     return float(err[ok].max())
+
+
+def check_six_row_use_C(backend, arm="ur5", B=400):
+    """orientation control + Coriolis compensation on a built-in (orthogonal-chain) arm vs the oracle: the six-row
+    kernels compute C(q,dq) dq in a pass of their own"""
+    from oracle.oracle import Oracle
+
+    o = Oracle(_abi.load_table(arm))
+    n = o.n
+    rng = np.random.RandomState(17)
+    q, dq, t = rng.uniform(0, 6.28, (B, n)), rng.uniform(-2, 2, (B, n)), rng.uniform(-0.8, 0.8, (B, 6))
+    worst = 0.0
+    for kw in (dict(kp=100, ko=60, kv=12, ctrlr_dof=SIX, use_C=True),
+               dict(kp=100, ko=60, kv=12, ctrlr_dof=[1, 0, 1, 0, 1, 0] if n > 3 else [1, 1, 0, 0, 0, 1], use_C=True,
+                    orientation_algorithm=1,
+                    ref_frame=f"link{n - 1}" if n > 3 else "EE", xyz_offset=[0.05, 0.0, -0.1] if n > 3 else [0.05, 0.1, 0],
+                    null_controllers=[make_damping(5)]),
+               dict(kp=50, ki=0.1, ctrlr_dof=XYZ if n > 3 else XY, use_C=True, vmax=[0.6, 1.0])):
+        if n < 6 and sum(kw["ctrlr_dof"]) > n:
+            continue
+        p = P(n, **kw)
+        ie_o = np.zeros((B, 6)) if kw.get("ki") else None
+        ie = np.zeros((B, 6)) if kw.get("ki") else None
+        uo = o.osc_batch(p, q, dq, t, None, ie_o, None)
+        u, _ = backend.osc(p, q, dq, t, ie=ie)
+        ok = np.ones(B, bool)
+        dof = np.array(kw["ctrlr_dof"], bool)
+        for b in range(B):
+            J = o.J(kw.get("ref_frame", "EE"), q[b], kw.get("xyz_offset"))[dof]
+            A = J @ np.linalg.inv(o.M(q[b])) @ J.T
+            sv = np.linalg.svd(A, compute_uv=False)
+            det = abs(np.linalg.det(A))
+            ok[b] = not (abs(det - 1e-3) < 1e-8 or (det < 1.001e-3 and np.any(np.abs(sv / sv.max() - 1e-4) < 1e-8))
+                         or sv.max() / max(sv.min(), 1e-300) > 1e9)
+        err = rel_err(np.asarray(u, float), uo)[ok].max()
+        assert err <= TOL_D, f"{arm} six-row use_C {kw}: {err:.3e}"
+        worst = max(worst, err)
+    return worst

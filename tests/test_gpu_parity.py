@@ -652,3 +652,9 @@ def test_gpu_xy_fast_kernel_equals_general_kernel(arm):
             u1, ts1 = be.osc(p, q, dq, t, ie=ie1)
             u2, ts2 = be.osc(p, q, dq, t, ie=ie2, une=np.zeros((B, n)))
             assert np.allclose(u1, u2, rtol=1e-10, atol=1e-10) and np.allclose(ts1, ts2, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "threejoint"])
+def test_gpu_six_row_use_C_on_orthogonal_chains(arm):
+    """orientation / arbitrary-row control with Coriolis compensation on built-in arms (two-pass kernels)"""
+    assert cases.check_six_row_use_C(cases.GpuBackend(arm), arm, B=2000) < 1e-6

@@ -300,3 +300,8 @@ def test_rows_xy_fast_kernel_equals_general_kernel(arm):
         assert np.allclose(u1, u2, rtol=1e-11, atol=1e-11) and np.allclose(ts1, ts2, rtol=1e-11, atol=1e-11)
         if ie1 is not None:
             assert np.allclose(ie1, ie2, rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "threejoint"])
+def test_rows_six_row_use_C_on_orthogonal_chains(arm):
+    assert cases.check_six_row_use_C(cases.HostsimBackend(arm), arm) < 1e-6
