@@ -791,7 +791,23 @@ ABRK_INL void sliding_row(const A& arm, const SlidingP<T>& P, const T (&q)[A::N]
     T Jv[N][3], Jw[N][3], dJv[N][3], dJw[N][3], Ji[N][3];
     jacobian(jt, p, P.m_joints, Jv, Jw);
     jacobian_dot(jt, dq, Jv, P.m_joints, dJv, dJw);
-    pinv_3xN<N>(Jv, T(1e-15), Ji);
+    if constexpr (A::kPlanar) {
+      // planar arm: the z row of J[:3] is identically zero, so pinv(J) = [pinv(J[:2]) | 0] - two rows, a single
+      // Jacobi pair (numpy.linalg.pinv drops the zero singular value the same way)
+      T J2[N][2], P2[N][2];
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        J2[i()][0] = Jv[i()][0];
+        J2[i()][1] = Jv[i()][1];
+      });
+      pinv_KxN<2, N, T>(J2, T(1e-15), P2);
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        Ji[i()][0] = P2[i()][0];
+        Ji[i()][1] = P2[i()][1];
+        Ji[i()][2] = T(0);
+      });
+    } else {
+      pinv_3xN<N>(Jv, T(1e-15), Ji);
+    }
     T dx[3], a[3], w[3];
     sfor<3>([&](auto r) ABRK_LAMBDA {
       T acc = T(-0.0);

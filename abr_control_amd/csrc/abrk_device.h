@@ -247,6 +247,18 @@ struct StaticArm {
     return true;
   }
   static constexpr bool kOrtho = compute_ortho();
+  // every static block rotates about z only: all joint axes are the world z axis and the z row of every
+  // linear Jacobian is identically zero (twojoint, threejoint, onejoint)
+  static constexpr bool aff_is_planar(const double* X) {
+    return X[2] == 0.0 && X[6] == 0.0 && X[8] == 0.0 && X[9] == 0.0 && X[10] == 1.0;
+  }
+  static constexpr bool compute_planar() {
+    if (!aff_is_planar(Tab::A0) || (kHasEE && !aff_is_planar(Tab::E))) return false;
+    for (int i = 0; i < N; i++)
+      if (!aff_is_planar(Tab::AJ[i]) || !aff_is_planar(Tab::B[i])) return false;
+    return true;
+  }
+  static constexpr bool kPlanar = compute_planar();
   // joint i's frame is an exact rotation iff every static block before it is (Jaco2: joints 0-2; its later
   // rotation constants are rounded, arms/jaco2/config.py:189-273): W_i is then the cross product with z_i
   // and needs no 3x3 matrix.
@@ -267,6 +279,7 @@ struct RtArm {
   static constexpr int N = NJ;
   static constexpr bool kStatic = false;
   static constexpr bool kOrtho = false;  // always differentiate the general affine chain
+  static constexpr bool kPlanar = false;
   static constexpr bool ortho_joint(int) { return false; }
   int NL;
   T J0v[12];
