@@ -18,7 +18,6 @@ Besides the contract fields the line carries
   cpu_baseline    - the CPU oracle (plain C port of the reference path) on this box's host cores.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
