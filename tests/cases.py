@@ -510,3 +510,59 @@ def check_six_row_use_C(backend, arm="ur5", B=400):
         assert err <= TOL_D, f"{arm} six-row use_C {kw}: {err:.3e}"
         worst = max(worst, err)
     return worst
+
+
+# ---------------------------------------------------------------------------- seeded fuzz: Sliding / Joint / dynamics
+def check_fuzz_other(backend_factory, seed, B=64):
+    """Sliding (Cartesian with frames/offsets/velocity+acceleration targets, joint space), Joint, Damping,
+    RestingConfig and every robot_config output on one random user arm vs the oracle"""
+    from oracle.oracle import Oracle
+    from tests.synthetic_arms import make_arm
+
+    rng = np.random.RandomState(seed)
+    n = int(rng.randint(1, 8))
+    tab = make_arm(n, 5000 + seed, non_orthogonal=bool(rng.randint(2)))
+    o, be = Oracle(tab), backend_factory(tab)
+    q, dq = rng.uniform(-3, 3, (B, n)), rng.uniform(-2, 2, (B, n))
+    frames = ["EE"] + [f"link{i}" for i in range(1, n + 1)] + [f"joint{i}" for i in range(n)]
+    worst = {}
+    # Sliding: the reference's pinv(J[:3]) has rcond 1e-15 - rows whose J[:3] is ill-conditioned amplify rounding on
+    # both sides and are left out
+    frame = frames[rng.randint(len(frames))]
+    off = rng.uniform(-0.2, 0.2, 3).tolist() if rng.randint(2) else None
+    sp = SP(n, kd=float(rng.uniform(5, 200)), lamb=float(rng.uniform(1, 40)), cartesian=True, ref_frame=frame, offset=off)
+    t3 = rng.uniform(-0.6, 0.6, (B, 3))
+    tv, ta = (rng.uniform(-1, 1, (B, 3)), rng.uniform(-1, 1, (B, 3))) if rng.randint(2) else (None, None)
+    uo, so = o.sliding_batch(sp, q, dq, t3, tv, ta)
+    u, s = backend_factory(tab).sliding(sp, q, dq, t3, tv, ta)
+    sv = np.array([np.linalg.svd(o.J(frame, q[b], off)[:3], compute_uv=False) for b in range(B)])
+    rank = (sv > 1e-9 * sv.max(axis=1, keepdims=True)).sum(axis=1)
+    full = rank == rank.max()
+    smin = np.array([sv[b][rank[b] - 1] for b in range(B)])
+    ok = full & (sv.max(axis=1) / smin < 1e4)
+    if ok.sum() >= 8:
+        worst["sliding"] = float(rel_err(np.asarray(u, float), uo)[ok].max())
+        assert worst["sliding"] <= TOL_D and rel_err(np.asarray(s, float), so)[ok].max() <= TOL_D, (seed, n, worst)
+    spj = SP(n, kd=12.0, lamb=3.0, cartesian=False)
+    tn, tvn, tan = rng.uniform(-2, 2, (B, n)), rng.uniform(-1, 1, (B, n)), rng.uniform(-1, 1, (B, n))
+    uo, _ = o.sliding_batch(spj, q, dq, tn, tvn, tan)
+    u, _ = be.sliding(spj, q, dq, tn, tvn, tan)
+    worst["sliding_joint"] = float(rel_err(np.asarray(u, float), uo).max())
+    assert worst["sliding_joint"] <= TOL_D, (seed, n, worst)
+    for name, ctrl, grav, tt, tvv in (("joint", make_joint(30, 6), True, tn, tvn), ("damping", make_damping(7), False, None, None),
+                                      ("resting", make_resting([None if i % 2 else 0.5 * i for i in range(n)], kp=20, kv=4),
+                                       False, None, None)):
+        uo = o.joint_batch(ctrl, grav, q, dq, tt, tvv)
+        u = be.joint(ctrl, grav, q, dq, tt, tvv)
+        worst[name] = float(np.max(np.abs(np.asarray(u, float) - uo)) / max(np.max(np.abs(uo)), 1e-9))
+        assert worst[name] <= 1e-10, (seed, n, worst)
+    f2 = frames[rng.randint(len(frames))]
+    want = ("Tx", "J", "dJ", "M", "g", "C", "R", "T", "Tinv", "quat")
+    r = be.dynamics(q, dq, f2, off, want)
+    ro = OracleBackend.__new__(OracleBackend)
+    ro.o, ro.n = o, n
+    ref = ro.dynamics(q, dq, f2, off, tuple(w for w in want if w not in ("T", "Tinv")))
+    for w, v in ref.items():
+        err = np.max(np.abs(np.asarray(r[w], float) - v)) / max(np.max(np.abs(v)), 1.0)
+        assert err <= 1e-10, (seed, n, f2, w, err)
+    return worst

@@ -658,3 +658,9 @@ def test_gpu_xy_fast_kernel_equals_general_kernel(arm):
 def test_gpu_six_row_use_C_on_orthogonal_chains(arm):
     """orientation / arbitrary-row control with Coriolis compensation on built-in arms (two-pass kernels)"""
     assert cases.check_six_row_use_C(cases.GpuBackend(arm), arm, B=2000) < 1e-6
+
+
+def test_gpu_fuzz_sliding_joint_dynamics():
+    """Sliding / Joint / Damping / RestingConfig / every robot_config output on random 1..7-joint user arms"""
+    for seed in range(16):
+        cases.check_fuzz_other(cases.GpuBackend, seed)

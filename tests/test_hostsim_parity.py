@@ -305,3 +305,8 @@ def test_rows_xy_fast_kernel_equals_general_kernel(arm):
 @pytest.mark.parametrize("arm", ["ur5", "threejoint"])
 def test_rows_six_row_use_C_on_orthogonal_chains(arm):
     assert cases.check_six_row_use_C(cases.HostsimBackend(arm), arm) < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_rows_fuzz_sliding_joint_dynamics(seed):
+    cases.check_fuzz_other(cases.HostsimBackend, seed)
