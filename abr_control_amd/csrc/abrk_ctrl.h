@@ -712,7 +712,8 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
       Dyn<A, T, CMODE_CVONLY> d1;
       T XR1[9], xo1[3];
       NoCap nc1;
-      kin_dyn_hook(arm, q, dq, jt1, d1, XR1, xo1, nc1, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScSave<T, N>{sv});
+      sincos_all<N>(q, sv);
+      kin_dyn_hook(arm, q, dq, jt1, d1, XR1, xo1, nc1, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScUse<T, N>{sv});
       sfor<N>([&](auto i) ABRK_LAMBDA { cv2[i()] = d1.cv[i()]; });
     }
     // the second pass must not be merged with the first (that would keep both register sets alive)

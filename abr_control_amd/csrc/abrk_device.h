@@ -38,6 +38,10 @@
 #define ABRK_SCHED_FENCE() ((void)0)
 #endif
 
+#ifndef ABRK_SINCOS_AHEAD
+#define ABRK_SINCOS_AHEAD 1
+#endif
+
 namespace abrk {
 
 // ---------------------------------------------------------------- compile-time loops
@@ -75,10 +79,15 @@ struct Rm<double> {
   // against ~65 on the main path of the library sincos (whose double-double reduction serves
   // |x| up to 2^1024).  Absolute error <= 1.2e-16; larger arguments take the library path.
   static ABRK_INL void sincos(double x, double& s, double& c) {
-    if (!(::fabs(x) < 1.0e5)) {
+    if (!sincos_in_range(x)) {
       ::sincos(x, &s, &c);
       return;
     }
+    sincos_fast(x, s, c);
+  }
+  static ABRK_INL bool sincos_in_range(double x) { return ::fabs(x) < 1.0e5; }
+  // the branch-free main path (valid for |x| < 1e5)
+  static ABRK_INL void sincos_fast(double x, double& s, double& c) {
     const double n = ::rint(x * 0.6366197723675814);
     double r = ::fma(-n, 1.5707963267948966, x);
     r = ::fma(-n, 6.123233995736766e-17, r);
@@ -142,6 +151,8 @@ struct Rm<double> {
 template <>
 struct Rm<float> {
   static ABRK_INL void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }  // a custom routine measured no faster
+  static ABRK_INL bool sincos_in_range(float) { return true; }
+  static ABRK_INL void sincos_fast(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
   static ABRK_INL float sqrt(float x) { return ::sqrtf(x); }
   static ABRK_INL float fabs(float x) { return ::fabsf(x); }
   static ABRK_INL float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
@@ -458,6 +469,19 @@ struct ScUse {
     c = sv[I][1];
   }
 };
+
+// sin/cos of all joint angles ahead of the chain: one straight-line block of N independent polynomial
+// evaluations (the per-joint range check would split the forward kinematics into N basic blocks and serialise
+// them); angles beyond the fast routine's range are redone by the library afterwards (one rarely taken branch)
+template <int N, class T>
+ABRK_INL void sincos_all(const T (&q)[N], T (&sv)[N][2]) {
+  bool all_in = true;
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    all_in = all_in && Rm<T>::sincos_in_range(q[i()]);
+    Rm<T>::sincos_fast(q[i()], sv[i()][0], sv[i()][1]);
+  });
+  if (!all_in) sfor<N>([&](auto i) ABRK_LAMBDA { Rm<T>::sincos(q[i()], sv[i()][0], sv[i()][1]); });
+}
 
 template <class A, class T, class Cap, class LinkFn, class Sc = ScCompute>
 ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (&XR)[9], T (&xo)[3],
@@ -811,13 +835,20 @@ template <class A, class T, int CM, class Cap, class Extra, class Sc = ScCompute
 ABRK_INL void kin_dyn_hook(const A& arm, const T (&q)[A::N], const T (&dq)[A::N], Joints<A, T>& jt,
                            Dyn<A, T, CM>& d, T (&XR)[9], T (&xo)[3], Cap& cap, Extra&& extra, const Sc& scp = Sc{}) {
   dyn_init(d);
-  fk_forward(arm, q, jt, XR, xo, cap, [&](auto L, const T(&p)[3]) ABRK_LAMBDA {
+  auto visit = [&](auto L, const T(&p)[3]) ABRK_LAMBDA {
     omega_advance<L()>(jt, dq, d);
     body_advance<L()>(jt, dq, d);
     link_accumulate<L()>(arm, jt, dq, p, d);
     angular_link_coriolis<L()>(arm, jt, d);
     extra(L, p);
-  }, scp);
+  };
+  if constexpr (std::is_same<Sc, ScCompute>::value && ABRK_SINCOS_AHEAD) {
+    T sv[A::N][2];
+    sincos_all<A::N>(q, sv);
+    fk_forward(arm, q, jt, XR, xo, cap, visit, ScUse<T, A::N>{sv});
+  } else {
+    fk_forward(arm, q, jt, XR, xo, cap, visit, scp);
+  }
   angular_finish(arm, jt, dq, d);
 }
 template <class A, class T, int CM, class Cap>
