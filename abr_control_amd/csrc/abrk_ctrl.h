@@ -6,6 +6,9 @@
 #pragma once
 #include "abrk_device.h"
 
+#ifndef ABRK_PINV_FAST_MINK
+#define ABRK_PINV_FAST_MINK 1
+#endif
 #ifndef ABRK_C_TWO_PASS
 #define ABRK_C_TWO_PASS 1
 #endif
@@ -213,7 +216,7 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
 // values keep their relative accuracy, which an eigen-decomposition of J J^T would lose.
 template <int K, int N, class T>
 ABRK_INL void pinv_KxN(const T (&J)[N][K] /* J[i][r] = J(r,i) */, T rcond, T (&P)[N][K] /* P[i][r] */) {
-  if constexpr (K <= N) {
+  if constexpr (K <= N && K >= ABRK_PINV_FAST_MINK) {
     // Well-conditioned full row rank (the common case along an IK path or a sliding-mode step): pinv(J) =
     // J^T (J J^T)^-1 through a K x K Cholesky factor.  cond(J J^T) <= trace^K / det; below 1e6 (fp32: 1e2) the
     // squared conditioning costs at most ~1e-10 (1e-5) relative and nothing is truncated at rcond = 1e-15.
