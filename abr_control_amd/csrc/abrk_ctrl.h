@@ -557,7 +557,20 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     // rcond*max; det >= rcond*trace^K proves none is (lam_min >= det/lam_max^(K-1)).
     T bound = rcond;
     sfor<KM>([&](auto r) ABRK_LAMBDA { bound *= sel[r()] ? trace : T(1); });
-    if (!(okA && det > bound)) {
+    bool truncates = !(okA && det > bound);
+    if (truncates && okA) {
+      // second, much tighter certificate (the determinant bound is hopeless for six rows of mixed units):
+      // lam_max(A) <= trace(A) and 1/lam_min(A) <= trace(A^-1), so trace(A) trace(A^-1) < 1/rcond proves
+      // every singular value is above rcond * max - pinv is the inverse the factor already gives
+      if constexpr (FEAT == 0) chol_inverse<KM>(LA, ila, Mx);
+      T tinv = T(0);
+      sfor<KM>([&](auto r) ABRK_LAMBDA { tinv += sel[r()] ? Mx[tri(r(), r())] : T(0); });
+      if (trace * tinv * rcond < T(1)) {
+        truncates = false;
+        mx_explicit = true;
+      }
+    }
+    if (truncates) {
       T S[KM * (KM + 1) / 2], V[KM][KM], lam[KM];
       sfor<KM*(KM + 1) / 2>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
       jacobi_eig<KM>(S, V, lam);
@@ -987,9 +1000,10 @@ ABRK_INL void point_inertia(const T (&L)[N * (N + 1) / 2], const T (&il)[N], con
   }
   bool direct = okA && (GATED ? det > det_thr : false);
   if (!direct) direct = okA && det > rcond * trace * trace * trace;
-  if (direct) {
-    chol_inverse<3>(LA, ila, Mx);
-  } else {
+  if (okA) chol_inverse<3>(LA, ila, Mx);
+  if (!direct && okA)  // lam_min/lam_max >= 1 / (trace(A) trace(A^-1)): nothing is truncated (see osc_law)
+    direct = trace * (Mx[tri(0, 0)] + Mx[tri(1, 1)] + Mx[tri(2, 2)]) * rcond < T(1);
+  if (!direct) {
     T S[6], V[3][3], lam[3];
     sfor<6>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
     jacobi_eig<3>(S, V, lam);

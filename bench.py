@@ -46,6 +46,8 @@ WORKLOADS = {
     "rollout": ("twojoint", 4096, "f64", "rollout", dict(kp=20, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 0]), 600),
     # InverseKinematics.generate_path, 200 iterations per path inside one launch (method 3)
     "ik": ("ur5", 4096, "f64", "ik", dict(method=3, n_timesteps=200), 2500),
+    # position + orientation control (all six task rows, orientation algorithm 0): the masked six-row kernel
+    "osc6": ("ur5", 4096, "f64", "osc", dict(kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6), 6000),
     # the remaining secondary controllers as their own kernels (u [B,n] each)
     "limits": ("ur5", 4096, "f64", "limits", dict(), 60),
     "floating": ("ur5", 4096, "f64", "floating", dict(dynamic=True, task_space=True), 3300),
