@@ -142,7 +142,10 @@ class Runner:
             nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
             self.params = _abi.make_osc_params(self.n, null_controllers=nulls, **kw)
         self.plan = None
-        self.graph_steps = int(os.environ.get("ABRK_BENCH_GRAPH", "0"))
+        # launch-bound at the config batch: the K steps are replayed as hipGraph launches of 100 kernel nodes each
+        # (abrk_plan_launch_graph; same kernel, same buffers, one node per step).  ABRK_BENCH_GRAPH=0: one
+        # hipLaunchKernel per step (4.55 instead of 4.06 us per step at B = 4096)
+        self.graph_steps = int(os.environ.get("ABRK_BENCH_GRAPH", "100"))
         if kind in ("osc", "osc_damp"):
             # the per-tick launch of a control loop on fixed device buffers: arguments validated once
             self.plan = engine.OscPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
@@ -202,8 +205,11 @@ class Runner:
     def timed(self, steps, warmup, barrier=None):
         """-> (wall seconds of the timed region, mean kernel ms per launch from HIP events)"""
         a = self.a
+        graph = self.used_graph = self.plan is not None and self.graph_steps > 1 and steps >= self.graph_steps
         for _ in range(warmup):
             self.step()
+        if graph:  # builds (captures + instantiates) the graph outside the timed region; untimed extra steps
+            self.plan.launch_graph(self.graph_steps)
         self.stream.sync()
         ev0, ev1 = a.Event(self.device), a.Event(self.device)
         if barrier:
@@ -211,7 +217,7 @@ class Runner:
         self.stream.sync()
         t0 = time.perf_counter()
         ev0.record(self.stream)
-        if self.plan is not None and self.graph_steps > 1:
+        if graph:
             # K steps as ceil(K/G) hipGraph launches of G kernel nodes each (+ a remainder of plain launches)
             for _ in range(steps // self.graph_steps):
                 self.plan.launch_graph(self.graph_steps)
@@ -439,7 +445,9 @@ def main():
             "config": {"workload": f"{args.workload}: {arm} {kind} batch={B} per GPU, inputs resident in HBM, "
                                    f"q~U(0,2pi) dq~U(0,5) target~U(-1,1) seed 1", "arm": arm, "batch_per_gpu": B,
                        "global_batch": B * world, "params": {k: list(v) if isinstance(v, (list, tuple)) else v for k, v in kw.items()},
-                       "parallelism": f"batch-shard x{world}, no collective", "device": a.device_name(device)},
+                       "parallelism": f"batch-shard x{world}, no collective", "device": a.device_name(device),
+                       "launch": (f"hipGraph replay, {run.graph_steps} kernel nodes (= steps) per graph launch"
+                                  if getattr(run, "used_graph", False) else "one kernel launch per step")},
             "roofline_config": roofline(run, ms, f"{args.workload} batch={B} (cache-resident, launch-bound)"),
         }
     # HBM-sized leg for the roofline (rank 0 only; every rank could, the figure is per GPU)
