@@ -164,6 +164,18 @@ ABRK_INL void chol_inverse(const T (&L)[K * (K + 1) / 2], const T (&il)[K], T (&
   });
 }
 
+// tan of the Jacobi rotation angle, t = sign(theta) / (|theta| + sqrt(theta^2 + 1)) with theta = num / den (den != 0),
+// multiplied through by |den|: t = +-|den| / (|num| + hypot(num, den)) - one rsqrt and one rcp seed with their Newton
+// corrections instead of two IEEE divisions and a square root (22 instead of ~50 vector instructions).
+template <class T>
+ABRK_INL T jacobi_tan(T num, T den) {
+  const T an = Rm<T>::fabs(num), ad = Rm<T>::fabs(den);
+  const T w = Rm<T>::fmax(Rm<T>::fma(num, num, den * den), Rm<T>::tiny());
+  const T h = w * Rm<T>::rsqrt(w);
+  const T t = ad * Rm<T>::rcp(an + h);
+  return ((num >= T(0)) == (den >= T(0))) ? t : -t;
+}
+
 // Cyclic two-sided Jacobi eigen-decomposition of a symmetric K x K matrix (packed lower
 // in, destroyed).  V columns = eigenvectors, lam = eigenvalues.  Stands in for the SVD
 // inside numpy.linalg.pinv(Mx_inv) (osc.py:145) - for a symmetric matrix |eigenvalues|
@@ -183,8 +195,7 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
         constexpr int p = pp(), q = qq();  // p < q
         T apq = S[tri(q, p)];
         if (apq != T(0)) {
-          T theta = (S[tri(q, q)] - S[tri(p, p)]) / (T(2) * apq);
-          T t = (theta >= T(0) ? T(1) : T(-1)) / (Rm<T>::fabs(theta) + Rm<T>::sqrt(theta * theta + T(1)));
+          T t = jacobi_tan(S[tri(q, q)] - S[tri(p, p)], T(2) * apq);
           T c = Rm<T>::rsqrt(t * t + T(1));
           T s = t * c;
           sfor<K>([&](auto k) ABRK_LAMBDA {
@@ -263,11 +274,10 @@ ABRK_INL void pinv_KxN(const T (&J)[N][K] /* J[i][r] = J(r,i) */, T rcond, T (&P
           beta += G[i()][q] * G[i()][q];
           gamma += G[i()][p] * G[i()][q];
         });
-        T lim = Rm<T>::sqrt(alpha * beta);
-        if (Rm<T>::fabs(gamma) > Rm<T>::eps() * lim && Rm<T>::fabs(gamma) > Rm<T>::tiny()) {
-          worst = Rm<T>::fmax(worst, Rm<T>::fabs(gamma) / lim);
-          T zeta = (beta - alpha) / (T(2) * gamma);
-          T t = (zeta >= T(0) ? T(1) : T(-1)) / (Rm<T>::fabs(zeta) + Rm<T>::sqrt(T(1) + zeta * zeta));
+        // |gamma| > eps sqrt(alpha beta), without the square root
+        if (gamma * gamma > Rm<T>::eps() * Rm<T>::eps() * alpha * beta && Rm<T>::fabs(gamma) > Rm<T>::tiny()) {
+          worst = T(1);  // a rotation was applied in this sweep
+          T t = jacobi_tan(beta - alpha, T(2) * gamma);
           T c = Rm<T>::rsqrt(T(1) + t * t);
           T s = c * t;
           sfor<N>([&](auto i) ABRK_LAMBDA {
