@@ -303,8 +303,12 @@ ABRK_INL void pinv_KxN(const T (&J)[N][K] /* J[i][r] = J(r,i) */, T rcond, T (&P
     smax2 = Rm<T>::fmax(smax2, acc);
   });
   T w[K];
-  T cut = rcond * Rm<T>::sqrt(smax2);
-  sfor<K>([&](auto j) ABRK_LAMBDA { w[j()] = (Rm<T>::sqrt(sig2[j()]) > cut) ? rcp(sig2[j()]) : T(0); });
+  // sigma_j > rcond * sigma_max, compared on the squares
+  T cut2 = rcond * rcond * smax2;
+  sfor<K>([&](auto j) ABRK_LAMBDA {
+    bool keep = sig2[j()] > cut2;
+    w[j()] = keep ? rcp(keep ? sig2[j()] : T(1)) : T(0);
+  });
   sfor<N>([&](auto i) ABRK_LAMBDA {
     sfor<K>([&](auto r) ABRK_LAMBDA {
       T acc = T(-0.0);
@@ -908,10 +912,16 @@ ABRK_INL void ik_row(const A& arm, const IkP<T>& P, T (&q)[A::N], const T (&tgt)
       cross3(a, b, c);
       sfor<3>([&](auto r) ABRK_LAMBDA { dr[r()] = Qe[0] * a[r()] - Qd[0] * b[r()] - c[r()]; });
     }
-    T ndx = Rm<T>::sqrt(dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2]);
-    T ndr = Rm<T>::sqrt(dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]);
-    if (ndx > P.max_dx) sfor<3>([&](auto r) ABRK_LAMBDA { dx[r()] = dx[r()] / ndx * P.max_dx; });
-    if (ndr > P.max_dr) sfor<3>([&](auto r) ABRK_LAMBDA { dr[r()] = dr[r()] / ndr * P.max_dr; });
+    // |dx| > max_dx: dx *= max_dx / |dx|  (norm comparison on the squares, 1/|dx| from the rsqrt seed)
+    T n2x = dx[0] * dx[0] + dx[1] * dx[1] + dx[2] * dx[2], n2r = dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2];
+    if (n2x > P.max_dx * P.max_dx) {
+      T sc = P.max_dx * Rm<T>::rsqrt(n2x);
+      sfor<3>([&](auto r) ABRK_LAMBDA { dx[r()] *= sc; });
+    }
+    if (n2r > P.max_dr * P.max_dr) {
+      T sc = P.max_dr * Rm<T>::rsqrt(n2r);
+      sfor<3>([&](auto r) ABRK_LAMBDA { dr[r()] *= sc; });
+    }
     T dq[N];
     if (P.method == 3) {
       // dq = pinv(Jx) dx + (I - pinv(Jx) Jx) pinv(Jw) dr   (inverse_kinematics.py:117-121)
@@ -964,7 +974,10 @@ ABRK_INL void ik_row(const A& arm, const IkP<T>& P, T (&q)[A::N], const T (&tgt)
     }
     T m = T(0);
     sfor<N>([&](auto i) ABRK_LAMBDA { m = Rm<T>::fmax(m, Rm<T>::fabs(dq[i()])); });
-    if (m > P.max_dq) sfor<N>([&](auto i) ABRK_LAMBDA { dq[i()] = dq[i()] / m * P.max_dq; });
+    if (m > P.max_dq) {
+      T sc = P.max_dq * rcp(m);
+      sfor<N>([&](auto i) ABRK_LAMBDA { dq[i()] *= sc; });
+    }
     sfor<N>([&](auto i) ABRK_LAMBDA {
       ppath[ii * N + i()] = q[i()];
       vpath[ii * N + i()] = dq[i()];
@@ -1049,8 +1062,8 @@ ABRK_INL void limits_row(const LimitsP<T>& P, const T (&qin)[N], T (&u)[N]) {
     const bool closer_to_max = both && Rm<T>::fabs(dmn) <= Rm<T>::fabs(dmx);
     T amin = T(0), amax = T(0);
     if (P.gr[i]) {  // :108-115.  1/0 -> +-inf in the reference: exp(+inf) is capped by max_torque, exp(-inf) = 0
-      if (hmin) amin = dmn == T(0) ? mt : Rm<T>::fmin(Rm<T>::exp(T(1) / dmn), mt);
-      if (hmax) amax = dmx == T(0) ? -mt : -Rm<T>::fmin(Rm<T>::exp(T(-1) / dmx), mt);
+      if (hmin) amin = dmn == T(0) ? mt : Rm<T>::fmin(Rm<T>::exp(rcp(dmn == T(0) ? T(1) : dmn)), mt);
+      if (hmax) amax = dmx == T(0) ? -mt : -Rm<T>::fmin(Rm<T>::exp(-rcp(dmx == T(0) ? T(1) : dmx)), mt);
     }
     bool min_index = hmin && dmn < T(0), max_index = hmax && dmx > T(0);  // :118-119
     if (P.cz[i]) {  // :124-134
@@ -1163,19 +1176,20 @@ ABRK_INL void obstacles_row(const A& arm, const ObsP<T>& P, const T (&q)[A::N], 
       const T len2 = dot3(vl, vl);
       // a zero-length segment is 0/0 in the reference: every later comparison is false, no contribution
       if (len2 > T(0)) {
-        T pr = dot3(vo, vl) / len2;  // :76
+        T pr = dot3(vo, vl) * rcp(len2);  // :76
         pr = pr < T(0) ? T(0) : (pr > T(1) ? T(1) : pr);  // :77-84 (closest = p1, p2 or in between)
         T cl[3], dv[3];
         sfor<3>([&](auto r) ABRK_LAMBDA {
           cl[r()] = pr == T(1) ? p2[r()] : p1[r()] + pr * vl[r()];
           dv[r()] = v[r()] - cl[r()];
         });
-        const T dist = Rm<T>::sqrt(dot3(dv, dv));
+        const T d2 = dot3(dv, dv);
+        const T dist = d2 > T(0) ? d2 * Rm<T>::rsqrt(d2 > T(0) ? d2 : T(1)) : T(0);
         const T rho = Rm<T>::fmax(dist - radius, lo);  // :90
         if (rho < P.threshold) {
           // Fpsp = eta (1/rho - 1/threshold) / rho^1.5 * (v - closest)/rho   (:94-102)
-          const T irho = T(1) / rho;
-          const T k = T(0.02) * (irho - ithr) * irho * irho / Rm<T>::sqrt(rho);
+          const T irho = rcp(rho);
+          const T k = T(0.02) * (irho - ithr) * irho * irho * Rm<T>::rsqrt(rho);
           T F[3] = {k * dv[0], k * dv[1], k * dv[2]};
           T Jp[N][3];
           if constexpr (!A::kOrtho) {
