@@ -228,9 +228,11 @@ class Runner:
                 self.step()
         ev1.record(self.stream)
         self.stream.sync()
+        # this rank's K steps, device-synchronised on both sides; the closing barrier keeps the ranks together but
+        # its own (gloo, TCP) latency is not step time - main() takes the MAX of `wall` over the ranks
+        wall = time.perf_counter() - t0
         if barrier:
             barrier()
-        wall = time.perf_counter() - t0
         return wall, ev1.elapsed_ms_since(ev0) / steps
 
 

@@ -430,6 +430,47 @@ def test_gpu_launch_plan_equals_direct_call():
         engine.OscPlan(be.arm_id, 6, p, q, dq_, t_, u_)
 
 
+def test_gpu_plan_graph_replay_equals_consecutive_launches():
+    """abrk_plan_launch_graph(repeat) == `repeat` consecutive abrk_plan_launch calls, in order: with the integral
+    term on (osc.py:262-264) every step reads the state its predecessor wrote, so a graph whose kernel nodes ran
+    out of order or concurrently would change integrated_error and u."""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+
+    be = cases.GpuBackend("ur5")
+    p = _abi.make_osc_params(6, kp=50, kv=7, ki=0.3)
+    B = 4096
+    q, dq, t = draw(41, B, 6)
+
+    def run(graph):
+        s = a.Stream(0)
+        dev = [a.DeviceArray.from_numpy(x) for x in (q, dq, t)]
+        ie, u = a.DeviceArray.from_numpy(np.zeros((B, 6))), a.DeviceArray((B, 6))
+        plan = engine.OscPlan(be.arm_id, 6, p, dev[0], dev[1], dev[2], u, integrated_error=ie, stream=s)
+        if graph:
+            plan.launch_graph(5)
+            plan.launch_graph(5)  # the cached executable graph, replayed
+            plan.launch_graph(3)  # a different repeat count re-captures
+        else:
+            for _ in range(13):
+                plan.launch()
+        s.sync()
+        return u.numpy(), ie.numpy()
+
+    (ug, ieg), (ud, ied) = run(True), run(False)
+    assert np.array_equal(ug, ud) and np.array_equal(ieg, ied)
+    # and the state did advance: 13 steps of u_task accumulated (osc.py:263)
+    ref = be.osc(p, q, dq, t)[0]
+    assert not np.array_equal(ug, ref)
+    from oracle.oracle import Oracle
+
+    o = Oracle(_abi.load_table("ur5"))
+    ie_o = np.zeros((B, 6))
+    for _ in range(13):
+        uo = o.osc_batch(p, q, dq, t, integrated_error=ie_o)
+    assert cases.rel_err(ug, uo).max() < 1e-9 and np.abs(ieg - ie_o).max() < 1e-9
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7])
 def test_gpu_user_arms_all_joint_counts(n):
     """runtime-table kernels for every joint count 1..ABRK_MAX_JOINTS on synthetic arms vs the oracle"""
