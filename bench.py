@@ -416,7 +416,18 @@ def main():
         import torch.distributed as dist
 
         # coordination only (barrier + max of timings): CPU tensors over gloo, no RCCL on the data path
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the ONE
+        # JSON line - file descriptor 1 points at stderr while the process group comes up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     import abr_control_amd as a
 
