@@ -305,6 +305,25 @@ def host_staged_rate(device):
     return res
 
 
+def usable_cores():
+    """host cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (the GPU
+    boxes show 256 logical CPUs but grant a container 16 of them - more threads than that only thrash)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(workload, budget_s=12.0):
     """the oracle (plain-C port of the reference path) on one host core, bounded sample"""
     from abr_control_amd import _abi
@@ -366,7 +385,7 @@ def cpu_baseline(workload, budget_s=12.0):
     # its own copy of the sample - the reference itself has no multi-core path
     from concurrent.futures import ThreadPoolExecutor
 
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     stop = time.perf_counter() + budget_s / 2
 
     def worker(_):
