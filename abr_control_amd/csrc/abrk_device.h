@@ -578,6 +578,9 @@ struct Dyn {
   // CMODE_VEC on orthogonal chains: kinematic state of the body the current link belongs to -
   // angular velocity, bias angular acceleration, bias acceleration of the last joint origin
   T bw[3], bal[3], bao[3];
+  // CMODE_CVONLY: bias force of every link and its moment about the world origin (+ the angular term n_l);
+  // projected onto the joint axes by one backward sweep after the chain (coriolis_backward)
+  T lf[CMODE == CMODE_CVONLY ? N : 1][3], lt[CMODE == CMODE_CVONLY ? N : 1][3];
 };
 // the recursive Coriolis-vector path (below) replaces the omega prefix sums
 template <class A, int CM>
@@ -627,11 +630,14 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
     if constexpr (!(L < A::NL) || !link_has_linear_mass<A, L>()) return;
   }
   if (!live) return;
-  T e[NJ][3];
-  sfor<NJ>([&](auto i) ABRK_LAMBDA {
-    T dlt[3] = {p[0] - jt.o[i()][0], p[1] - jt.o[i()][1], p[2] - jt.o[i()][2]};
-    wapply<i()>(jt, dlt, e[i()]);
-  });
+  constexpr bool kBackward = (CM == CMODE_CVONLY) && kRecursiveC<A, CM>;
+  T e[kBackward ? 1 : NJ][3];
+  if constexpr (!kBackward) {
+    sfor<NJ>([&](auto i) ABRK_LAMBDA {
+      T dlt[3] = {p[0] - jt.o[i()][0], p[1] - jt.o[i()][1], p[2] - jt.o[i()][2]};
+      wapply<i()>(jt, dlt, e[i()]);
+    });
+  }
   T m0 = AccMD<A, T, L, 0>::get(arm), m1 = AccMD<A, T, L, 1>::get(arm), m2 = AccMD<A, T, L, 2>::get(arm);
   if constexpr (CM != CMODE_CVONLY) {
     sfor<NJ>([&](auto i) ABRK_LAMBDA {
@@ -650,7 +656,19 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
     cross3(d.bal, dl, ad);
     cross3(d.bw, t, wt);
     T ma[3] = {m0 * (d.bao[0] + ad[0] + wt[0]), m1 * (d.bao[1] + ad[1] + wt[1]), m2 * (d.bao[2] + ad[2] + wt[2])};
-    sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], e[k()], ma); });
+    if constexpr (kBackward) {
+      // e_k . ma = z_k . ((p - o_k) x ma): keep the force and its moment about the world origin; the sum over the
+      // links beyond joint k is taken once, backwards (coriolis_backward) - 12 instead of 12 (L) instructions per link
+      static_assert(L >= 1 && L <= A::N, "links beyond the last joint carry no joint-dependent term");
+      T mo[3];
+      cross3(p, ma, mo);
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        d.lf[L - 1][r()] = ma[r()];
+        d.lt[L - 1][r()] += mo[r()];
+      });
+    } else {
+      sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], e[k()], ma); });
+    }
   } else if constexpr (CM != CMODE_NONE) {
     T s[3] = {T(-0.0), T(-0.0), T(-0.0)};
     T a[3] = {T(-0.0), T(-0.0), T(-0.0)};  // COM bias acceleration  Edot dq
@@ -701,7 +719,33 @@ ABRK_INL void angular_link_coriolis(const A& arm, const Joints<A, T>& jt, Dyn<A,
     n[0] = Rm<T>::fma(I0, d.bal[0], n[0]);
     n[1] = Rm<T>::fma(I1, d.bal[1], n[1]);
     n[2] = Rm<T>::fma(I2, d.bal[2], n[2]);
-    sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], jt.z[k()], n); });
+    if constexpr (CM == CMODE_CVONLY) {
+      sfor<3>([&](auto r) ABRK_LAMBDA { d.lt[L - 1][r()] += n[r()]; });
+    } else {
+      sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], jt.z[k()], n); });
+    }
+  }
+}
+
+// c_k = z_k . (sum_{l>k} (p_l x f_l + n_l) - o_k x sum_{l>k} f_l): the backward half of the recursion (what the
+// recursive Newton-Euler algorithm does with its link wrenches), after the forward pass has left f_l and the
+// moments in d.lf / d.lt
+template <class A, class T, int CM>
+ABRK_INL void coriolis_backward(const Joints<A, T>& jt, Dyn<A, T, CM>& d) {
+  if constexpr (CM == CMODE_CVONLY && kRecursiveC<A, CM>) {
+    constexpr int N = A::N;
+    T F[3] = {T(0), T(0), T(0)}, Nm[3] = {T(0), T(0), T(0)};
+    sfor<N>([&](auto kr) ABRK_LAMBDA {
+      constexpr int k = N - 1 - kr();
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        F[r()] += d.lf[k][r()];
+        Nm[r()] += d.lt[k][r()];
+      });
+      T of[3];
+      cross3(jt.o[k], F, of);
+      T w[3] = {Nm[0] - of[0], Nm[1] - of[1], Nm[2] - of[2]};
+      d.cv[k] = dot3(jt.z[k], w);
+    });
   }
 }
 
@@ -737,6 +781,11 @@ ABRK_INL void dyn_init(Dyn<A, T, CM>& d) {
   sfor<N>([&](auto i) ABRK_LAMBDA { d.gz[i()] = T(-0.0); });
   if constexpr (CM == CMODE_MAT) sfor<N * N>([&](auto e) ABRK_LAMBDA { d.Cm[e()] = T(-0.0); });
   if constexpr (CM == CMODE_VEC || CM == CMODE_CVONLY) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(-0.0); });
+  if constexpr (CM == CMODE_CVONLY) {
+    sfor<N>([&](auto l) ABRK_LAMBDA {
+      sfor<3>([&](auto r) ABRK_LAMBDA { d.lf[l()][r()] = d.lt[l()][r()] = T(0); });
+    });
+  }
 }
 
 // weighted dot  sum_r Isuf(m,r) a[r] b[r]
@@ -751,7 +800,10 @@ ABRK_INL T idot(const A& arm, const T (&a)[3], const T (&b)[3], T acc = T(-0.0))
 template <class A, class T, int CM>
 ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
   constexpr int N = A::N;
-  if constexpr (CM == CMODE_CVONLY) return;
+  if constexpr (CM == CMODE_CVONLY) {
+    coriolis_backward(jt, d);
+    return;
+  }
   sfor<N>([&](auto i) ABRK_LAMBDA {
     sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = idot<i()>(arm, jt.z[i()], jt.z[j()], d.Ms[tri(i(), j())]); });
   });
