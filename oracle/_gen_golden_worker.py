@@ -480,8 +480,70 @@ def gen_secondary(arm):
     print(f"  wrote {OUT}/sec_{arm}.npz ({len(out)} arrays)", flush=True)
 
 
+def gen_osc_helpers(arm):
+    """The three helper methods of OSC that the reference's own tests call directly
+    (controllers/tests/test_osc.py:12-59 `_velocity_limiting`, :62-86 `_Mx`, :94-140
+    `_calc_orientation_forces`), run on the reference classes: the inputs of those tests plus seeded random ones."""
+    mod = importlib.import_module(f"abr_control.arms.{arm}")
+    from abr_control.controllers import OSC
+
+    rc = mod.Config(use_cython=True)
+    raw = RawConfig(rc)
+    n = rc.N_JOINTS
+    out = {}
+    # ---- _velocity_limiting: test_osc.py:24-59 (kp=10, ko=8, kv=4, vmax=[1,1]) + random task-space errors
+    kp, ko, kv, vmax = 10, 8, 4, 1
+    c = OSC(raw, kp=kp, ko=ko, kv=kv, vmax=[vmax, vmax], ctrlr_dof=[True] * 6)
+    rng = np.random.RandomState(80)
+    ut = np.vstack([np.ones((1, 6)) * 0.05, np.hstack([np.ones((1, 3)) * 100, np.ones((1, 3)) * 0.05]),
+                    np.ones((1, 6)) * 100, rng.uniform(-1, 1, (61, 6)) * rng.choice([0.05, 0.5, 5.0], (61, 1))])
+    out["vl_gains"] = np.array([kp, ko, kv, vmax, vmax], dtype=float)
+    out["vl_in"] = ut
+    out["vl_out"] = np.array([c._velocity_limiting(u.copy()) for u in ut])
+    # the expected values the reference test asserts (test_osc.py:36-59)
+    assert np.allclose(out["vl_out"][0], [kp * 0.05] * 3 + [ko * 0.05] * 3, atol=1e-5)
+    assert np.allclose(out["vl_out"][1], [kv * np.sqrt(vmax / 3.0)] * 3 + [ko * 0.05] * 3, atol=1e-5)
+    assert np.allclose(out["vl_out"][2], [kv * np.sqrt(vmax / 3.0)] * 6, atol=1e-5)
+    # ---- _Mx: test_osc.py:62-86 (J = I with threshold 1e-5; J = ones) + random selected rows
+    c = OSC(raw, ctrlr_dof=[True] * 6 if n >= 6 else [True] * n + [False] * (6 - n))
+    B = 100
+    q = rng.uniform(0, 2 * np.pi, (B, n))
+    M = np.array([raw.M(q[b]) for b in range(B)])
+    out["mx_q"], out["mx_M"] = q, M
+    r = [c._Mx(M=M[b], J=np.eye(n), threshold=1e-5) for b in range(B)]
+    out["mx_eye_Mx"], out["mx_eye_Minv"] = np.array([x[0] for x in r]), np.array([x[1] for x in r])
+    assert all(np.allclose(M[b], out["mx_eye_Mx"][b], atol=1e-5) for b in range(B))  # test_osc.py:80
+    r = [c._Mx(M=M[b], J=np.ones((6, n))) for b in range(B)]
+    out["mx_ones_Mx"] = np.array([x[0] for x in r])
+    assert all(np.all(np.abs(np.linalg.svd(x)[1][1:]) < 1e-10) for x in out["mx_ones_Mx"])  # test_osc.py:86
+    for k in sorted({1, 2, 3, min(n, 6)}):
+        if k > 6:
+            continue
+        Jk = np.array([raw.J("EE", q[b])[rng.permutation(6)[:k]] for b in range(B)])
+        r = [c._Mx(M=M[b], J=Jk[b]) for b in range(B)]
+        out[f"mx_k{k}_J"] = Jk
+        out[f"mx_k{k}_Mx"] = np.array([x[0] for x in r])
+        A = np.array([Jk[b] @ np.linalg.inv(M[b]) @ Jk[b].T for b in range(B)])
+        out[f"mx_k{k}_det"] = np.linalg.det(A)
+        out[f"mx_k{k}_sv"] = np.linalg.svd(A, compute_uv=False)
+    # ---- _calc_orientation_forces (osc.py:149-196; the reference test calls it without ref_frame,
+    # test_osc.py:127, and fails for that reason - called here with the argument the method requires)
+    Bo = 100
+    q = rng.uniform(0, 2 * np.pi, (Bo, n))
+    abg = rng.uniform(-np.pi, np.pi, (Bo, 3))
+    out["of_q"], out["of_abg"] = q, abg
+    out["of_R"] = np.array([raw.R("EE", q[b]) for b in range(Bo)])
+    for alg in (0, 1):
+        c = OSC(raw, orientation_algorithm=alg, ctrlr_dof=[True] * 6)
+        out[f"of_alg{alg}"] = np.array([c._calc_orientation_forces(abg[b], q[b], "EE") for b in range(Bo)])
+    np.savez_compressed(f"{OUT}/oschelpers_{arm}.npz", **out)
+    print(f"  wrote {OUT}/oschelpers_{arm}.npz ({len(out)} arrays)", flush=True)
+
+
 if what == "known":
     gen_known()
+elif what.startswith("helpers:"):
+    gen_osc_helpers(what[8:])
 elif what.startswith("sec:"):
     gen_secondary(what[4:])
 else:

@@ -551,6 +551,78 @@ int abrk_oracle_joint_generate(const abrk_arm_desc* a, const abrk_null_ctrl* c, 
 }
 
 /* ------------------------------------------------------------------ OSC.generate, osc.py:217-320 */
+/* OSC._Mx, osc.py:120-147.  M [n,n]; J [k,n] (the task rows OSC keeps); Mx [k,k]; Minv [n,n] */
+void abrk_oracle_osc_mx(int n, int k, const double* M, const double* J, double threshold, double* Mx, double* Minv) {
+  double Mxinv[36], T1[6 * NJ];
+  la_inv(M, n, Minv); /* osc.py:136 */
+  for (int r = 0; r < k; r++) /* T1 = J Minv  [k x n] */
+    for (int j = 0; j < n; j++) {
+      double s = 0;
+      for (int i = 0; i < n; i++) s += J[r * n + i] * Minv[i * n + j];
+      T1[r * n + j] = s;
+    }
+  for (int r = 0; r < k; r++) /* osc.py:137 */
+    for (int c = 0; c < k; c++) {
+      double s = 0;
+      for (int j = 0; j < n; j++) s += T1[r * n + j] * J[c * n + j];
+      Mxinv[r * k + c] = s;
+    }
+  double det = la_inv(Mxinv, k, Mx);                                       /* osc.py:138-141 */
+  if (!(fabs(det) >= threshold)) la_pinv(Mxinv, k, k, threshold * 0.1, Mx); /* osc.py:142-145 */
+}
+
+/* OSC._calc_orientation_forces, osc.py:149-196, from R_e = robot_config.R(ref_frame, q) (robot_config.quaternion is
+ * quaternion_from_matrix of the same R, base_config.py:304-318).  Returns -2 for an unknown algorithm. */
+int abrk_oracle_osc_orientation_forces(int algorithm, const double R_e[9], const double target_abg[3], double u_o[3]) {
+  if (algorithm == 0) {
+    double q_d[4], q_e[4], q_ec[4], q_r[4];
+    abrk_oracle_quat_from_euler_rxyz(target_abg[0], target_abg[1], target_abg[2], q_d);
+    tf_unit(q_d, 4);
+    abrk_oracle_quat_from_matrix(R_e, q_e);
+    tf_unit(q_e, 4);
+    q_ec[0] = q_e[0]; q_ec[1] = -q_e[1]; q_ec[2] = -q_e[2]; q_ec[3] = -q_e[3];
+    abrk_oracle_quat_mul(q_d, q_ec, q_r);
+    double sg = (q_r[0] > 0) - (q_r[0] < 0); /* np.sign */
+    for (int r = 0; r < 3; r++) u_o[r] = -q_r[1 + r] * sg;
+  } else if (algorithm == 1) {
+    double R_d[9], R_ed[9], q_ed[4];
+    abrk_oracle_euler_matrix_rxyz(target_abg[0], target_abg[1], target_abg[2], R_d);
+    for (int r = 0; r < 3; r++)
+      for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int m = 0; m < 3; m++) s += R_e[m * 3 + r] * R_d[m * 3 + c];
+        R_ed[r * 3 + c] = s;
+      }
+    abrk_oracle_quat_from_matrix(R_ed, q_ed);
+    tf_unit(q_ed, 4);
+    for (int r = 0; r < 3; r++) {
+      double s = 0;
+      for (int c = 0; c < 3; c++) s += R_e[r * 3 + c] * q_ed[1 + c];
+      u_o[r] = -1 * s;
+    }
+  } else {
+    return -2;
+  }
+  return 0;
+}
+
+/* OSC._velocity_limiting, osc.py:198-215 with the constants of osc.py:89-115; in place on u_task[6] */
+void abrk_oracle_osc_velocity_limiting(const abrk_osc_params* P, double u_task[6]) {
+  double gains[6] = {P->kp, P->kp, P->kp, P->ko, P->ko, P->ko};
+  double lamb[6];
+  for (int r = 0; r < 6; r++) lamb[r] = gains[r] / P->kv;
+  double sat_gain_xyz = P->vmax[0] / P->kp * P->kv, sat_gain_abg = P->vmax[1] / P->ko * P->kv;
+  double scale_xyz = sat_gain_xyz, scale_abg = sat_gain_abg;
+  double norm_xyz = sqrt(u_task[0] * u_task[0] + u_task[1] * u_task[1] + u_task[2] * u_task[2]);
+  double norm_abg = sqrt(u_task[3] * u_task[3] + u_task[4] * u_task[4] + u_task[5] * u_task[5]);
+  double scale[6] = {1, 1, 1, 1, 1, 1};
+  if (norm_xyz > sat_gain_xyz)
+    for (int r = 0; r < 3; r++) scale[r] *= scale_xyz / norm_xyz;
+  if (norm_abg > sat_gain_abg)
+    for (int r = 3; r < 6; r++) scale[r] *= scale_abg / norm_abg;
+  for (int r = 0; r < 6; r++) u_task[r] = P->kv * scale[r] * lamb[r] * u_task[r];
+}
+
 int abrk_oracle_osc_generate(const abrk_arm_desc* a, const abrk_osc_params* P, const double* q,
                              const double* dq, const double* target, const double* target_velocity,
                              double* integrated_error, const double* u_null_ext, double* u,
@@ -570,22 +642,8 @@ int abrk_oracle_osc_generate(const abrk_arm_desc* a, const abrk_osc_params* P, c
   abrk_oracle_M(a, q, M);
 
   /* _Mx, osc.py:120-147 */
-  double Mx[36], Mxinv[36], T1[6 * NJ];
-  la_inv(M, n, Minv);
-  for (int r = 0; r < k; r++) /* T1 = J Minv  [k x n] */
-    for (int j = 0; j < n; j++) {
-      double s = 0;
-      for (int i = 0; i < n; i++) s += J[r * n + i] * Minv[i * n + j];
-      T1[r * n + j] = s;
-    }
-  for (int r = 0; r < k; r++)
-    for (int c = 0; c < k; c++) {
-      double s = 0;
-      for (int j = 0; j < n; j++) s += T1[r * n + j] * J[c * n + j];
-      Mxinv[r * k + c] = s;
-    }
-  double det = la_inv(Mxinv, k, Mx);
-  if (!(fabs(det) >= 1e-3)) la_pinv(Mxinv, k, k, 1e-3 * 0.1, Mx);
+  double Mx[36];
+  abrk_oracle_osc_mx(n, k, M, J, 1e-3, Mx, Minv);
 
   /* desired task-space forces, osc.py:250-259 */
   double u_task[6] = {0, 0, 0, 0, 0, 0};
@@ -596,35 +654,9 @@ int abrk_oracle_osc_generate(const abrk_arm_desc* a, const abrk_osc_params* P, c
   }
   if (P->ctrlr_dof[3] + P->ctrlr_dof[4] + P->ctrlr_dof[5] > 0) {
     /* _calc_orientation_forces, osc.py:149-196 */
-    if (P->orientation_algorithm == 0) {
-      double q_d[4], q_e[4], q_ec[4], q_r[4];
-      abrk_oracle_quat_from_euler_rxyz(target[3], target[4], target[5], q_d);
-      tf_unit(q_d, 4);
-      abrk_oracle_quaternion(a, P->ref_frame, q, q_e);
-      q_ec[0] = q_e[0]; q_ec[1] = -q_e[1]; q_ec[2] = -q_e[2]; q_ec[3] = -q_e[3];
-      abrk_oracle_quat_mul(q_d, q_ec, q_r);
-      double sg = (q_r[0] > 0) - (q_r[0] < 0); /* np.sign */
-      for (int r = 0; r < 3; r++) u_task[3 + r] = -q_r[1 + r] * sg;
-    } else if (P->orientation_algorithm == 1) {
-      double R_e[9], R_d[9], R_ed[9], q_ed[4];
-      abrk_oracle_R(a, P->ref_frame, q, R_e);
-      abrk_oracle_euler_matrix_rxyz(target[3], target[4], target[5], R_d);
-      for (int r = 0; r < 3; r++)
-        for (int c = 0; c < 3; c++) {
-          double s = 0;
-          for (int m = 0; m < 3; m++) s += R_e[m * 3 + r] * R_d[m * 3 + c];
-          R_ed[r * 3 + c] = s;
-        }
-      abrk_oracle_quat_from_matrix(R_ed, q_ed);
-      tf_unit(q_ed, 4);
-      for (int r = 0; r < 3; r++) {
-        double s = 0;
-        for (int c = 0; c < 3; c++) s += R_e[r * 3 + c] * q_ed[1 + c];
-        u_task[3 + r] = -1 * s;
-      }
-    } else {
-      return -2;
-    }
+    double R_e[9];
+    abrk_oracle_R(a, P->ref_frame, q, R_e);
+    if (abrk_oracle_osc_orientation_forces(P->orientation_algorithm, R_e, target + 3, u_task + 3)) return -2;
   }
 
   /* integral term, osc.py:262-264 */
@@ -638,18 +670,7 @@ int abrk_oracle_osc_generate(const abrk_arm_desc* a, const abrk_osc_params* P, c
   /* gains / velocity limiting, osc.py:266-272, 198-215, constants osc.py:89-115 */
   double gains[6] = {P->kp, P->kp, P->kp, P->ko, P->ko, P->ko};
   if (P->use_vmax) {
-    double lamb[6];
-    for (int r = 0; r < 6; r++) lamb[r] = gains[r] / P->kv;
-    double sat_gain_xyz = P->vmax[0] / P->kp * P->kv, sat_gain_abg = P->vmax[1] / P->ko * P->kv;
-    double scale_xyz = sat_gain_xyz, scale_abg = sat_gain_abg;
-    double norm_xyz = sqrt(u_task[0] * u_task[0] + u_task[1] * u_task[1] + u_task[2] * u_task[2]);
-    double norm_abg = sqrt(u_task[3] * u_task[3] + u_task[4] * u_task[4] + u_task[5] * u_task[5]);
-    double scale[6] = {1, 1, 1, 1, 1, 1};
-    if (norm_xyz > sat_gain_xyz)
-      for (int r = 0; r < 3; r++) scale[r] *= scale_xyz / norm_xyz;
-    if (norm_abg > sat_gain_abg)
-      for (int r = 3; r < 6; r++) scale[r] *= scale_abg / norm_abg;
-    for (int r = 0; r < 6; r++) u_task[r] = P->kv * scale[r] * lamb[r] * u_task[r];
+    abrk_oracle_osc_velocity_limiting(P, u_task);
   } else {
     for (int r = 0; r < 6; r++) u_task[r] *= gains[r];
   }

@@ -226,3 +226,27 @@ def quat_mul(q1, q0):
     out = np.zeros(4)
     lib().abrk_oracle_quat_mul(_p(_c(q1)), _p(_c(q0)), _p(out))
     return out
+
+
+def osc_mx(M, J, threshold=1e-3):
+    """OSC._Mx (osc.py:120-147) for one (M [n,n], J [k,n]) -> (Mx [k,k], M_inv [n,n])"""
+    M, J = _c(M), _c(J)
+    n, k = M.shape[0], J.shape[0]
+    Mx, Minv = np.zeros((k, k)), np.zeros((n, n))
+    lib().abrk_oracle_osc_mx(int(n), int(k), _p(M), _p(J), C.c_double(threshold), _p(Mx), _p(Minv))
+    return Mx, Minv
+
+
+def osc_orientation_forces(algorithm, R_e, target_abg):
+    """OSC._calc_orientation_forces (osc.py:149-196) from R_e = robot_config.R(ref_frame, q)"""
+    out = np.zeros(3)
+    rc = lib().abrk_oracle_osc_orientation_forces(int(algorithm), _p(_c(R_e)), _p(_c(target_abg)), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def osc_velocity_limiting(params, u_task):
+    """OSC._velocity_limiting (osc.py:198-215)"""
+    out = _c(u_task).copy()
+    lib().abrk_oracle_osc_velocity_limiting(C.byref(params), _p(out))
+    return out

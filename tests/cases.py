@@ -119,6 +119,15 @@ def threshold_band(g, key, eps=1e-6):
     return near_det | near_cut
 
 
+def mx_rows_clear_of_thresholds(det, sv, eps=1e-6):
+    """the same band test for `_Mx` called directly (fixtures oschelpers_<arm>.npz): True = safe to compare"""
+    det, sv = np.abs(np.asarray(det)), np.asarray(sv)
+    near_det = np.abs(det - 1e-3) <= eps * 1e-3 * 1e3
+    ratio = sv / sv.max(axis=1, keepdims=True)
+    near_cut = (np.abs(ratio - 1e-4) <= eps * 1e2).any(axis=1) & (det < 1e-3 * (1 + 1e-3))
+    return ~(near_det | near_cut)
+
+
 # ---------------------------------------------------------------------------- backends
 class OracleBackend:
     name = "oracle"
