@@ -93,6 +93,46 @@ class OSC(Controller):
             ctrlr_dof=self.ctrlr_dof, null_controllers=self._fused, use_g=self.use_g, use_C=self.use_C,
             orientation_algorithm=self.orientation_algorithm, ref_frame=ref_frame, xyz_offset=xyz_offset)
 
+    # ---- the helper methods the reference's own tests call (controllers/tests/test_osc.py); each is one
+    # kernel launch - nothing here is computed on the host
+    def _device_dtype(self):
+        rc = self.robot_config
+        return getattr(rc, "dtype", np.float64), getattr(rc, "device", 0)
+
+    def _Mx(self, M, J, threshold=1e-3):
+        """Task-space inertia (osc.py:120-147): M [n,n], J [k,n] -> (Mx [k,k], M_inv [n,n]); stacks
+        [B,n,n] / [B,k,n] give [B,k,k] / [B,n,n]."""
+        dtype, device = self._device_dtype()
+        M, J = np.asarray(M, dtype=dtype), np.asarray(J, dtype=dtype)
+        single = M.ndim == 2
+        M3, J3 = (M[None], J[None]) if single else (M, J)
+        Mx, Minv = engine.osc_mx(M3.shape[-1], M3, J3, threshold, dtype=dtype, device=device)
+        return (Mx[0], Minv[0]) if single else (Mx, Minv)
+
+    def _calc_orientation_forces(self, target_abg, q, ref_frame):
+        """Task-space orientation error (osc.py:149-196); (3,), (n,) -> (3,) or [B,3], [B,n] -> [B,3]"""
+        rc = self.robot_config
+        dtype, device = self._device_dtype()
+        single = np.ndim(q) == 1
+        # full-precision rotation (the reference goes through the float32 cast of robot_config.R, base_config.py:301)
+        R = rc._eval("R", q, None, ref_frame) if self._fused_config else rc.R(ref_frame, q)
+        R = np.asarray(R, dtype=dtype).reshape(-1, 3, 3)
+        abg = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(np.asarray(target_abg, dtype=dtype)), (R.shape[0], 3)))
+        u = engine.osc_orientation_forces(self.orientation_algorithm, R, abg, dtype=dtype, device=device)
+        u = u.astype(np.float64)
+        return u[0] if single else u
+
+    def _velocity_limiting(self, u_task):
+        """Scale the task-space signal so that the velocity limits hold (osc.py:198-215); (6,) or [B,6]"""
+        if self.vmax is None:
+            raise AttributeError("'OSC' object has no attribute 'sat_gain_xyz'")  # what the reference raises
+        dtype, device = self._device_dtype()
+        ut = np.asarray(u_task, dtype=dtype)
+        single = ut.ndim == 1
+        out = engine.osc_velocity_limiting(self._params("EE", None), np.atleast_2d(ut), dtype=dtype, device=device)
+        out = out.astype(np.float64)
+        return out[0] if single else out
+
     def generate(self, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None):
         """Control signal(s) moving `ref_frame` to `target` (osc.py:217-320).
 

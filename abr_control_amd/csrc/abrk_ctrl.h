@@ -1246,4 +1246,83 @@ ABRK_INL void joint_row(const A& arm, const JointP<T>& P, const T (&q)[A::N], co
   if (P.c.kind == 0 && P.account_for_gravity) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += T(9.81) * d.gz[i()]; });
 }
 
+// ---- the helper methods of OSC as functions of their own (what controllers/tests/test_osc.py calls directly).
+// The fused OSC kernels carry the same steps inline, specialised (packed M from the chain, certificates that
+// skip the eigen-decomposition, solve-based Mx u); these are the general forms behind OSC._Mx / ._velocity_limiting /
+// ._calc_orientation_forces of the Python mirror.
+
+// OSC._Mx (osc.py:120-147): M [N,N] symmetric positive definite (a mass matrix), J = the k task rows OSC keeps
+// (Jr[i][r] = J(r,i), rows >= k ignored).  Mx (k x k block of the packed 6 x 6) and M^-1 (packed).
+template <int N, class T>
+ABRK_INL void mx_row(const T (&Ms)[N * (N + 1) / 2], const T (&Jin)[N][6], int k, T thr, T (&Mx)[21],
+                     T (&Minv)[N * (N + 1) / 2]) {
+  T L[N * (N + 1) / 2], il[N];
+  chol<N>(Ms, L, il);
+  chol_inverse<N>(L, il, Minv);  // osc.py:136
+  bool sel[6];
+  T Y[N][6];
+  sfor<6>([&](auto r) ABRK_LAMBDA {
+    sel[r()] = r() < k;
+    T b[N], x[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { b[i()] = sel[r()] ? Jin[i()][r()] : T(0); });
+    chol_fwd<N>(L, il, b, x);
+    sfor<N>([&](auto i) ABRK_LAMBDA { Y[i()][r()] = x[i()]; });
+  });
+  // Mx_inv = J M^-1 J^T = Y^T Y (osc.py:137); a masked row is an isolated unit diagonal, which leaves determinant,
+  // inverse and singular values of the selected block as they are
+  T Am[21];
+  sfor<6>([&](auto r) ABRK_LAMBDA {
+    sfor<r() + 1>([&](auto c) ABRK_LAMBDA {
+      T acc = T(-0.0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { acc += Y[i()][r()] * Y[i()][c()]; });
+      Am[tri(r(), c())] = acc;
+    });
+    if (!sel[r()]) Am[tri(r(), r())] = T(1);
+  });
+  T LA[21], ila[6];
+  const bool okA = chol<6>(Am, LA, ila);
+  T det = T(1);
+  sfor<6>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
+  if (okA && det >= thr) {  // osc.py:138-141
+    chol_inverse<6>(LA, ila, Mx);
+  } else {  // osc.py:142-145: pinv(rcond = 0.1 threshold) of a symmetric positive semi-definite matrix
+    T S[21], V[6][6], lam[6];
+    sfor<21>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
+    jacobi_eig<6>(S, V, lam);
+    T smax = T(0);
+    sfor<6>([&](auto r) ABRK_LAMBDA {
+      lam[r()] = sel[r()] ? lam[r()] : T(0);  // Jacobi never rotates an isolated unit diagonal: eigenpair r = (1, e_r)
+      smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()]));
+    });
+    const T cut = T(0.1) * thr * smax;
+    T wv[6];
+    sfor<6>([&](auto r) ABRK_LAMBDA {
+      const bool keep = Rm<T>::fabs(lam[r()]) > cut;
+      wv[r()] = keep ? rcp(keep ? lam[r()] : T(1)) : T(0);
+    });
+    sfor<6>([&](auto a) ABRK_LAMBDA {
+      sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
+        T acc = T(-0.0);
+        sfor<6>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
+        Mx[tri(a(), b())] = acc;
+      });
+    });
+  }
+}
+
+// OSC._velocity_limiting (osc.py:198-215, constants osc.py:89-115)
+template <class T>
+ABRK_INL void velocity_limiting_row(T kp, T ko, T kv, T vmax0, T vmax1, T (&ut)[6]) {
+  const T sat_xyz = vmax0 / kp * kv, sat_abg = vmax1 / ko * kv;
+  const T nx = Rm<T>::sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
+  const T na = Rm<T>::sqrt(ut[3] * ut[3] + ut[4] * ut[4] + ut[5] * ut[5]);
+  const T sx = (nx > sat_xyz) ? sat_xyz / nx : T(1);
+  const T sa = (na > sat_abg) ? sat_abg / na : T(1);
+  const T lx = kp / kv, la = ko / kv;
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    ut[r()] = kv * sx * lx * ut[r()];
+    ut[3 + r()] = kv * sa * la * ut[3 + r()];
+  });
+}
+
 }  // namespace abrk

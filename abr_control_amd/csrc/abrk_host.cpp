@@ -806,6 +806,75 @@ extern "C" int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params
   return st.finish();
 }
 
+// ------------------------------------------------------------------------------- helper methods of OSC
+static int check_helper(int dtype, int64_t B) {
+  if (dtype != ABRK_F64 && dtype != ABRK_F32) return fail(ABRK_EINVAL, "dtype %d is not ABRK_F64/ABRK_F32", dtype);
+  if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
+  return 0;
+}
+
+extern "C" int abrk_osc_mx_batch(int n_joints, int k, int dtype, int64_t B, const void* M, const void* J,
+                                 double threshold, void* Mx, void* M_inv, int device, void* stream) {
+  const int n = n_joints;
+  if (n < 1 || n > ABRK_MAX_JOINTS) return fail(ABRK_EINVAL, "n_joints=%d outside 1..%d", n, ABRK_MAX_JOINTS);
+  if (k < 1 || k > 6) return fail(ABRK_EINVAL, "k=%d task rows outside 1..6", k);
+  if (int rc = check_helper(dtype, B)) return rc;
+  if (!M || !J || !Mx) return fail(ABRK_EINVAL, "M, J and Mx are required");
+  if (!(threshold >= 0)) return fail(ABRK_EINVAL, "threshold must be >= 0");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* M_ = st.add(M, B * n * n * s, true, false);
+  const void* J_ = st.add(J, B * k * n * s, true, false);
+  void* X_ = st.add(Mx, B * k * k * s, false, true);
+  void* I_ = st.add(M_inv, B * n * n * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
+  HIPCHK(launch_osc_mx(n, dtype, la, k, threshold, st.fix(M_, M), st.fix(J_, J), st.fix(X_, Mx), st.fix(I_, M_inv)));
+  return st.finish();
+}
+
+extern "C" int abrk_osc_velocity_limiting_batch(int dtype, const abrk_osc_params* P, int64_t B, const void* u_task,
+                                                void* out, int device, void* stream) {
+  if (int rc = check_helper(dtype, B)) return rc;
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (!P->use_vmax) return fail(ABRK_EINVAL, "velocity limiting needs vmax (OSC(vmax=[xyz, abg]))");
+  if (!u_task || !out) return fail(ABRK_EINVAL, "u_task and out are required");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* i_ = st.add(u_task, B * 6 * s, true, false);
+  void* o_ = st.add(out, B * 6 * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
+  const double g[5] = {P->kp, P->ko, P->kv, P->vmax[0], P->vmax[1]};
+  HIPCHK(launch_velocity_limiting(dtype, la, g, st.fix(i_, u_task), st.fix(o_, out)));
+  return st.finish();
+}
+
+extern "C" int abrk_osc_orientation_forces_batch(int algorithm, int dtype, int64_t B, const void* R,
+                                                 const void* target_abg, void* u_task_orientation, int device,
+                                                 void* stream) {
+  if (int rc = check_helper(dtype, B)) return rc;
+  if (algorithm != 0 && algorithm != 1)
+    return fail(ABRK_EINVAL, "Invalid algorithm number %d for calculating orientation error", algorithm);
+  if (!R || !target_abg || !u_task_orientation) return fail(ABRK_EINVAL, "R, target_abg and the output are required");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* R_ = st.add(R, B * 9 * s, true, false);
+  const void* a_ = st.add(target_abg, B * 3 * s, true, false);
+  void* o_ = st.add(u_task_orientation, B * 3 * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
+  HIPCHK(launch_orientation_forces(dtype, la, algorithm, st.fix(R_, R), st.fix(a_, target_abg),
+                                   st.fix(o_, u_task_orientation)));
+  return st.finish();
+}
+
 // ------------------------------------------------------------------------------- two-link plant / closed loop
 namespace {
 template <class T>

@@ -173,6 +173,33 @@ obstacles_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restri
   obstacles_body<A, T>(b, arm, P, qg, ug, acc);
 }
 
+template <int N, class T>
+__global__ void __launch_bounds__(kBlock)
+mx_kernel(long B, int k, T thr, const T* __restrict__ Mg, const T* __restrict__ Jg, T* __restrict__ Mxg,
+          T* __restrict__ Minvg) {
+  ABRK_ROW_INDEX
+  mx_body<N, T>(b, k, thr, Mg, Jg, Mxg, Minvg);
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+velocity_limiting_kernel(long B, T kp, T ko, T kv, T vmax0, T vmax1, const T* __restrict__ ing, T* __restrict__ outg) {
+  ABRK_ROW_INDEX
+  velocity_limiting_body<T>(b, kp, ko, kv, vmax0, vmax1, ing, outg);
+}
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+orientation_forces_kernel(long B, int alg, const T* __restrict__ Rg, const T* __restrict__ ag, T* __restrict__ outg) {
+  ABRK_ROW_INDEX
+  orientation_forces_body<T>(b, alg, Rg, ag, outg);
+}
+// arm-independent helpers of the OSC law (abrk_law.hip)
+hipError_t launch_osc_mx(int n_joints, int dtype, const LaunchArgs& la, int k, double threshold, const void* M,
+                         const void* J, void* Mx, void* Minv);
+hipError_t launch_velocity_limiting(int dtype, const LaunchArgs& la, const double (&gains)[5], const void* in,
+                                    void* out);
+hipError_t launch_orientation_forces(int dtype, const LaunchArgs& la, int alg, const void* R, const void* abg,
+                                     void* out);
+
 struct FloatingArgs {
   int dynamic, task_space, acc;
   const void *q, *dq;

@@ -35,6 +35,41 @@ hipError_t launch_limits(int n, int dtype, const LaunchArgs& la, const void* P, 
 #undef ABRK_CASE
   return hipErrorInvalidValue;
 }
+template <int N, class T>
+static hipError_t mx_launch(const LaunchArgs& la, int k, double thr, const void* M, const void* J, void* Mx, void* Minv) {
+  hipLaunchKernelGGL((mx_kernel<N, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, la.B, k, T(thr), (const T*)M,
+                     (const T*)J, (T*)Mx, (T*)Minv);
+  return hipGetLastError();
+}
+hipError_t launch_osc_mx(int n, int dtype, const LaunchArgs& la, int k, double thr, const void* M, const void* J,
+                         void* Mx, void* Minv) {
+#define ABRK_CASE(NN) \
+  case NN:            \
+    return dtype == 0 ? mx_launch<NN, double>(la, k, thr, M, J, Mx, Minv) : mx_launch<NN, float>(la, k, thr, M, J, Mx, Minv);
+  switch (n) {
+    ABRK_CASE(1) ABRK_CASE(2) ABRK_CASE(3) ABRK_CASE(4) ABRK_CASE(5) ABRK_CASE(6) ABRK_CASE(7)
+  }
+#undef ABRK_CASE
+  return hipErrorInvalidValue;
+}
+hipError_t launch_velocity_limiting(int dtype, const LaunchArgs& la, const double (&g)[5], const void* in, void* out) {
+  if (dtype == 0)
+    hipLaunchKernelGGL((velocity_limiting_kernel<double>), grid_for(la.B), dim3(kBlock), 0, la.stream, la.B, g[0], g[1],
+                       g[2], g[3], g[4], (const double*)in, (double*)out);
+  else
+    hipLaunchKernelGGL((velocity_limiting_kernel<float>), grid_for(la.B), dim3(kBlock), 0, la.stream, la.B, float(g[0]),
+                       float(g[1]), float(g[2]), float(g[3]), float(g[4]), (const float*)in, (float*)out);
+  return hipGetLastError();
+}
+hipError_t launch_orientation_forces(int dtype, const LaunchArgs& la, int alg, const void* R, const void* abg, void* out) {
+  if (dtype == 0)
+    hipLaunchKernelGGL((orientation_forces_kernel<double>), grid_for(la.B), dim3(kBlock), 0, la.stream, la.B, alg,
+                       (const double*)R, (const double*)abg, (double*)out);
+  else
+    hipLaunchKernelGGL((orientation_forces_kernel<float>), grid_for(la.B), dim3(kBlock), 0, la.stream, la.B, alg,
+                       (const float*)R, (const float*)abg, (float*)out);
+  return hipGetLastError();
+}
 hipError_t launch_twolink_step(int dtype, const LaunchArgs& la, const void* K, void* q, void* dq, const void* u) {
   if (dtype == 0)
     hipLaunchKernelGGL((twolink_step_kernel<double>), grid_for(la.B), dim3(kBlock), 0, la.stream,

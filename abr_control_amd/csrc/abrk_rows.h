@@ -352,4 +352,47 @@ ABRK_INL void twolink_step_body(long b, const TwoLinkP<T>& K, T* __restrict__ qg
   store_row<2>(dqg, b, dq);
 }
 
+// ---- OSC._Mx / ._velocity_limiting / ._calc_orientation_forces for B rows (osc.py:120-215)
+template <int N, class T>
+ABRK_INL void mx_body(long b, int k, T thr, const T* __restrict__ Mg, const T* __restrict__ Jg, T* __restrict__ Mxg,
+                      T* __restrict__ Minvg) {
+  T Ms[N * (N + 1) / 2], Jr[N][6], Mx[21], Minv[N * (N + 1) / 2];
+  const T* Mp = Mg + b * (N * N);
+  sfor<N>([&](auto i) ABRK_LAMBDA { sfor<i() + 1>([&](auto j) ABRK_LAMBDA { Ms[tri(i(), j())] = Mp[i() * N + j()]; }); });
+  const T* Jp = Jg + b * (long)k * N;
+  sfor<6>([&](auto r) ABRK_LAMBDA {
+    sfor<N>([&](auto i) ABRK_LAMBDA { Jr[i()][r()] = (r() < k) ? Jp[r() * N + i()] : T(0); });
+  });
+  mx_row<N, T>(Ms, Jr, k, thr, Mx, Minv);
+  T* Xp = Mxg + b * (long)k * k;
+  sfor<6>([&](auto r) ABRK_LAMBDA {
+    sfor<6>([&](auto c) ABRK_LAMBDA {
+      if (r() < k && c() < k) Xp[r() * k + c()] = Mx[tri(r(), c())];
+    });
+  });
+  if (Minvg) {
+    T* Ip = Minvg + b * (N * N);
+    sfor<N>([&](auto i) ABRK_LAMBDA { sfor<N>([&](auto j) ABRK_LAMBDA { Ip[i() * N + j()] = Minv[tri(i(), j())]; }); });
+  }
+}
+
+template <class T>
+ABRK_INL void velocity_limiting_body(long b, T kp, T ko, T kv, T vmax0, T vmax1, const T* __restrict__ ing,
+                                     T* __restrict__ outg) {
+  T ut[6];
+  load_row<6>(ing, b, ut);
+  velocity_limiting_row<T>(kp, ko, kv, vmax0, vmax1, ut);
+  store_row<6>(outg, b, ut);
+}
+
+template <class T>
+ABRK_INL void orientation_forces_body(long b, int alg, const T* __restrict__ Rg, const T* __restrict__ ag,
+                                      T* __restrict__ outg) {
+  T R[9], abg[3], uo[3];
+  load_row<9>(Rg, b, R);
+  load_row<3>(ag, b, abg);
+  orientation_forces(alg, R, abg, uo);
+  store_row<3>(outg, b, uo);
+}
+
 }  // namespace abrk

@@ -178,6 +178,39 @@ def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=N
     return (uo, tso) if training_signal else uo
 
 
+def osc_mx(n, M, J, threshold=1e-3, want_minv=True, dtype=np.float64, device=0, stream=None):
+    """OSC._Mx (osc.py:120-147) for B rows: M [B,n,n], J [B,k,n] -> (Mx [B,k,k], M_inv [B,n,n] or None)"""
+    a = _Args(dtype)
+    B, k = J.shape[0], J.shape[1]
+    Mp = a.inp(M, (B, n, n), "M")
+    Jp = a.inp(J, (B, k, n), "J")
+    xp, xo = a.out(None, (B, k, k), device, "Mx")
+    ip, io = a.out(None, (B, n, n), device, "M_inv") if want_minv else (None, None)
+    check(lib().abrk_osc_mx_batch(n, k, a.code, B, Mp, Jp, float(threshold), xp, ip, device, _sp(stream)))
+    return xo, io
+
+
+def osc_velocity_limiting(params, u_task, dtype=np.float64, device=0, stream=None):
+    """OSC._velocity_limiting (osc.py:198-215) for B rows of u_task [B,6]"""
+    a = _Args(dtype)
+    B = u_task.shape[0]
+    ip = a.inp(u_task, (B, 6), "u_task")
+    op, oo = a.out(None, (B, 6), device, "out")
+    check(lib().abrk_osc_velocity_limiting_batch(a.code, C.byref(params), B, ip, op, device, _sp(stream)))
+    return oo
+
+
+def osc_orientation_forces(algorithm, R, target_abg, dtype=np.float64, device=0, stream=None):
+    """OSC._calc_orientation_forces (osc.py:149-196) from R [B,3,3] = robot_config.R(ref_frame, q), target_abg [B,3]"""
+    a = _Args(dtype)
+    B = R.shape[0]
+    Rp = a.inp(R, (B, 3, 3), "R")
+    tp = a.inp(target_abg, (B, 3), "target_abg")
+    op, oo = a.out(None, (B, 3), device, "u_task_orientation")
+    check(lib().abrk_osc_orientation_forces_batch(int(algorithm), a.code, B, Rp, tp, op, device, _sp(stream)))
+    return oo
+
+
 def sliding_generate(arm_id, n, params, q, dq, target, target_velocity=None, target_acc=None, u=None,
                      want_s=False, dtype=np.float64, device=0, stream=None):
     a = _Args(dtype)

@@ -202,6 +202,24 @@ int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params* params, i
                        void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
                        int device, void* stream);
 
+/* The helper methods of OSC that callers (and the reference's own tests, controllers/tests/test_osc.py:12-140)
+ * use directly.  The fused kernels above carry the same steps inline; these are their general forms.
+ *
+ * OSC._Mx (controllers/osc.py:120-147): task-space inertia Mx = (J M^-1 J^T)^-1, inverse while
+ * |det| >= threshold, else pinv(rcond = 0.1 threshold).
+ *   M [B,n,n] symmetric positive definite; J [B,k,n] = the k task rows OSC keeps (J[ctrlr_dof]), 1 <= k <= 6;
+ *   Mx [B,k,k] out; M_inv [B,n,n] out or NULL.                                                    */
+int abrk_osc_mx_batch(int n_joints, int k, int dtype, int64_t B, const void* M, const void* J, double threshold,
+                      void* Mx, void* M_inv, int device, void* stream);
+/* OSC._velocity_limiting (osc.py:198-215): u_task [B,6] -> out [B,6] with kp, ko, kv, vmax of params
+ * (params->use_vmax must be set).                                                                 */
+int abrk_osc_velocity_limiting_batch(int dtype, const abrk_osc_params* params, int64_t B, const void* u_task,
+                                     void* out, int device, void* stream);
+/* OSC._calc_orientation_forces (osc.py:149-196) from R [B,3,3] = robot_config.R(ref_frame, q) (W_R of
+ * abrk_dynamics_batch) and target_abg [B,3] (Euler angles, 'rxyz'); algorithm 0 or 1; out [B,3]. */
+int abrk_osc_orientation_forces_batch(int algorithm, int dtype, int64_t B, const void* R, const void* target_abg,
+                                      void* u_task_orientation, int device, void* stream);
+
 /* Launch plans for control loops that call the same law on the same device buffers every tick (the
  * shape of every example loop, examples/PyGame/force_osc_xy.py:57-78): all arguments of
  * abrk_osc_generate_batch are validated and converted ONCE; abrk_plan_launch then only enqueues the
