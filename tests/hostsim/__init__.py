@@ -194,6 +194,37 @@ def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=N
     return u, ts
 
 
+def osc_mx(n, M, J, threshold=1e-3, dtype=np.float64):
+    dt = np.dtype(dtype)
+    M, J = _in(M, dt), _in(J, dt)
+    B, k = J.shape[0], J.shape[1]
+    Mx, Minv = np.full((B, k, k), np.nan, dt), np.full((B, n, n), np.nan, dt)
+    rc = _lib_for(law=True).hostsim_osc_mx(n, k, _dtype_code(dt), C.c_int64(B), _p(M), _p(J), C.c_double(threshold),
+                                           _p(Mx), _p(Minv))
+    assert rc == 0, rc
+    return Mx, Minv
+
+
+def osc_velocity_limiting(params, u_task, dtype=np.float64):
+    dt = np.dtype(dtype)
+    u_task = _in(u_task, dt)
+    out = np.full(u_task.shape, np.nan, dt)
+    rc = _lib_for(law=True).hostsim_velocity_limiting(_dtype_code(dt), C.byref(params), C.c_int64(len(u_task)),
+                                                      _p(u_task), _p(out))
+    assert rc == 0, rc
+    return out
+
+
+def osc_orientation_forces(alg, R, abg, dtype=np.float64):
+    dt = np.dtype(dtype)
+    R, abg = _in(R, dt), _in(abg, dt)
+    out = np.full((len(R), 3), np.nan, dt)
+    rc = _lib_for(law=True).hostsim_orientation_forces(int(alg), _dtype_code(dt), C.c_int64(len(R)), _p(R), _p(abg),
+                                                       _p(out))
+    assert rc == 0, rc
+    return out
+
+
 def rollout_twolink(arm, params, plant, q0, dq0, target, n_steps, every, dtype=np.float64):
     name, desc, n = _arm(arm)
     dt = np.dtype(dtype)

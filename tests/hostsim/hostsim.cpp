@@ -225,6 +225,42 @@ extern "C" int hostsim_limits(int n, int dtype, const abrk_limits_params* P, int
   return -1;
 }
 
+extern "C" int hostsim_osc_mx(int n, int k, int dtype, int64_t B, const void* M, const void* J, double thr, void* Mx,
+                              void* Minv) {
+#define MX_CASE(NN)                                                                                               \
+  if (n == NN) {                                                                                                  \
+    for (long b = 0; b < B; b++) {                                                                                \
+      if (dtype == 0)                                                                                             \
+        mx_body<NN, double>(b, k, thr, (const double*)M, (const double*)J, (double*)Mx, (double*)Minv);           \
+      else                                                                                                        \
+        mx_body<NN, float>(b, k, float(thr), (const float*)M, (const float*)J, (float*)Mx, (float*)Minv);         \
+    }                                                                                                             \
+    return 0;                                                                                                     \
+  }
+  MX_CASE(1) MX_CASE(2) MX_CASE(3) MX_CASE(4) MX_CASE(5) MX_CASE(6) MX_CASE(7)
+#undef MX_CASE
+  return -1;
+}
+extern "C" int hostsim_velocity_limiting(int dtype, const abrk_osc_params* P, int64_t B, const void* in, void* out) {
+  for (long b = 0; b < B; b++) {
+    if (dtype == 0)
+      velocity_limiting_body<double>(b, P->kp, P->ko, P->kv, P->vmax[0], P->vmax[1], (const double*)in, (double*)out);
+    else
+      velocity_limiting_body<float>(b, float(P->kp), float(P->ko), float(P->kv), float(P->vmax[0]), float(P->vmax[1]),
+                                    (const float*)in, (float*)out);
+  }
+  return 0;
+}
+extern "C" int hostsim_orientation_forces(int alg, int dtype, int64_t B, const void* R, const void* abg, void* out) {
+  for (long b = 0; b < B; b++) {
+    if (dtype == 0)
+      orientation_forces_body<double>(b, alg, (const double*)R, (const double*)abg, (double*)out);
+    else
+      orientation_forces_body<float>(b, alg, (const float*)R, (const float*)abg, (float*)out);
+  }
+  return 0;
+}
+
 extern "C" int hostsim_osc_law(int n, int dtype, const abrk_osc_params* P, int64_t B, const void* J, const void* M,
                                const void* g, const void* c, const void* xyz, const void* R, const void* q,
                                const void* dq, const void* tg, const void* tv, void* ie, const void* une, void* u,

@@ -840,3 +840,32 @@ def test_gpu_osc_helpers_fp32_and_errors():
     # empty batch
     Mx, _ = engine.osc_mx(n, np.zeros((0, n, n)), np.zeros((0, 3, n)))
     assert Mx.shape == (0, 3, 3)
+
+
+def test_gpu_twojoint_closed_forms_through_robot_config():
+    """abr_control/arms/tests/test_base_config.py:40-180 (test_g, test_dJ, test_J, test_M, test_R, test_C, test_Tx,
+    test_T_inv): every robot_config function of the two-link arm against the hand-derived closed forms of the
+    reference's fixture (arms/tests/dummy_base_arm.py) on its grids, np.allclose defaults as there - here through the
+    Python mirror, whole grids per call"""
+    from abr_control_amd.arms import twojoint
+
+    k = golden("known_answers")
+    robot_config = twojoint.Config()
+    Q, QD = k["q_grid"], k["qdq_grid"]
+    assert np.allclose(robot_config.g(Q), k["g"])
+    assert np.allclose(robot_config.M(Q), k["M"])
+    assert np.allclose(robot_config.C(QD[:, :2], QD[:, 2:]), k["C"])
+    for name in ("link0", "joint0", "link1", "joint1", "link2", "EE"):
+        assert np.allclose(robot_config.J(name, Q), k[f"J_{name}"]), name
+        assert np.allclose(robot_config.dJ(name, QD[:, :2], QD[:, 2:]), k[f"dJ_{name}"]), name
+        assert np.allclose(robot_config.R(name, Q), k[f"R_{name}"]), name
+        assert np.allclose(robot_config.Tx(name, Q), k[f"Tx_{name}"]), name
+        assert np.allclose(robot_config.T_inv(name, Q), k[f"Tinv_{name}"]), name
+    # one state at a time, as the reference's tests call them: reference shapes and dtypes (base_config.py:223-415)
+    q, dq = Q[77], QD[1234, 2:]
+    assert robot_config.g(q).shape == (2,) and robot_config.g(q).dtype == np.float32
+    assert robot_config.M(q).shape == (2, 2) and robot_config.J("EE", q).shape == (6, 2)
+    assert robot_config.Tx("EE", q).dtype == np.float64 and robot_config.Tx("EE", q).shape == (3,)
+    assert robot_config.C(q, dq).shape == (2, 2) and robot_config.dJ("EE", q, dq).shape == (6, 2)
+    with pytest.raises(Exception, match="Invalid transformation name"):
+        robot_config.Tx("link9", q)

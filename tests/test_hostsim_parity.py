@@ -310,3 +310,36 @@ def test_rows_six_row_use_C_on_orthogonal_chains(arm):
 @pytest.mark.parametrize("seed", range(12))
 def test_rows_fuzz_sliding_joint_dynamics(seed):
     cases.check_fuzz_other(cases.HostsimBackend, seed)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2", "threejoint"])
+def test_rows_osc_helper_methods_vs_reference(arm):
+    """the row programs behind OSC._Mx / ._velocity_limiting / ._calc_orientation_forces against the reference's own
+    outputs (tests/golden/oschelpers_<arm>.npz; inputs and expectations of controllers/tests/test_osc.py)"""
+    from abr_control_amd import _abi
+    from tests import hostsim
+
+    g = golden(f"oschelpers_{arm}")
+    kp, ko, kv, v0, v1 = g["vl_gains"]
+    n = g["mx_q"].shape[1]
+    p = _abi.make_osc_params(n, kp=kp, ko=ko, kv=kv, vmax=[v0, v1], ctrlr_dof=[1] * 6)
+    assert np.max(np.abs(hostsim.osc_velocity_limiting(p, g["vl_in"]) - g["vl_out"])) < 1e-12
+    for alg in (0, 1):
+        assert np.max(np.abs(hostsim.osc_orientation_forces(alg, g["of_R"], g["of_abg"]) - g[f"of_alg{alg}"])) < 1e-9
+    M = g["mx_M"]
+    B = len(M)
+    nrm = lambda a: np.maximum(np.abs(a).max(axis=(1, 2)), 1e-300)
+    Mx, Minv = hostsim.osc_mx(n, M, np.broadcast_to(np.eye(n), (B, n, n)).copy(), 1e-5)
+    assert np.allclose(Mx, M, atol=1e-5)  # test_osc.py:80
+    assert (np.abs(Mx - g["mx_eye_Mx"]).max(axis=(1, 2)) / nrm(g["mx_eye_Mx"])).max() < 1e-9
+    assert (np.abs(Minv - g["mx_eye_Minv"]).max(axis=(1, 2)) / nrm(g["mx_eye_Minv"])).max() < 1e-9
+    Mx1, _ = hostsim.osc_mx(n, M, np.ones((B, 6, n)))
+    assert all(np.all(np.linalg.svd(x)[1][1:] < 1e-10) for x in Mx1)  # test_osc.py:86
+    assert (np.abs(Mx1 - g["mx_ones_Mx"]).max(axis=(1, 2)) / nrm(g["mx_ones_Mx"])).max() < 1e-9
+    for k in (1, 2, 3, 6):
+        if f"mx_k{k}_J" not in g.files:
+            continue
+        ok = cases.mx_rows_clear_of_thresholds(g[f"mx_k{k}_det"], g[f"mx_k{k}_sv"])
+        Mxk, _ = hostsim.osc_mx(n, M, g[f"mx_k{k}_J"])
+        err = np.abs(Mxk - g[f"mx_k{k}_Mx"]).max(axis=(1, 2)) / nrm(g[f"mx_k{k}_Mx"])
+        assert err[ok].max() <= 1e-7, (k, err[ok].max())
