@@ -875,6 +875,27 @@ extern "C" int abrk_osc_orientation_forces_batch(int algorithm, int dtype, int64
   return st.finish();
 }
 
+extern "C" int abrk_transformations_batch(int op, int dtype, int64_t B, const void* a, const void* b, void* out,
+                                          int device, void* stream) {
+  // elements per row of (a, b, out) for each ABRK_TF_* operation
+  static const int kIn[8] = {3, 3, 9, 4, 4, 4, 3, 3}, kIn2[8] = {0, 0, 0, 4, 0, 0, 0, 0}, kOut[8] = {4, 4, 4, 4, 4, 4, 3, 9};
+  if (op < 0 || op > 7) return fail(ABRK_EINVAL, "unknown transformations op %d", op);
+  if (int rc = check_helper(dtype, B)) return rc;
+  if (!a || !out || (kIn2[op] && !b)) return fail(ABRK_EINVAL, "input and output arrays are required");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* b_in = kIn2[op] ? b : nullptr;
+  const void* a_ = st.add(a, B * kIn[op] * s, true, false);
+  const void* b_ = st.add(b_in, B * kIn2[op] * s, true, false);
+  void* o_ = st.add(out, B * kOut[op] * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
+  HIPCHK(launch_transformations(dtype, la, op, st.fix(a_, a), st.fix(b_, b_in), st.fix(o_, out)));
+  return st.finish();
+}
+
 // ------------------------------------------------------------------------------- two-link plant / closed loop
 namespace {
 template <class T>

@@ -192,6 +192,13 @@ orientation_forces_kernel(long B, int alg, const T* __restrict__ Rg, const T* __
   ABRK_ROW_INDEX
   orientation_forces_body<T>(b, alg, Rg, ag, outg);
 }
+template <class T>
+__global__ void __launch_bounds__(kBlock)
+transformations_kernel(long B, int op, const T* __restrict__ ag, const T* __restrict__ bg, T* __restrict__ outg) {
+  ABRK_ROW_INDEX
+  transformations_body<T>(b, op, ag, bg, outg);
+}
+hipError_t launch_transformations(int dtype, const LaunchArgs& la, int op, const void* a, const void* b, void* out);
 // arm-independent helpers of the OSC law (abrk_law.hip)
 hipError_t launch_osc_mx(int n_joints, int dtype, const LaunchArgs& la, int k, double threshold, const void* M,
                          const void* J, void* Mx, void* Minv);

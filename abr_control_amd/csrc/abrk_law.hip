@@ -70,6 +70,15 @@ hipError_t launch_orientation_forces(int dtype, const LaunchArgs& la, int alg, c
                        (const float*)R, (const float*)abg, (float*)out);
   return hipGetLastError();
 }
+hipError_t launch_transformations(int dtype, const LaunchArgs& la, int op, const void* a, const void* b, void* out) {
+  if (dtype == 0)
+    hipLaunchKernelGGL((transformations_kernel<double>), grid_for(la.B), dim3(kBlock), 0, la.stream, la.B, op,
+                       (const double*)a, (const double*)b, (double*)out);
+  else
+    hipLaunchKernelGGL((transformations_kernel<float>), grid_for(la.B), dim3(kBlock), 0, la.stream, la.B, op,
+                       (const float*)a, (const float*)b, (float*)out);
+  return hipGetLastError();
+}
 hipError_t launch_twolink_step(int dtype, const LaunchArgs& la, const void* K, void* q, void* dq, const void* u) {
   if (dtype == 0)
     hipLaunchKernelGGL((twolink_step_kernel<double>), grid_for(la.B), dim3(kBlock), 0, la.stream,

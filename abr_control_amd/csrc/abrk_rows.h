@@ -395,4 +395,56 @@ ABRK_INL void orientation_forces_body(long b, int alg, const T* __restrict__ Rg,
   store_row<3>(outg, b, uo);
 }
 
+// ---- the six functions of abr_control/utils/transformations.py that the control path uses (:973 euler_matrix,
+// :1096 quaternion_from_euler, :1192 quaternion_from_matrix, :1274 quaternion_multiply, :1293 quaternion_conjugate,
+// :1632 unit_vector), one row each.  Euler axes: 'rxyz' (osc.py:164,178) and 'sxyz' (inverse_kinematics.py:73-82).
+enum { TF_QUAT_FROM_EULER_RXYZ = 0, TF_QUAT_FROM_EULER_SXYZ = 1, TF_QUAT_FROM_MATRIX = 2, TF_QUAT_MULTIPLY = 3,
+       TF_QUAT_CONJUGATE = 4, TF_UNIT_VECTOR4 = 5, TF_UNIT_VECTOR3 = 6, TF_EULER_MATRIX_RXYZ = 7 };
+template <class T>
+ABRK_INL void transformations_body(long b, int op, const T* __restrict__ ag, const T* __restrict__ bg,
+                                   T* __restrict__ outg) {
+  if (op == TF_QUAT_FROM_EULER_RXYZ || op == TF_QUAT_FROM_EULER_SXYZ) {
+    T a[3], q[4];
+    load_row<3>(ag, b, a);
+    if (op == TF_QUAT_FROM_EULER_RXYZ) quat_from_euler_rxyz(a[0], a[1], a[2], q);
+    else quat_from_euler_sxyz(a[0], a[1], a[2], q);
+    store_row<4>(outg, b, q);
+  } else if (op == TF_QUAT_FROM_MATRIX) {
+    T R[9], q[4];
+    load_row<9>(ag, b, R);
+    quat_from_R(R, q);
+    store_row<4>(outg, b, q);
+  } else if (op == TF_QUAT_MULTIPLY) {
+    T q1[4], q0[4], r[4];
+    load_row<4>(ag, b, q1);
+    load_row<4>(bg, b, q0);
+    quat_mul(q1, q0, r);
+    store_row<4>(outg, b, r);
+  } else if (op == TF_QUAT_CONJUGATE) {
+    T q[4];
+    load_row<4>(ag, b, q);
+    q[1] = -q[1];
+    q[2] = -q[2];
+    q[3] = -q[3];
+    store_row<4>(outg, b, q);
+  } else if (op == TF_UNIT_VECTOR4) {
+    T v[4];
+    load_row<4>(ag, b, v);
+    const T inv = T(1) / Rm<T>::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]);
+    sfor<4>([&](auto i) ABRK_LAMBDA { v[i()] *= inv; });
+    store_row<4>(outg, b, v);
+  } else if (op == TF_UNIT_VECTOR3) {
+    T v[3];
+    load_row<3>(ag, b, v);
+    const T inv = T(1) / Rm<T>::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    sfor<3>([&](auto i) ABRK_LAMBDA { v[i()] *= inv; });
+    store_row<3>(outg, b, v);
+  } else {
+    T a[3], M[9];
+    load_row<3>(ag, b, a);
+    euler_matrix_rxyz(a[0], a[1], a[2], M);
+    store_row<9>(outg, b, M);
+  }
+}
+
 }  // namespace abrk

@@ -211,6 +211,22 @@ def osc_orientation_forces(algorithm, R, target_abg, dtype=np.float64, device=0,
     return oo
 
 
+_TF_WIDTHS = {0: (3, 0, 4), 1: (3, 0, 4), 2: (9, 0, 4), 3: (4, 4, 4), 4: (4, 0, 4), 5: (4, 0, 4), 6: (3, 0, 3),
+              7: (3, 0, 9)}
+
+
+def transformations(op, a, b=None, dtype=np.float64, device=0, stream=None):
+    """abrk_transformations_batch: op = ABRK_TF_* (include/abrk.h); a [B,wa], b [B,wb] or None -> out [B,wo]"""
+    wa, wb, wo = _TF_WIDTHS[int(op)]
+    ar = _Args(dtype)
+    B = a.shape[0]
+    ap = ar.inp(a, (B, wa), "a")
+    bp = ar.inp(b, (B, wb), "b") if wb else None
+    op_, oo = ar.out(None, (B, wo), device, "out")
+    check(lib().abrk_transformations_batch(int(op), ar.code, B, ap, bp, op_, device, _sp(stream)))
+    return oo
+
+
 def sliding_generate(arm_id, n, params, q, dq, target, target_velocity=None, target_acc=None, u=None,
                      want_s=False, dtype=np.float64, device=0, stream=None):
     a = _Args(dtype)

@@ -220,6 +220,22 @@ int abrk_osc_velocity_limiting_batch(int dtype, const abrk_osc_params* params, i
 int abrk_osc_orientation_forces_batch(int algorithm, int dtype, int64_t B, const void* R, const void* target_abg,
                                       void* u_task_orientation, int device, void* stream);
 
+/* The functions of abr_control/utils/transformations.py that the control path uses, B rows per call:
+ *   ABRK_TF_QUAT_FROM_EULER_RXYZ / _SXYZ  a [B,3] angles          -> out [B,4] (w,x,y,z)   transformations.py:1096
+ *   ABRK_TF_QUAT_FROM_MATRIX              a [B,3,3] rotations     -> out [B,4], w >= 0     :1192
+ *   ABRK_TF_QUAT_MULTIPLY                 a = q1, b = q0 [B,4]    -> out [B,4]             :1274
+ *   ABRK_TF_QUAT_CONJUGATE                a [B,4]                 -> out [B,4]             :1293
+ *   ABRK_TF_UNIT_VECTOR4 / _VECTOR3       a [B,4] / [B,3]         -> out same shape        :1632
+ *   ABRK_TF_EULER_MATRIX_RXYZ             a [B,3] angles          -> out [B,3,3]           :973
+ * b is NULL except for the product.                                                               */
+enum {
+  ABRK_TF_QUAT_FROM_EULER_RXYZ = 0, ABRK_TF_QUAT_FROM_EULER_SXYZ = 1, ABRK_TF_QUAT_FROM_MATRIX = 2,
+  ABRK_TF_QUAT_MULTIPLY = 3, ABRK_TF_QUAT_CONJUGATE = 4, ABRK_TF_UNIT_VECTOR4 = 5, ABRK_TF_UNIT_VECTOR3 = 6,
+  ABRK_TF_EULER_MATRIX_RXYZ = 7
+};
+int abrk_transformations_batch(int op, int dtype, int64_t B, const void* a, const void* b, void* out, int device,
+                               void* stream);
+
 /* Launch plans for control loops that call the same law on the same device buffers every tick (the
  * shape of every example loop, examples/PyGame/force_osc_xy.py:57-78): all arguments of
  * abrk_osc_generate_batch are validated and converted ONCE; abrk_plan_launch then only enqueues the

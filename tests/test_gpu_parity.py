@@ -869,3 +869,42 @@ def test_gpu_twojoint_closed_forms_through_robot_config():
     assert robot_config.C(q, dq).shape == (2, 2) and robot_config.dJ("EE", q, dq).shape == (6, 2)
     with pytest.raises(Exception, match="Invalid transformation name"):
         robot_config.Tx("link9", q)
+
+
+def test_gpu_transformations_known_answers():
+    """abr_control/utils/transformations.py: the six functions on the control path against the reference's own
+    outputs on seeded inputs (tests/golden/known_answers.npz, written by oracle/gen_golden.py) and its doctest
+    constants (:1203-1214, :1276-1277, :1295-1299)"""
+    from abr_control_amd.utils import transformations as tf
+
+    k = golden("known_answers")
+    ang = k["tf_angles"]
+    assert np.allclose(tf.quaternion_from_euler(ang[:, 0], ang[:, 1], ang[:, 2], "rxyz"), k["tf_quat_from_euler_rxyz"],
+                       atol=1e-14)
+    M = tf.euler_matrix(ang[:, 0], ang[:, 1], ang[:, 2], "rxyz")
+    assert M.shape == (len(ang), 4, 4) and np.allclose(M[:, :3, :3], k["tf_euler_matrix_rxyz"], atol=1e-14)
+    assert np.allclose(M[:, 3], [0, 0, 0, 1]) and np.allclose(M[:, :3, 3], 0)
+    assert np.allclose(tf.quaternion_from_matrix(k["tf_euler_matrix_rxyz"]), k["tf_quat_from_matrix"], atol=1e-12)
+    assert np.allclose(tf.quaternion_multiply(k["tf_qa"], k["tf_qb"]), k["tf_quat_mul"], atol=1e-14)
+    assert np.allclose(tf.quaternion_conjugate(k["tf_qa"]), k["tf_quat_conj"], atol=0)
+    assert np.allclose(tf.unit_vector(k["tf_qa"], axis=-1), k["tf_unit"], atol=1e-15)
+    # the reference's doctests
+    assert np.allclose(tf.quaternion_multiply([4, 1, -2, 3], [8, -5, 6, 7]), [28, -44, -14, 48])
+    assert np.allclose(tf.quaternion_from_matrix(np.identity(4), True), [1, 0, 0, 0])
+    R = [[-0.545, 0.797, 0.260, 0], [0.733, 0.603, -0.313, 0], [-0.407, 0.021, -0.913, 0], [0, 0, 0, 1]]
+    assert np.allclose(tf.quaternion_from_matrix(R), [0.19069, 0.43736, 0.87485, -0.083611], atol=1e-5)
+    R = [[0.395, 0.362, 0.843, 0], [-0.626, 0.796, -0.056, 0], [-0.677, -0.498, 0.529, 0], [0, 0, 0, 1]]
+    assert np.allclose(tf.quaternion_from_matrix(R), [0.82336615, -0.13610694, 0.46344705, -0.29792603], atol=1e-5)
+    q0 = k["tf_qa"][0]
+    q1 = tf.quaternion_conjugate(q0)
+    assert q1[0] == q0[0] and all(q1[1:] == -q0[1:])
+    v0 = np.array([0.3, -1.2, 2.0])
+    assert np.allclose(tf.unit_vector(v0), v0 / np.linalg.norm(v0))
+    # the default axes of the reference ('sxyz') against the closed form of transformations.py:1131-1147
+    ai, aj, ak = 0.3, -0.7, 1.9
+    ci, si, cj, sj, ck, sk = (f(x / 2) for x in (ai, aj, ak) for f in (np.cos, np.sin))
+    want = [cj * ci * ck + sj * si * sk, cj * si * ck - sj * ci * sk, cj * si * sk + sj * ci * ck,
+            cj * ci * sk - sj * si * ck]
+    assert np.allclose(tf.quaternion_from_euler(ai, aj, ak), want, atol=1e-15)
+    with pytest.raises(ValueError):
+        tf.quaternion_from_euler(1, 2, 3, "ryxz")
