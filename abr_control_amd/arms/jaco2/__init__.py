@@ -1,1 +1,6 @@
+"""Kinova Jaco2 (6 joints in the reference): constant table of abr_control/arms/jaco2/config.py.
+
+Nothing is generated or compiled per arm at run time: `Config()` only registers the table with libabrk.so."""
 from .config import Config
+
+__all__ = ['Config']
