@@ -236,6 +236,32 @@ class Runner:
         return wall, ev1.elapsed_ms_since(ev0) / steps
 
 
+def concurrent_streams_rate(workload, B, device, n_streams, steps, graph_steps=100):
+    """Several INDEPENDENT batches of the config size, each with its own stream, launch plan and buffers (e.g. separate
+    fleets with separate control loops): the config-sized step is issue-latency-bound on 64 of the chip's 1024 SIMDs, so
+    concurrent loops fill the rest.  Reported beside `value` (one loop), never as `value`."""
+    import abr_control_amd as a
+
+    streams = [a.Stream(device) for _ in range(n_streams)]
+    runs = [Runner(workload, B, device, st) for st in streams]
+    reps = max(steps // graph_steps, 1)
+    for r in runs:  # warm-up: builds each plan's graph
+        r.plan.launch_graph(graph_steps)
+    for st in streams:
+        st.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        for r in runs:
+            r.plan.launch_graph(graph_steps)
+    for st in streams:
+        st.sync()
+    wall = time.perf_counter() - t0
+    total_steps = reps * graph_steps
+    return {"streams": n_streams, "batch_per_stream": B, "steps_per_stream": total_steps,
+            "evals_per_s": round(n_streams * B * total_steps / wall, 1),
+            "us_per_step_per_stream": round(wall / total_steps * 1e6, 3)}
+
+
 def profiled_traffic(kernel, batch):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
     (profiles/round1/traffic.json, tools/gpu_profiles.sh); None when that (kernel, batch) was not profiled."""
@@ -510,6 +536,8 @@ def main():
             _, ms_x = extra.timed(max(args.roofline_steps // 3, 3), 2)
             out["also"][w] = roofline(extra, ms_x, f"{w} batch={extra.B}")
             del extra
+    if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg:
+        out["concurrent_streams"] = [concurrent_streams_rate("cfg2", B, device, s, args.steps) for s in (2, 4, 8, 16)]
     if rank == 0 and args.workload == "cfg2":
         out["parity"] = parity_vs_reference(device)
         out["host_staged"] = host_staged_rate(device)
