@@ -1007,7 +1007,12 @@ struct OscPlan {
   OscP<double> p64;
   OscP<float> p32;
   OscArgs oa;
+  bool sliding = false;  // a Sliding.generate plan (abrk_sliding_plan_create) instead of an OSC one
+  SlidingP<double> s64;
+  SlidingP<float> s32;
+  SlidingArgs sa;
   LaunchArgs la;
+  hipError_t enqueue() const { return sliding ? ops->sliding(dtype, la, sa) : ops->osc(dtype, la, oa); }
   int graph_repeat = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
@@ -1019,6 +1024,9 @@ constexpr int kMaxPlans = 4096;
 OscPlan* g_plans[kMaxPlans] = {};
 int g_n_plans = 0;
 }  // namespace
+
+namespace { struct OscPlan; }
+static int register_plan(OscPlan* pl);
 
 extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
                                     const void* dq, const void* target, const void* target_velocity,
@@ -1063,6 +1071,10 @@ extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params
   pl->oa.use_C = P->use_C ? 1 : 0;
   pl->oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
   pl->la = LaunchArgs{a->builtin ? nullptr : (const void*)pl->rt.data(), (long)B, (hipStream_t)stream};
+  return register_plan(pl);
+}
+
+static int register_plan(OscPlan* pl) {
   std::lock_guard<std::mutex> lk(g_plan_mu);
   if (g_n_plans >= kMaxPlans) {
     delete pl;
@@ -1071,6 +1083,42 @@ extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params
   g_plans[g_n_plans] = pl;
   __atomic_thread_fence(__ATOMIC_RELEASE);
   return g_n_plans++;
+}
+
+extern "C" int abrk_sliding_plan_create(int arm_id, int dtype, const abrk_sliding_params* P, int64_t B, const void* q,
+                                        const void* dq, const void* target, const void* target_velocity,
+                                        const void* target_acc, void* u, void* s_out, int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (P->ref_frame < 0 || P->ref_frame > 2 * n + 1)
+    return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", P->ref_frame);
+  if (B <= 0) return fail(ABRK_EINVAL, "a plan needs a positive batch");
+  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
+  if (int rc = use_device(device)) return rc;
+  const void* ptrs[] = {q, dq, target, target_velocity, target_acc, u, s_out};
+  for (const void* p : ptrs)
+    if (p && !is_device_ptr(p)) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
+  OscPlan* pl = new OscPlan;
+  pl->live = true;
+  pl->sliding = true;
+  pl->dtype = dtype;
+  pl->device = device;
+  pl->ops = a->ops;
+  if (!a->builtin) pl->rt = dtype == ABRK_F64 ? a->rt64 : a->rt32;
+  pl->s64 = make_slidingp<double>(*P, n);
+  pl->s32 = make_slidingp<float>(*P, n);
+  pl->sa.P = dtype == ABRK_F64 ? (const void*)&pl->s64 : (const void*)&pl->s32;
+  pl->sa.q = q;
+  pl->sa.dq = dq;
+  pl->sa.target = target;
+  pl->sa.tv = target_velocity;
+  pl->sa.ta = target_acc;
+  pl->sa.u = u;
+  pl->sa.s = s_out;
+  pl->la = LaunchArgs{a->builtin ? nullptr : (const void*)pl->rt.data(), (long)B, (hipStream_t)stream};
+  return register_plan(pl);
 }
 
 extern "C" int abrk_plan_launch(int plan) {
@@ -1082,7 +1130,7 @@ extern "C" int abrk_plan_launch(int plan) {
     HIPCHK(hipSetDevice(pl->device));
     t_current_device = pl->device;
   }
-  HIPCHK(pl->ops->osc(pl->dtype, pl->la, pl->oa));
+  HIPCHK(pl->enqueue());
   return 0;
 }
 
@@ -1104,7 +1152,7 @@ extern "C" int abrk_plan_launch_graph(int plan, int repeat) {
     pl->graph_repeat = 0;
     HIPCHK(hipStreamBeginCapture(pl->la.stream, hipStreamCaptureModeThreadLocal));
     hipError_t le = hipSuccess;
-    for (int i = 0; i < repeat && le == hipSuccess; i++) le = pl->ops->osc(pl->dtype, pl->la, pl->oa);
+    for (int i = 0; i < repeat && le == hipSuccess; i++) le = pl->enqueue();
     hipError_t ce = hipStreamEndCapture(pl->la.stream, &pl->graph);
     if (le != hipSuccess || ce != hipSuccess)
       return fail(ABRK_ENODEV, "graph capture failed: %s", hipGetErrorString(le != hipSuccess ? le : ce));

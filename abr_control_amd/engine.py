@@ -375,6 +375,28 @@ class OscPlan:
             pass
 
 
+class SlidingPlan(OscPlan):
+    """The same for Sliding.generate (abrk_sliding_plan_create): launch(), launch_graph(repeat)"""
+
+    def __init__(self, arm_id, n, params, q, dq, target, u, target_velocity=None, target_acc=None, s=None,
+                 dtype=np.float64, device=0, stream=None):
+        a = _Args(dtype)
+        B = q.shape[0]
+        nt = 3 if params.cartesian else n
+        arrs = dict(q=(q, (B, n)), dq=(dq, (B, n)), target=(target, (B, nt)), target_velocity=(target_velocity, (B, nt)),
+                    target_acc=(target_acc, (B, nt)), u=(u, (B, n)), s=(s, (B, n)))
+        ptr = {}
+        for name, (arr, shape) in arrs.items():
+            if arr is not None and not isinstance(arr, DeviceArray):
+                raise TypeError(f"{name}: launch plans take DeviceArrays")
+            ptr[name] = a.inp(arr, shape, name)
+        self._keep = [v[0] for v in arrs.values()] + [params, stream]
+        self._launch = lib().abrk_plan_launch
+        self.id = check(lib().abrk_sliding_plan_create(
+            arm_id, a.code, C.byref(params), B, ptr["q"], ptr["dq"], ptr["target"], ptr["target_velocity"],
+            ptr["target_acc"], ptr["u"], ptr["s"], device, _sp(stream)))
+
+
 def ik_generate_path(arm_id, n, params, position, target, dtype=np.float64, device=0, stream=None,
                      position_path=None, velocity_path=None):
     """InverseKinematics.generate_path for B paths: position [B,n], target [B,6] (xyz + Euler 'sxyz').

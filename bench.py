@@ -150,6 +150,9 @@ class Runner:
             # the per-tick launch of a control loop on fixed device buffers: arguments validated once
             self.plan = engine.OscPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
                                        dtype=self.dt, device=device, stream=stream)
+        elif kind == "sliding":
+            self.plan = engine.SlidingPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
+                                           dtype=self.dt, device=device, stream=stream)
         self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
         self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else kw["n_timesteps"] if kind == "ik" else 1)
 

@@ -265,6 +265,11 @@ int abrk_sliding_generate_batch(int arm_id, int dtype, const abrk_sliding_params
                                 int64_t B, const void* q, const void* dq, const void* target,
                                 const void* target_velocity, const void* target_acc, void* u,
                                 void* s, int device, void* stream);
+/* Launch plan for Sliding.generate on fixed device buffers (see abrk_osc_plan_create; launched, replayed as a
+ * hipGraph and destroyed by abrk_plan_launch / abrk_plan_launch_graph / abrk_plan_destroy).      */
+int abrk_sliding_plan_create(int arm_id, int dtype, const abrk_sliding_params* params, int64_t B, const void* q,
+                             const void* dq, const void* target, const void* target_velocity, const void* target_acc,
+                             void* u, void* s, int device, void* stream);
 
 /* ---------------------------------------------------------------------------------
  * Closed loop on the device: the reference's examples alternate OSC.generate and

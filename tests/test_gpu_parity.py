@@ -908,3 +908,28 @@ def test_gpu_transformations_known_answers():
     assert np.allclose(tf.quaternion_from_euler(ai, aj, ak), want, atol=1e-15)
     with pytest.raises(ValueError):
         tf.quaternion_from_euler(1, 2, 3, "ryxz")
+
+
+def test_gpu_sliding_plan_equals_direct_call():
+    """abrk_sliding_plan_create + abrk_plan_launch / abrk_plan_launch_graph == abrk_sliding_generate_batch"""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+
+    be = cases.GpuBackend("threejoint")
+    p = _abi.make_sliding_params(3)
+    B = 5000
+    q, dq, t = draw(51, B, 3, nt=3)
+    ref_u, ref_s = be.sliding(p, q, dq, t)
+    s = a.Stream(0)
+    dev = [a.DeviceArray.from_numpy(x) for x in (q, dq, t)]
+    u_, s_ = a.DeviceArray((B, 3)), a.DeviceArray((B, 3))
+    plan = engine.SlidingPlan(be.arm_id, 3, p, dev[0], dev[1], dev[2], u_, s=s_, stream=s)
+    plan.launch()
+    s.sync()
+    assert np.array_equal(u_.numpy(), ref_u) and np.array_equal(s_.numpy(), ref_s)
+    a._lib.check(a._lib.lib().abrk_memset(0, u_.ptr, 0, u_.nbytes, None))
+    plan.launch_graph(7)
+    s.sync()
+    assert np.array_equal(u_.numpy(), ref_u)
+    with pytest.raises(TypeError):
+        engine.SlidingPlan(be.arm_id, 3, p, q, dev[1], dev[2], u_)
