@@ -1167,7 +1167,20 @@ extern "C" int abrk_plan_destroy(int plan) {
   std::lock_guard<std::mutex> lk(g_plan_mu);
   if (plan < 0 || plan >= kMaxPlans || !g_plans[plan] || !g_plans[plan]->live)
     return fail(ABRK_EINVAL, "unknown plan %d", plan);
-  g_plans[plan]->live = false;
+  OscPlan* pl = g_plans[plan];
+  pl->live = false;
+  // the slot stays (ids are never reused); the captured graph and its executable are released
+  if (pl->graph_exec || pl->graph) {
+    if (hipSetDevice(pl->device) == hipSuccess) {
+      t_current_device = pl->device;
+      if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
+      if (pl->graph) (void)hipGraphDestroy(pl->graph);
+    }
+    (void)hipGetLastError();
+    pl->graph_exec = nullptr;
+    pl->graph = nullptr;
+    pl->graph_repeat = 0;
+  }
   return 0;
 }
 
