@@ -126,7 +126,12 @@ extern "C" int abrk_arm_create(const abrk_arm_desc* d) {
     return fail(ABRK_EINVAL, "n_links_dyn=%d outside 0..n_joints+1", d->n_links_dyn);
   std::lock_guard<std::mutex> lk(g_mu);
   init_builtins();
-  if (g_arms.size() >= 4096) return fail(ABRK_ENOMEM, "too many arms");
+  // a destroyed user arm's slot is taken again (ids are handles, like file descriptors): a long-running process
+  // may register and drop any number of arms, 4096 at a time
+  int slot = -1;
+  for (int i = 5; i < (int)g_arms.size() && slot < 0; i++)
+    if (!g_arms[i].live) slot = i;
+  if (slot < 0 && g_arms.size() >= 4096) return fail(ABRK_ENOMEM, "too many arms (4096 live at once)");
   ArmEntry e;
   e.live = true;
   e.desc = *d;
@@ -136,6 +141,10 @@ extern "C" int abrk_arm_create(const abrk_arm_desc* d) {
   e.rt32.resize(rt_table_size(d->n_joints, ABRK_F32));
   rt_table_fill(d->n_joints, ABRK_F64, d, e.rt64.data());
   rt_table_fill(d->n_joints, ABRK_F32, d, e.rt32.data());
+  if (slot >= 0) {
+    g_arms[slot] = std::move(e);
+    return slot;
+  }
   g_arms.push_back(std::move(e));
   return (int)g_arms.size() - 1;
 }
@@ -153,6 +162,8 @@ extern "C" int abrk_arm_destroy(int arm_id) {
   if (arm_id < 5 || arm_id >= (int)g_arms.size() || !g_arms[arm_id].live)
     return fail(ABRK_ENOARM, "arm id %d is not a user arm", arm_id);
   g_arms[arm_id].live = false;
+  g_arms[arm_id].rt64 = {};
+  g_arms[arm_id].rt32 = {};
   return 0;
 }
 

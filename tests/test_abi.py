@@ -84,6 +84,23 @@ def test_user_arm_create_and_validation(L):
     assert L.abrk_arm_create(C.byref(d)) == -1
 
 
+def test_user_arm_slots_are_reused(L):
+    """a long-running process may register and drop any number of arms: destroyed slots are handed out again;
+    only the number of arms alive at once is bounded"""
+    d = _abi.desc_from_table(_abi.load_table("twojoint"))
+    seen = set()
+    for _ in range(6000):
+        aid = L.abrk_arm_create(C.byref(d))
+        assert aid >= 5
+        seen.add(aid)
+        assert L.abrk_arm_destroy(aid) == 0
+    assert len(seen) <= 4  # the same slot(s) over and over (other tests may hold a few)
+    held = [L.abrk_arm_create(C.byref(d)) for _ in range(50)]
+    assert len(set(held)) == 50 and min(held) >= 5
+    for aid in held:
+        assert L.abrk_arm_destroy(aid) == 0
+
+
 def test_frame_ids_and_invalid_names():
     assert _abi.frame_id("link0", 6) == 0 and _abi.frame_id("joint0", 6) == 1
     assert _abi.frame_id("link6", 6) == 12 and _abi.frame_id("EE", 6) == 13
