@@ -591,3 +591,62 @@ def check_fuzz_other(backend_factory, seed, B=64):
         err = np.max(np.abs(np.asarray(r[w], float) - v)) / max(np.max(np.abs(v)), 1.0)
         assert err <= 1e-10, (seed, n, f2, w, err)
     return worst
+
+
+def check_fuzz_secondary(backend_factory, seed, B=64):
+    """AvoidJointLimits (random limits, gradient / cross_zero flags, missing limits), Floating (all four modes) and
+    AvoidObstacles (random obstacles, threshold, gain) on one random user arm vs the oracle"""
+    from oracle.oracle import Oracle, avoid_joint_limits_batch
+    from tests.synthetic_arms import make_arm
+
+    rng = np.random.RandomState(seed)
+    n = int(rng.randint(1, 8))
+    tab = make_arm(n, 9000 + seed, non_orthogonal=bool(rng.randint(2)))
+    o, be = Oracle(tab), backend_factory(tab)
+    q, dq = rng.uniform(-3.5, 3.5, (B, n)), rng.uniform(-2, 2, (B, n))
+    worst = {}
+    # ---- AvoidJointLimits
+    lo = rng.uniform(0.2, 3.0, n)
+    hi = lo + rng.uniform(0.3, 3.0, n)
+    mn = [None if rng.rand() < 0.2 else float(v) for v in lo]
+    mx = [None if rng.rand() < 0.2 else float(v) for v in hi]
+    PL = _abi.make_limits_params(n, mn, mx, list(rng.uniform(0.5, 50, n)), list(rng.rand(n) < 0.3),
+                                 list(rng.rand(n) < 0.4))
+    with np.errstate(all="ignore"):
+        want = avoid_joint_limits_batch(n, PL, q)
+    got = np.asarray(be.limits(PL, q), float)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12), f"limits seed {seed} n={n}"
+    # ---- Floating
+    for dyn in (0, 1):
+        for ts in (0, 1):
+            uo, diag = o.floating_batch(dyn, ts, q, dq)
+            ok = (np.abs(np.abs(diag[:, 0]) - 1e-3) > 1e-9) & (np.abs(diag[:, 1] - 1e-4) > 1e-8)
+            for b in range(B):  # ill-conditioned M / task inertia: 1e-9 is not attainable by either side
+                M = o.M(q[b])
+                if np.linalg.cond(M) > 1e6:
+                    ok[b] = False
+            u = np.asarray(be.floating(dyn, ts, q, dq), float)
+            zero = np.max(np.abs(uo), axis=1) < 1e-12
+            with np.errstate(invalid="ignore", divide="ignore"):
+                err = np.where(zero, np.max(np.abs(u - uo), axis=1), rel_err(u, uo))
+            if ok.any():
+                worst[f"floating{dyn}{ts}"] = float(err[ok].max())
+                assert err[ok].max() < 1e-6, f"floating seed {seed} n={n} dyn={dyn} ts={ts}: {err[ok].max():.3e}"
+    # ---- AvoidObstacles
+    k = int(rng.randint(1, 5))
+    obstacles = np.column_stack([rng.uniform(-0.8, 0.8, (k, 3)), rng.uniform(0.02, 0.2, k)])
+    PO = _abi.make_obstacles_params(obstacles=obstacles, threshold=float(rng.uniform(0.1, 0.6)),
+                                    gain=float(rng.uniform(1, 50)))
+    with np.errstate(all="ignore"):
+        uo, diag = o.avoid_obstacles_batch(PO, q)
+    ok = (diag[:, 0] > 1e-7) & (diag[:, 1] > 1e-20)
+    for b in range(B):
+        if np.linalg.cond(o.M(q[b])) > 1e6:
+            ok[b] = False
+    u = np.asarray(be.obstacles(PO, q), float)
+    if ok.any():
+        scale = np.maximum(np.max(np.abs(uo), axis=1), 1e-6)
+        err = np.max(np.abs(u - uo), axis=1) / scale
+        worst["obstacles"] = float(err[ok].max())
+        assert err[ok].max() < 1e-5, f"obstacles seed {seed} n={n} k={k}: {err[ok].max():.3e} (row {int(np.argmax(np.where(ok, err, 0)))})"
+    return worst

@@ -933,3 +933,9 @@ def test_gpu_sliding_plan_equals_direct_call():
     assert np.array_equal(u_.numpy(), ref_u)
     with pytest.raises(TypeError):
         engine.SlidingPlan(be.arm_id, 3, p, q, dev[1], dev[2], u_)
+
+
+def test_gpu_fuzz_secondary_controllers():
+    """AvoidJointLimits / Floating / AvoidObstacles on random user arms with random parameters vs the oracle"""
+    for seed in range(20, 60):
+        cases.check_fuzz_secondary(cases.GpuBackend, seed)

@@ -343,3 +343,9 @@ def test_rows_osc_helper_methods_vs_reference(arm):
         Mxk, _ = hostsim.osc_mx(n, M, g[f"mx_k{k}_J"])
         err = np.abs(Mxk - g[f"mx_k{k}_Mx"]).max(axis=(1, 2)) / nrm(g[f"mx_k{k}_Mx"])
         assert err[ok].max() <= 1e-7, (k, err[ok].max())
+
+
+@pytest.mark.parametrize("seed", range(20, 32))
+def test_rows_fuzz_secondary_controllers(seed):
+    """AvoidJointLimits / Floating / AvoidObstacles on random user arms with random parameters vs the oracle"""
+    cases.check_fuzz_secondary(cases.HostsimBackend, seed)

@@ -29,6 +29,16 @@ while time.time() - t0 < budget:
         fails.append(("other", s2, traceback.format_exc()[-400:]))
     n_other += 1
     s2 += 1
+s3, n_sec = 5000, 0
+t3 = time.time()
+while time.time() - t3 < budget * 0.4:
+    try:
+        cases.check_fuzz_secondary(cases.GpuBackend, s3)
+    except Exception as e:  # noqa: BLE001
+        fails.append(("secondary", s3, repr(e)[:300]))
+    n_sec += 1
+    s3 += 1
+print(f"soak: {n_sec} secondary-controller cases (seeds 5000..{s3 - 1})")
 print(f"soak: {n_osc} OSC cases (seeds 100..{seed - 1}), worst rel err {worst:.3e}; {n_other} other cases "
       f"(seeds 1000..{s2 - 1}); {len(fails)} failures in {time.time() - t0:.0f} s")
 for f in fails[:20]:
