@@ -6,9 +6,13 @@ for all arms, and the plant step (ArmSim.send_forces) is one more.
 
     python examples/avoid_obstacles_headless.py        (needs an MI355X)
 """
+import os
+import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 
 from abr_control_amd.arms import twojoint as arm  # was: from abr_control.arms import threejoint as arm
 from abr_control_amd.controllers import OSC, AvoidJointLimits, AvoidObstacles, Damping

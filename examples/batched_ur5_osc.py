@@ -3,9 +3,13 @@ device-resident buffers with a launch plan (the per-tick call of a control loop)
 
     python examples/batched_ur5_osc.py        (needs an MI355X)
 """
+import os
+import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 
 import abr_control_amd as abrk
 from abr_control_amd import _abi, engine

@@ -5,9 +5,13 @@ one simulated second inside a single kernel launch.
 
     python examples/force_osc_xy_headless.py        (needs an MI355X)
 """
+import os
+import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # run from a checkout
 
 from abr_control_amd.arms import twojoint as arm  # was: from abr_control.arms import twojoint as arm
 from abr_control_amd.controllers import OSC, Damping, RestingConfig  # was: abr_control.controllers

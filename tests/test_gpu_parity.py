@@ -939,3 +939,18 @@ def test_gpu_fuzz_secondary_controllers():
     """AvoidJointLimits / Floating / AvoidObstacles on random user arms with random parameters vs the oracle"""
     for seed in range(20, 60):
         cases.check_fuzz_secondary(cases.GpuBackend, seed)
+
+
+def test_gpu_examples_run_from_a_checkout():
+    """the headless example loops (the reference's PyGame scripts with the interface taken out) run as scripts"""
+    import glob
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    scripts = sorted(glob.glob(os.path.join(root, "examples", "*.py")))
+    assert len(scripts) >= 3
+    for sc in scripts:
+        r = subprocess.run([sys.executable, sc], cwd="/tmp", capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, f"{sc}:\n{r.stderr[-800:]}"
