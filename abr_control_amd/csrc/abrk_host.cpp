@@ -195,7 +195,8 @@ extern "C" int abrk_device_name(int device, char* buf, size_t len) {
   if (int rc = use_device(device)) return rc;
   hipDeviceProp_t p;
   HIPCHK(hipGetDeviceProperties(&p, device));
-  snprintf(buf, len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+  // the marketing name comes from libdrm's amdgpu.ids, which minimal images lack: fall back to the architecture
+  snprintf(buf, len, "%s (%s, %d CUs)", p.name[0] ? p.name : "AMD GPU", p.gcnArchName, p.multiProcessorCount);
   return 0;
 }
 extern "C" void* abrk_malloc(int device, size_t bytes) {
