@@ -213,6 +213,8 @@ class Runner:
     def timed(self, steps, warmup, barrier=None):
         """-> (wall seconds of the timed region, mean kernel ms per launch from HIP events)"""
         a = self.a
+        if self.plan is not None and 8 <= steps < self.graph_steps:
+            self.graph_steps = steps  # a short run is one graph of exactly K nodes
         graph = self.used_graph = self.plan is not None and self.graph_steps > 1 and steps >= self.graph_steps
         for _ in range(warmup):
             self.step()
