@@ -215,7 +215,7 @@ int abrk_osc_mx_batch(int n_joints, int k, int dtype, int64_t B, const void* M, 
  * (params->use_vmax must be set).                                                                 */
 int abrk_osc_velocity_limiting_batch(int dtype, const abrk_osc_params* params, int64_t B, const void* u_task,
                                      void* out, int device, void* stream);
-/* OSC._calc_orientation_forces (osc.py:149-196) from R [B,3,3] = robot_config.R(ref_frame, q) (W_R of
+/* OSC._calc_orientation_forces (osc.py:149-196) from R [B,3,3] = robot_config.R(ref_frame, q) (ABRK_WANT_R of
  * abrk_dynamics_batch) and target_abg [B,3] (Euler angles, 'rxyz'); algorithm 0 or 1; out [B,3]. */
 int abrk_osc_orientation_forces_batch(int algorithm, int dtype, int64_t B, const void* R, const void* target_abg,
                                       void* u_task_orientation, int device, void* stream);
