@@ -24,7 +24,9 @@ What it does (SURVEY.md section 7 "Hazards" explains every precaution):
   * stores the closed-form twojoint known answers of the reference's own test fixture
     (abr_control/arms/tests/dummy_base_arm.py) on grids like test_base_config.py:40-180.
 
-Usage:  python oracle/gen_golden.py [arm ...]     (default: all arms + known answers)
+Usage:  python oracle/gen_golden.py [what ...]    (default: all arms + known answers)
+        what = <arm> | known | sec:<arm> (secondary controllers, sec_<arm>.npz) |
+               helpers:<arm> (OSC._Mx / _velocity_limiting / _calc_orientation_forces, oschelpers_<arm>.npz)
 """
 import os
 import re
