@@ -454,6 +454,8 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
+    ap.add_argument("--no-streams-leg", action="store_true", help="skip the concurrent_streams leg (rocprofv3's "
+                    "kernel tracing crashes inside hipGraphLaunch when 16 streams replay graphs at once)")
     ap.add_argument("--also", default="", help="comma-separated extra workloads: one HBM-sized roofline leg each "
                                                "(same process, so one rocprofv3 session sees every kernel)")
     args = ap.parse_args()
@@ -550,7 +552,7 @@ def main():
             _, ms_x = extra.timed(max(args.roofline_steps // 3, 3), 2)
             out["also"][w] = roofline(extra, ms_x, f"{w} batch={extra.B}")
             del extra
-    if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg:
+    if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg and not args.no_streams_leg:
         out["concurrent_streams"] = [concurrent_streams_rate("cfg2", B, device, s, args.steps) for s in (2, 4, 8, 16)]
     if rank == 0 and args.workload == "cfg2":
         out["parity"] = parity_vs_reference(device)

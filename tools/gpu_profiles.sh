@@ -9,7 +9,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 
 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err; tail -3 $O/bench_cfg2.err
 for w in cfg3 cfg4 cfg5; do python bench.py --workload $w --steps 500 --warmup 50 --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err; done
 for w in limits floating obstacles rollout ik dynF; do python bench.py --workload $w --steps 200 --warmup 20 --roofline-batch 4194304 --roofline-steps 10 > $O/bench_$w.json 2> $O/bench_$w.err; done
-ALSO="--also limits,floating,obstacles,cfg3,cfg4,cfg5"
+ALSO="--no-streams-leg --also limits,floating,obstacles,cfg3,cfg4,cfg5"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $ALSO > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
