@@ -38,6 +38,16 @@ if os.path.exists(ks):
     for _, r in g.iterrows():
         lines.append(f"| `{r['kernel']}` | {r['Grid_Size_X']} | {r['count']} | {r['mean']/1e3:.2f} | {r['min']/1e3:.2f} | "
                      f"{r['max']/1e3:.2f} |")
+    # the HBM-sized legs: launches in time order, and the mean of the last 30 = the launches bench.py's HIP events
+    # bracket (the ones before are construction, warm-up and the untimed first replay of the timed graph)
+    big = kt[kt["Grid_Size_X"] >= (1 << 22)].sort_values("Start_Timestamp")
+    lines += ["", "HBM-sized legs, launch by launch (us, time order) - the first launches after idle run at boost clocks, "
+              "the power limiter overshoots, then the rate settles; `roofline.achieved` is measured on the last "
+              "`--roofline-steps` launches:", ""]
+    for (kname, grid), grp in big.groupby(["kernel", "Grid_Size_X"], sort=False):
+        d = (grp["dur"] / 1e3).round().astype(int).tolist()
+        tail = d[-30:] if len(d) >= 43 else d[-10:]
+        lines.append(f"* `{kname}`, {grid} rows: {d} -> mean of the timed launches {sum(tail) / len(tail):.1f} us")
 rows = []
 for d in sorted(os.listdir(src)):
     cc = os.path.join(src, d, "bench_counter_collection.csv")
