@@ -235,6 +235,14 @@ def gen_arm(arm):
         run_osc("osc_xy_C", 128, 3, dict(kp=10, kv=3, ctrlr_dof=xy, use_C=True))
         run_simple("sliding", 256, 4, lambda c: Sliding(c), 3,
                    lambda c, q, dq, t: c.generate(q, dq, t))
+    elif arm == "onejoint":
+        # N_LINKS = 1 (arms/onejoint/config.py:32): only link0 - which no joint moves - is summed, so M, g, C are
+        # identically zero and OSC (inv(M), osc.py:136) raises in the reference.  What the arm offers is its
+        # kinematics (above, every frame) and the controllers that never invert M:
+        run_simple("sliding", 128, 60, lambda c: Sliding(c), 3,
+                   lambda c, q, dq, t: c.generate(q, dq, t))
+        run_simple("sliding_tv", 128, 61, lambda c: Sliding(c, kd=20.0, lamb=5.0), 3,
+                   lambda c, q, dq, t: c.generate(q, dq, t, target_velocity=t[::-1] * 0.3, target_acc=t * 0.1))
     elif arm == "threejoint":
         # BASELINE config 5: threejoint Sliding(), defaults kd=160, lamb=30, cartesian
         run_simple("cfg5", 2048, 0, lambda c: Sliding(c), 3,
@@ -540,8 +548,32 @@ def gen_osc_helpers(arm):
     print(f"  wrote {OUT}/oschelpers_{arm}.npz ({len(out)} arrays)", flush=True)
 
 
+def gen_quat(arm):
+    """robot_config.R / .quaternion (base_config.py:287-318; quaternion_from_matrix = eigh of the 4x4 K matrix,
+    transformations.py:1192-1271) for EVERY frame: Jaco2's rounded rotation constants make R R^T - I grow to 4e-4
+    along the chain, which is where a non-eigh quaternion extraction could drift from the reference's."""
+    mod = importlib.import_module(f"abr_control.arms.{arm}")
+    rc = mod.Config(use_cython=True)
+    raw = RawConfig(rc)
+    n = rc.N_JOINTS
+    rng = np.random.RandomState(90)
+    B = 64
+    q = rng.uniform(0, 2 * np.pi, (B, n))
+    frames = frames_of(rc)
+    out = {"q": q, "frames": np.array(frames)}
+    for f in frames:
+        out[f"R_{f}"] = np.array([raw.R(f, q[b]) for b in range(B)])
+        out[f"quat_{f}"] = np.array([raw.quaternion(f, q[b]) for b in range(B)])
+        dev = max(np.max(np.abs(R @ R.T - np.eye(3))) for R in out[f"R_{f}"])
+        print(f"  {f}: max |R R^T - I| = {dev:.1e}", flush=True)
+    np.savez_compressed(f"{OUT}/quat_{arm}.npz", **out)
+    print(f"  wrote {OUT}/quat_{arm}.npz ({len(out)} arrays)", flush=True)
+
+
 if what == "known":
     gen_known()
+elif what.startswith("quat:"):
+    gen_quat(what[5:])
 elif what.startswith("helpers:"):
     gen_osc_helpers(what[8:])
 elif what.startswith("sec:"):

@@ -24,8 +24,9 @@ What it does (SURVEY.md section 7 "Hazards" explains every precaution):
   * stores the closed-form twojoint known answers of the reference's own test fixture
     (abr_control/arms/tests/dummy_base_arm.py) on grids like test_base_config.py:40-180.
 
-Usage:  python oracle/gen_golden.py [what ...]    (default: all arms + known answers)
+Usage:  python oracle/gen_golden.py [--out DIR] [what ...]    (default: tests/golden, all arms + known answers)
         what = <arm> | known | sec:<arm> (secondary controllers, sec_<arm>.npz) |
+               quat:<arm> (R and quaternion of every frame, quat_<arm>.npz) |
                helpers:<arm> (OSC._Mx / _velocity_limiting / _calc_orientation_forces, oschelpers_<arm>.npz)
 """
 import os
@@ -38,7 +39,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
 SCRATCH = "/tmp/abrk_ref_scratch"
 OUT = os.path.join(REPO, "tests", "golden")
-ARMS = ["twojoint", "threejoint", "ur5", "jaco2"]
+ARMS = ["twojoint", "threejoint", "ur5", "jaco2", "onejoint"]
 
 
 def make_scratch():
@@ -59,7 +60,11 @@ def make_scratch():
 
 
 def main():
-    which = sys.argv[1:] or ARMS + ["known"]
+    global OUT
+    args = sys.argv[1:]
+    if args[:1] == ["--out"]:  # tests/test_reference_provenance.py regenerates into a scratch directory and diffs
+        OUT, args = os.path.abspath(args[1]), args[2:]
+    which = args or ARMS + ["known"]
     make_scratch()
     env = dict(os.environ)
     env["PYTHONDONTWRITEBYTECODE"] = "1"

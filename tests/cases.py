@@ -36,6 +36,9 @@ _osc("twojoint", "cfg1", lambda n: P(n, kp=10, kv=3, ctrlr_dof=XY))
 _osc("twojoint", "osc_xy_vmax", lambda n: P(n, kp=20, kv=5, ctrlr_dof=XY, vmax=[0.5, 0.5]))
 _osc("twojoint", "osc_xy_C", lambda n: P(n, kp=10, kv=3, ctrlr_dof=XY, use_C=True))
 _sl("twojoint", "sliding", lambda n: SP(n))
+# ---- onejoint (N_LINKS = 1: M, g, C vanish identically - only the controllers that never invert M run in the reference)
+_sl("onejoint", "sliding", lambda n: SP(n))
+_sl("onejoint", "sliding_tv", lambda n: SP(n, kd=20.0, lamb=5.0), tvf=lambda t: t[:, ::-1] * 0.3, taf=lambda t: t * 0.1)
 # ---- threejoint (BASELINE config 5 = cfg5)
 _sl("threejoint", "cfg5", lambda n: SP(n))
 _sl("threejoint", "sliding_tv", lambda n: SP(n, kd=20.0, lamb=5.0), tvf=lambda t: t[:, ::-1] * 0.3,
@@ -113,18 +116,30 @@ def threshold_band(g, key, eps=1e-6):
     if f"{key}_det" not in g:
         return None
     det, sv = np.abs(g[f"{key}_det"]), g[f"{key}_sv"]
-    near_det = np.abs(det - 1e-3) <= eps * 1e-3 * 1e3
+    near_det = np.abs(det - 1e-3) <= eps * 1e-3
     ratio = sv / sv.max(axis=1, keepdims=True)
-    near_cut = (np.abs(ratio - 1e-4) <= eps * 1e2).any(axis=1) & (det < 1e-3 * (1 + 1e-3))
+    near_cut = (np.abs(ratio - 1e-4) <= eps * 1e-4).any(axis=1) & (det < 1e-3 * (1 + eps))
     return near_det | near_cut
+
+
+def truncating_rows(g, key):
+    """rows on which `pinv(Mx_inv, rcond=1e-4)` really drops a singular value (osc.py:142-145): |det| < 1e-3 and
+    min(sv) < 1e-4 max(sv).  These rows are NOT excluded from the golden assert (only the 1e-6-relative band
+    around the two thresholds is) - the count is reported so that a test can insist they were compared."""
+    if f"{key}_det" not in g:
+        return None
+    det, sv = np.abs(g[f"{key}_det"]), g[f"{key}_sv"]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ratio = sv / sv.max(axis=1, keepdims=True)
+    return (det < 1e-3) & (ratio.min(axis=1) < 1e-4)
 
 
 def mx_rows_clear_of_thresholds(det, sv, eps=1e-6):
     """the same band test for `_Mx` called directly (fixtures oschelpers_<arm>.npz): True = safe to compare"""
     det, sv = np.abs(np.asarray(det)), np.asarray(sv)
-    near_det = np.abs(det - 1e-3) <= eps * 1e-3 * 1e3
+    near_det = np.abs(det - 1e-3) <= eps * 1e-3
     ratio = sv / sv.max(axis=1, keepdims=True)
-    near_cut = (np.abs(ratio - 1e-4) <= eps * 1e2).any(axis=1) & (det < 1e-3 * (1 + 1e-3))
+    near_cut = (np.abs(ratio - 1e-4) <= eps * 1e-4).any(axis=1) & (det < 1e-3 * (1 + eps))
     return ~(near_det | near_cut)
 
 
@@ -274,6 +289,10 @@ class GpuBackend:
 TOL_D = 1e-6
 TOL_F32 = 1e-4
 TOL_THREEJOINT = 2e-5  # the reference's own float32-`L` inconsistency (see above), amplified by pinv
+# (median, p99) caps of max|du|/max|u| against the as-shipped (float32-rounding) reference path on the BASELINE configs;
+# the reference's own fp64 formulas sit at median 0.8-1.4e-7, p99 0.5-2.4e-6 from it (cfg1: p99 1.2e-5, truncated pinv)
+SHIPPED_CAPS = {"ur5:cfg2": (2e-7, 5e-6), "ur5:cfg4": (2e-7, 5e-6), "jaco2:cfg3": (2e-7, 5e-6),
+                "threejoint:cfg5": (2e-7, 5e-6), "twojoint:cfg1": (2e-7, 5e-5)}
 
 
 def check_case_against_golden(backend, case_id, g, dtype=np.float64, rows=None):
@@ -306,8 +325,27 @@ def check_case_against_golden(backend, case_id, g, dtype=np.float64, rows=None):
     if "ts" in extra and extra["ts"] is not None and f"{key}_tsD" in g and dtype == np.float64:
         rT = rel_err(np.asarray(extra["ts"], float), g[f"{key}_tsD"][sl])
         assert rT[ok].max() <= tol, f"{case_id}: training_signal {rT[ok].max():.3e}"
+    trunc = truncating_rows(g, key)
+    rS = rel_err(np.asarray(u, float), uS)
+    okrow = ok if ok.ndim == 1 else ok.all(axis=0)
+    if dtype == np.float64:
+        # distance to the AS-SHIPPED path (Oracle-S, float32 rounding points included): asserted as a distribution.
+        # It cannot be closer than the reference's own fp64 formulas are to its shipped path (uD vs uS), and must
+        # not be farther: median and p99 within 10 % of that floor (+ the distance to uD itself), plus absolute caps on the BASELINE configs.
+        with np.errstate(invalid="ignore", divide="ignore"):
+            floor = rel_err(uD, uS)
+        fin = np.isfinite(floor) & np.isfinite(rS)
+        for name, f in (("median", np.median), ("p99", lambda x: np.percentile(x, 99))):
+            mine, ref = f(rS[fin]), f(floor[fin]) + f(rD[fin])  # row-wise: |u - uS| <= |uD - uS| + |u - uD|
+            assert mine <= 1.1 * ref + 1e-9, f"{case_id} [{backend.name}]: {name} vs shipped path {mine:.3e}, reference's own {ref:.3e}"
+        cap = SHIPPED_CAPS.get(case_id)
+        if cap:
+            assert np.median(rS[fin]) <= cap[0] and np.percentile(rS[fin], 99) <= cap[1], \
+                f"{case_id} [{backend.name}]: vs shipped path median {np.median(rS[fin]):.3e} p99 {np.percentile(rS[fin], 99):.3e}"
     return dict(case=case_id, worst_vs_D=float(worst), median_vs_D=float(np.median(rD)),
-                median_vs_S=float(np.median(rel_err(np.asarray(u, float), uS))), n_band=int((~ok).sum()))
+                median_vs_S=float(np.median(rS)), p99_vs_S=float(np.percentile(rS, 99)), n_band=int((~ok).sum()),
+                n_trunc=0 if trunc is None else int(trunc[sl].sum()),
+                n_trunc_compared=0 if trunc is None else int((trunc[sl] & okrow).sum()))
 
 
 # ---- AvoidJointLimits / Floating / AvoidObstacles against tests/golden/sec_<arm>.npz
@@ -418,6 +456,23 @@ def check_dynamics_against_golden(backend, arm, g, dtype=np.float64):
             ref = g[f"{w}_{f}"]
             err = np.max(np.abs(np.asarray(r[w], float) - ref)) / scale(ref)
             assert err <= tol, f"{arm} {w}({f}) [{backend.name}]: {err:.3e}"
+
+
+def check_quaternions_all_frames(backend, arm, g, dtype=np.float64):
+    """robot_config.R / .quaternion of EVERY frame vs the reference (eigh of the 4x4 K matrix,
+    transformations.py:1192-1271); Jaco2's late frames are 6e-4 away from a rotation (tests/golden/quat_<arm>.npz)"""
+    worst = 0.0
+    for f in g["frames"]:
+        f = str(f)
+        r = backend.dynamics(g["q"], None, f, None, ("R", "quat"), dtype)
+        assert np.max(np.abs(np.asarray(r["R"], float) - g[f"R_{f}"])) <= (1e-12 if dtype == np.float64 else 1e-5)
+        qq, ref = np.asarray(r["quat"], float), g[f"quat_{f}"]
+        # w >= 0 fixes the sign (transformations.py:1269) except at w == 0, where either sign is the reference's answer
+        flip = np.abs(ref[:, 0]) < 1e-9
+        err = np.minimum(np.max(np.abs(qq - ref), axis=1), np.where(flip, np.max(np.abs(qq + ref), axis=1), np.inf))
+        worst = max(worst, float(err.max()))
+    assert worst <= (1e-9 if dtype == np.float64 else 1e-4), f"{arm} quaternion [{backend.name}]: {worst:.3e}"
+    return worst
 
 
 # ---------------------------------------------------------------------------- seeded fuzz over OSC parameters

@@ -11,6 +11,7 @@ from tests.conftest import golden
 pytestmark = pytest.mark.gpu
 
 ARMS = ["twojoint", "threejoint", "ur5", "jaco2"]
+DYN_ARMS = ARMS + ["onejoint"]  # N_LINKS = 1: kinematics of every frame, M = g = C = 0
 
 
 def draw(seed, B, n, nt=6):
@@ -29,7 +30,7 @@ def test_native_library_is_loaded():
 
 
 @pytest.mark.parametrize("variant", ["static", "rt"])
-@pytest.mark.parametrize("arm", ARMS)
+@pytest.mark.parametrize("arm", DYN_ARMS)
 def test_gpu_dynamics_match_reference(arm, variant):
     cases.check_dynamics_against_golden(cases.GpuBackend(arm, variant), arm, golden(arm))
 
@@ -954,3 +955,23 @@ def test_gpu_examples_run_from_a_checkout():
     for sc in scripts:
         r = subprocess.run([sys.executable, sc], cwd="/tmp", capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, f"{sc}:\n{r.stderr[-800:]}"
+
+
+def test_gpu_truncated_pinv_rows_are_compared():
+    """every golden row on which `pinv(Mx_inv, rcond=1e-4)` really truncates (osc.py:142-145; 49 rows over the OSC
+    cases) takes part in the golden assert - only rows within 1e-6 (relative) of a threshold may be excluded"""
+    tot = cmp_ = 0
+    for case_id, case in sorted(cases.CASES.items()):
+        if case["kind"] != "osc":
+            continue
+        r = cases.check_case_against_golden(cases.GpuBackend(case["arm"], "static"), case_id, golden(case["arm"]))
+        tot += r["n_trunc"]
+        cmp_ += r["n_trunc_compared"]
+        assert r["n_band"] <= 1, (case_id, r)
+    assert tot >= 45 and cmp_ == tot, (tot, cmp_)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2"])
+def test_gpu_quaternion_every_frame(arm):
+    """power-iteration quaternion vs the reference's eigh on every frame, incl. Jaco2's non-orthogonal late frames"""
+    cases.check_quaternions_all_frames(cases.GpuBackend(arm, "static"), arm, golden(f"quat_{arm}"))

@@ -10,11 +10,12 @@ from tests import cases
 from tests.conftest import golden
 
 ARMS = ["twojoint", "threejoint", "ur5", "jaco2"]
+DYN_ARMS = ARMS + ["onejoint"]  # N_LINKS = 1: kinematics of every frame, M = g = C = 0
 BIG = {"ur5:cfg2": 1024, "ur5:cfg4": 512, "jaco2:cfg3": 512, "threejoint:cfg5": 1024}
 
 
 @pytest.mark.parametrize("variant", ["static", "rt"])
-@pytest.mark.parametrize("arm", ARMS)
+@pytest.mark.parametrize("arm", DYN_ARMS)
 def test_rows_dynamics_match_reference(arm, variant):
     cases.check_dynamics_against_golden(cases.HostsimBackend(arm, variant), arm, golden(arm))
 
@@ -349,3 +350,23 @@ def test_rows_osc_helper_methods_vs_reference(arm):
 def test_rows_fuzz_secondary_controllers(seed):
     """AvoidJointLimits / Floating / AvoidObstacles on random user arms with random parameters vs the oracle"""
     cases.check_fuzz_secondary(cases.HostsimBackend, seed)
+
+
+def test_rows_truncated_pinv_rows_are_compared():
+    """every golden row on which `pinv(Mx_inv, rcond=1e-4)` really truncates (osc.py:142-145; 49 rows over the OSC
+    cases) takes part in the golden assert - only rows within 1e-6 (relative) of a threshold may be excluded"""
+    tot = cmp_ = 0
+    for case_id, case in sorted(cases.CASES.items()):
+        if case["kind"] != "osc":
+            continue
+        r = cases.check_case_against_golden(cases.HostsimBackend(case["arm"], "static"), case_id, golden(case["arm"]))
+        tot += r["n_trunc"]
+        cmp_ += r["n_trunc_compared"]
+        assert r["n_band"] <= 1, (case_id, r)
+    assert tot >= 45 and cmp_ == tot, (tot, cmp_)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2"])
+def test_rows_quaternion_every_frame(arm):
+    """power-iteration quaternion vs the reference's eigh on every frame, incl. Jaco2's non-orthogonal late frames"""
+    cases.check_quaternions_all_frames(cases.HostsimBackend(arm, "static"), arm, golden(f"quat_{arm}"))

@@ -10,9 +10,10 @@ from tests import cases
 from tests.conftest import golden
 
 ARMS = ["twojoint", "threejoint", "ur5", "jaco2"]
+DYN_ARMS = ARMS + ["onejoint"]  # N_LINKS = 1: kinematics of every frame, M = g = C = 0
 
 
-@pytest.mark.parametrize("arm", ARMS)
+@pytest.mark.parametrize("arm", DYN_ARMS)
 def test_oracle_dynamics_match_reference(arm):
     cases.check_dynamics_against_golden(cases.OracleBackend(arm), arm, golden(arm))
 
@@ -192,3 +193,23 @@ def test_oracle_orientation_forces_vs_reference(arm, alg):
     g = golden(f"oschelpers_{arm}")
     got = np.array([O.osc_orientation_forces(alg, R, abg) for R, abg in zip(g["of_R"], g["of_abg"])])
     assert np.max(np.abs(got - g[f"of_alg{alg}"])) < 1e-9
+
+
+def test_oracle_truncated_pinv_rows_are_compared():
+    """every golden row on which `pinv(Mx_inv, rcond=1e-4)` really truncates (osc.py:142-145; 49 rows over the OSC
+    cases) takes part in the golden assert - only rows within 1e-6 (relative) of a threshold may be excluded"""
+    tot = cmp_ = 0
+    for case_id, case in sorted(cases.CASES.items()):
+        if case["kind"] != "osc":
+            continue
+        r = cases.check_case_against_golden(cases.OracleBackend(case["arm"]), case_id, golden(case["arm"]))
+        tot += r["n_trunc"]
+        cmp_ += r["n_trunc_compared"]
+        assert r["n_band"] <= 1, (case_id, r)
+    assert tot >= 45 and cmp_ == tot, (tot, cmp_)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2"])
+def test_oracle_quaternion_every_frame(arm):
+    """power-iteration quaternion vs the reference's eigh on every frame, incl. Jaco2's non-orthogonal late frames"""
+    cases.check_quaternions_all_frames(cases.OracleBackend(arm), arm, golden(f"quat_{arm}"))

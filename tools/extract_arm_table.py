@@ -34,9 +34,15 @@ def _snap(v):
     if abs(a - v) < 1e-13:
         return a
     b = float(np.float32(v))
-    if abs(b - v) < 1e-13:
+    if abs(b - v) < 1e-13 and b != 0.0:
         return b
-    raise ValueError(f"cannot snap {v!r} to a decimal literal or a float32 value")
+    # neither: a constant that is not a short literal (e.g. cos(pi/4) in a non-axis-aligned static rotation).  The
+    # runtime tables take arbitrary doubles, so keep the value as evaluated - it then carries the ~1e-16 noise of the
+    # matrix solve that isolated it, which is far below the 1e-6 parity bound.
+    import warnings
+
+    warnings.warn(f"extract_arm_table: keeping {v!r} as evaluated (not a <=10-digit decimal or a float32 value)")
+    return float(v)
 
 
 def _snapm(M):
