@@ -52,6 +52,7 @@ def lib():
         L.abrk_osc_plan_create.argtypes = L.abrk_osc_generate_batch.argtypes
         L.abrk_sliding_plan_create.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.SlidingParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]
+        L.abrk_plan_begin.argtypes = [C.c_int, _vp]
         L.abrk_plan_launch.argtypes = [C.c_int]
         L.abrk_plan_launch_graph.argtypes = [C.c_int, C.c_int]
         L.abrk_plan_destroy.argtypes = [C.c_int]

@@ -81,6 +81,22 @@ class BatchedConfig:
                 self._arm_id = check(lib().abrk_arm_create(C.byref(desc)))
         return self._arm_id
 
+    def close(self):
+        """hand a user arm's registry slot back to the library (built-in arms hold none).  Called on garbage
+        collection too, so loops that build configs repeatedly do not run out of the 4091 user slots."""
+        arm_id, self._arm_id = self._arm_id, None
+        if arm_id is not None and self._builtin is None:
+            try:
+                lib().abrk_arm_destroy(arm_id)
+            except Exception:  # noqa: BLE001 - interpreter shutdown: the library may already be gone
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
     def frame_id(self, name):
         return _abi.frame_id(name, self.N_JOINTS)
 

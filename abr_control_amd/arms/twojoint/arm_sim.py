@@ -61,8 +61,13 @@ class ArmSim:
         ie = None
         if ctrlr.ki != 0:
             ie = np.ascontiguousarray(np.broadcast_to(np.atleast_2d(ctrlr.integrated_error), (B, 6)), dtype=float)
-        if ctrlr._foreign:
-            raise TypeError("rollout needs device-side null controllers (Damping / RestingConfig)")
+        # the fused loop evaluates only what lives inside the OSC kernel: Damping / RestingConfig.  Anything else
+        # (AvoidJointLimits, AvoidObstacles, Floating, Python controllers) would be silently dropped - refuse it
+        if ctrlr._foreign or ctrlr._device:
+            raise TypeError("rollout needs fused null controllers (Damping / RestingConfig); run the per-step "
+                            "loop (ctrlr.generate + send_forces) for the others")
+        if ctrlr.robot_config is not rc:
+            raise ValueError("rollout: the controller was built on a different robot_config than this plant")
         res = engine.osc_rollout_twolink(rc.arm_id, ctrlr._params("EE", None), self._plant, q, dq, t2, n_steps,
                                          every, ie, want_traj=every > 0, device=rc.device)
         self._commit(q, dq)

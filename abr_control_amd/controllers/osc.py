@@ -58,18 +58,34 @@ class OSC(Controller):
         # controllers (AvoidJointLimits, AvoidObstacles, Floating) are summed on the device by their own
         # kernels and enter the null-space filter as u_null_ext; any other object with generate(q, dq)
         # is evaluated by the caller's code per state and only projected
-        self._fused, self._device, self._foreign = [], [], []
+        # (_fused_src holds the live controller objects: their gains are read at every generate(), as the
+        #  reference calls null_controller.generate() every tick, osc.py:311-313 - gain scheduling keeps working)
+        self._fused_src, self._device, self._foreign = [], [], []
         for nc in null_controllers or []:
             if not self._fused_config:
                 self._foreign.append(nc)  # evaluated with the foreign config's own M(q)
-            elif type(nc) is Damping:
-                self._fused.append(_abi.make_damping(nc.kv))
-            elif type(nc) is RestingConfig:
-                self._fused.append(_abi.make_resting(nc.rest_angles_list, nc.kp, nc.kv))
+            elif type(nc) in (Damping, RestingConfig) and len(self._fused_src) < _abi.MAX_NULL:
+                self._fused_src.append(nc)
             elif hasattr(nc, "_accumulate") and getattr(nc, "robot_config", None) is robot_config:
-                self._device.append(nc)
+                self._device.append(nc)  # also Damping / RestingConfig beyond the MAX_NULL fused slots
             else:
                 self._foreign.append(nc)
+
+    def _fused_key(self):
+        """current gains of the fused secondary controllers (part of the parameter-cache key)"""
+        key = []
+        for nc in self._fused_src:
+            if type(nc) is Damping:
+                key.append(("d", float(nc.kv)))
+            else:
+                key.append(("r", float(nc.kp), float(nc.kv),
+                            tuple(None if a is None else float(a) for a in nc.rest_angles_list)))
+        return tuple(key)
+
+    @property
+    def _fused(self):
+        return [_abi.make_damping(nc.kv) if type(nc) is Damping else _abi.make_resting(nc.rest_angles_list, nc.kp, nc.kv)
+                for nc in self._fused_src]
 
     def _params(self, ref_frame, xyz_offset):
         """abrk_osc_params of the current attribute values (cached: a control loop calls generate() per tick)"""
@@ -78,7 +94,7 @@ class OSC(Controller):
             ref_frame, xyz_offset = "EE", None  # applied by the foreign config when it produced J/Tx/R
         key = (ref_frame, None if xyz_offset is None else tuple(float(v) for v in xyz_offset), self.kp, self.ko,
                self.kv, self.ki, None if self.vmax is None else tuple(self.vmax), tuple(self.ctrlr_dof), self.use_g,
-               self.use_C, self.orientation_algorithm)
+               self.use_C, self.orientation_algorithm, self._fused_key())
         hit = self._params_cache.get(key)
         if hit is None:
             if len(self._params_cache) > 64:

@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -325,8 +327,8 @@ void* device_view(const void* p) {
   if (at.type == hipMemoryTypeHost && at.devicePointer) return at.devicePointer;
   return nullptr;
 }
-bool is_device_ptr(const void* p) { return device_view(p) == p && p; }
 
+bool recording();  // is this thread inside abrk_plan_begin .. abrk_plan_end?
 struct Stager {
   int device;
   hipStream_t stream;
@@ -351,6 +353,7 @@ struct Stager {
   int reserve() {
     if (items.empty()) return 0;
     staged = true;
+    if (recording()) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
     if (need <= zero_copy_max()) {
       PinArena& pa = t_pin;
       if (pa.cap < need) {
@@ -439,6 +442,43 @@ struct Stager {
 
 size_t esz(int dtype) { return dtype == ABRK_F64 ? 8 : 4; }
 
+// ---- launch recording (abrk_plan_begin .. abrk_plan_end).  While a thread records, every abrk_*_batch call on it
+// is validated and converted as usual but its kernel launch is kept as a closure instead of being enqueued; the
+// closures own their parameter blocks and (for user arms) a private copy of the arm table.
+struct Recorder {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<std::function<hipError_t()>> steps;
+  std::vector<std::unique_ptr<std::vector<unsigned char>>> tables;  // stable addresses
+};
+thread_local Recorder* t_rec = nullptr;
+bool recording() { return t_rec != nullptr; }
+
+const void* arm_table(const ArmEntry* a, int dtype) {
+  if (!a || a->builtin) return nullptr;
+  return dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data();
+}
+
+// enqueue now (and finish the staging), or keep the launch for the plan being recorded.  fn(arm_rt) launches the
+// kernel; it captures its arguments by value.
+template <class F>
+int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn) {
+  if (Recorder* r = t_rec) {
+    if (st.staged) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
+    if (st.device != r->device || st.stream != r->stream)
+      return fail(ABRK_EINVAL, "a recorded call must use the device and stream given to abrk_plan_begin");
+    const void* rt = nullptr;
+    if (a && !a->builtin) {
+      r->tables.emplace_back(new std::vector<unsigned char>(dtype == ABRK_F64 ? a->rt64 : a->rt32));
+      rt = r->tables.back()->data();
+    }
+    r->steps.emplace_back([fn, rt]() { return fn(rt); });
+    return 0;
+  }
+  HIPCHK(fn(arm_table(a, dtype)));
+  return st.finish();
+}
+
 int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
   *a = get_arm(arm_id);
   if (!*a) return fail(ABRK_ENOARM, "unknown arm id %d", arm_id);
@@ -483,10 +523,9 @@ extern "C" int abrk_dynamics_batch(int arm_id, int dtype, int64_t B, const void*
   da.m = frame_m(frame, n);
   for (int r = 0; r < 3; r++) da.off[r] = x_off ? x_off[r] : 0.0;
   da.want = want;
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->dyn(dtype, la, da));
-  return st.finish();
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) { return ops->dyn(dtype, LaunchArgs{rt, (long)B, hs}, da); });
 }
 
 // ------------------------------------------------------------------------------- OSC
@@ -536,19 +575,15 @@ extern "C" int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_par
   oa.ts = st.fix(ts_, training_signal);
   oa.use_C = P->use_C ? 1 : 0;
   oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
-  OscP<double> p64;
-  OscP<float> p32;
-  if (dtype == ABRK_F64) {
-    p64 = make_oscp<double>(*P, n);
-    oa.P = &p64;
-  } else {
-    p32 = make_oscp<float>(*P, n);
-    oa.P = &p32;
-  }
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->osc(dtype, la, oa));
-  return st.finish();
+  const OscP<double> p64 = make_oscp<double>(*P, n);
+  const OscP<float> p32 = make_oscp<float>(*P, n);
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) {
+    OscArgs o = oa;
+    o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return ops->osc(dtype, LaunchArgs{rt, (long)B, hs}, o);
+  });
 }
 
 // ------------------------------------------------------------------------------- Sliding
@@ -584,19 +619,15 @@ extern "C" int abrk_sliding_generate_batch(int arm_id, int dtype, const abrk_sli
   sa.ta = st.fix(ta_, target_acc);
   sa.u = st.fix(u_, u);
   sa.s = st.fix(s_, s_out);
-  SlidingP<double> p64;
-  SlidingP<float> p32;
-  if (dtype == ABRK_F64) {
-    p64 = make_slidingp<double>(*P, n);
-    sa.P = &p64;
-  } else {
-    p32 = make_slidingp<float>(*P, n);
-    sa.P = &p32;
-  }
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->sliding(dtype, la, sa));
-  return st.finish();
+  const SlidingP<double> p64 = make_slidingp<double>(*P, n);
+  const SlidingP<float> p32 = make_slidingp<float>(*P, n);
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) {
+    SlidingArgs o = sa;
+    o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return ops->sliding(dtype, LaunchArgs{rt, (long)B, hs}, o);
+  });
 }
 
 // ------------------------------------------------------------------------------- Joint / Damping / RestingConfig
@@ -626,19 +657,15 @@ extern "C" int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_
   ja.target = st.fix(t_, target);
   ja.tv = st.fix(tv_, target_velocity);
   ja.u = st.fix(u_, u);
-  JointP<double> p64;
-  JointP<float> p32;
-  if (dtype == ABRK_F64) {
-    p64 = make_jointp<double>(*ctrl, account_for_gravity);
-    ja.P = &p64;
-  } else {
-    p32 = make_jointp<float>(*ctrl, account_for_gravity);
-    ja.P = &p32;
-  }
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->joint(dtype, la, ja));
-  return st.finish();
+  const JointP<double> p64 = make_jointp<double>(*ctrl, account_for_gravity);
+  const JointP<float> p32 = make_jointp<float>(*ctrl, account_for_gravity);
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) {
+    JointArgs o = ja;
+    o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return ops->joint(dtype, LaunchArgs{rt, (long)B, hs}, o);
+  });
 }
 
 // ------------------------------------------------------------------------------- AvoidJointLimits / Floating / AvoidObstacles
@@ -658,19 +685,15 @@ extern "C" int abrk_avoid_joint_limits_generate_batch(int n_joints, int dtype, c
   const void* q_ = st.add(q, B * n * s, true, false);
   void* u_ = st.add(u, B * n * s, accumulate != 0, true);
   if (int rc = st.reserve()) return rc;
-  LimitsP<double> p64;
-  LimitsP<float> p32;
-  const void* P;
-  if (dtype == ABRK_F64) {
-    p64 = make_limitsp<double>(*params);
-    P = &p64;
-  } else {
-    p32 = make_limitsp<float>(*params);
-    P = &p32;
-  }
-  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
-  HIPCHK(launch_limits(n, dtype, la, P, st.fix(q_, q), st.fix(u_, u), accumulate != 0));
-  return st.finish();
+  const LimitsP<double> p64 = make_limitsp<double>(*params);
+  const LimitsP<float> p32 = make_limitsp<float>(*params);
+  const void* qd = st.fix(q_, q);
+  void* ud = st.fix(u_, u);
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, nullptr, dtype, [=](const void*) {
+    return launch_limits(n, dtype, LaunchArgs{nullptr, (long)B, hs},
+                         dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32, qd, ud, accumulate != 0);
+  });
 }
 
 extern "C" int abrk_floating_generate_batch(int arm_id, int dtype, int dynamic, int task_space, int64_t B,
@@ -696,10 +719,9 @@ extern "C" int abrk_floating_generate_batch(int arm_id, int dtype, int dynamic, 
   fa.q = st.fix(q_, q);
   fa.dq = dynamic ? st.fix(dq_, dq) : nullptr;
   fa.u = st.fix(u_, u);
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->floating(dtype, la, fa));
-  return st.finish();
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) { return ops->floating(dtype, LaunchArgs{rt, (long)B, hs}, fa); });
 }
 
 extern "C" int abrk_avoid_obstacles_generate_batch(int arm_id, int dtype, const abrk_obstacles_params* params,
@@ -721,22 +743,19 @@ extern "C" int abrk_avoid_obstacles_generate_batch(int arm_id, int dtype, const 
   void* u_ = st.add(u, B * n * s, accumulate != 0, true);
   if (int rc = st.reserve()) return rc;
   ObstaclesArgs oa;
-  ObsP<double> p64;
-  ObsP<float> p32;
-  if (dtype == ABRK_F64) {
-    p64 = make_obsp<double>(*params);
-    oa.P = &p64;
-  } else {
-    p32 = make_obsp<float>(*params);
-    oa.P = &p32;
-  }
+  const ObsP<double> p64 = make_obsp<double>(*params);
+  const ObsP<float> p32 = make_obsp<float>(*params);
+  oa.P = nullptr;
   oa.acc = accumulate != 0;
   oa.q = st.fix(q_, q);
   oa.u = st.fix(u_, u);
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->obstacles(dtype, la, oa));
-  return st.finish();
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) {
+    ObstaclesArgs o = oa;
+    o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return ops->obstacles(dtype, LaunchArgs{rt, (long)B, hs}, o);
+  });
 }
 
 // ------------------------------------------------------------------------------- OSC law on supplied dynamics
@@ -804,22 +823,20 @@ extern "C" int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params
   a.une = st.fix(une_, u_null_ext);
   a.u = st.fix(u_, u);
   a.ts = st.fix(ts_, training_signal);
-  OscP<double> p64;
-  OscP<float> p32;
-  if (dtype == ABRK_F64) {
-    p64 = make_oscp<double>(*P, n);
-    a.P = &p64;
-  } else {
-    p32 = make_oscp<float>(*P, n);
-    a.P = &p32;
-  }
-  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
-  HIPCHK(launch_osc_law(n, dtype, la, a));
-  return st.finish();
+  const OscP<double> p64 = make_oscp<double>(*P, n);
+  const OscP<float> p32 = make_oscp<float>(*P, n);
+  a.P = nullptr;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, nullptr, dtype, [=](const void*) {
+    LawArgs o = a;
+    o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return launch_osc_law(n, dtype, LaunchArgs{nullptr, (long)B, hs}, o);
+  });
 }
 
 // ------------------------------------------------------------------------------- helper methods of OSC
 static int check_helper(int dtype, int64_t B) {
+  if (recording()) return fail(ABRK_EINVAL, "the OSC helper / transformations entry points cannot be recorded into a plan");
   if (dtype != ABRK_F64 && dtype != ABRK_F32) return fail(ABRK_EINVAL, "dtype %d is not ABRK_F64/ABRK_F32", dtype);
   if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
   return 0;
@@ -935,12 +952,15 @@ extern "C" int abrk_twolink_step_batch(int dtype, const abrk_twolink_plant* plan
   void* dq_ = st.add(dq, B * 2 * s, true, true);
   const void* u_ = st.add(u, B * 2 * s, true, false);
   if (int rc = st.reserve()) return rc;
-  TwoLinkP<double> k64 = make_plant<double>(*plant);
-  TwoLinkP<float> k32 = make_plant<float>(*plant);
-  LaunchArgs la{nullptr, (long)B, (hipStream_t)stream};
-  HIPCHK(launch_twolink_step(dtype, la, dtype == ABRK_F64 ? (const void*)&k64 : (const void*)&k32, st.fix(q_, q),
-                             st.fix(dq_, dq), st.fix(u_, u)));
-  return st.finish();
+  const TwoLinkP<double> k64 = make_plant<double>(*plant);
+  const TwoLinkP<float> k32 = make_plant<float>(*plant);
+  void *qd = st.fix(q_, q), *dqd = st.fix(dq_, dq);
+  const void* ud = st.fix(u_, u);
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, nullptr, dtype, [=](const void*) {
+    return launch_twolink_step(dtype, LaunchArgs{nullptr, (long)B, hs},
+                               dtype == ABRK_F64 ? (const void*)&k64 : (const void*)&k32, qd, dqd, ud);
+  });
 }
 
 extern "C" int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_osc_params* P,
@@ -990,154 +1010,153 @@ extern "C" int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_
   ra.qt = st.fix(qt_, q_traj);
   ra.dqt = st.fix(dqt_, dq_traj);
   ra.ut = st.fix(ut_, u_traj);
-  OscP<double> p64;
-  OscP<float> p32;
-  TwoLinkP<double> k64 = make_plant<double>(*plant);
-  TwoLinkP<float> k32 = make_plant<float>(*plant);
-  if (dtype == ABRK_F64) {
-    p64 = make_oscp<double>(*P, n);
-    ra.P = &p64;
-    ra.K = &k64;
-  } else {
-    p32 = make_oscp<float>(*P, n);
-    ra.P = &p32;
-    ra.K = &k32;
-  }
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->rollout(dtype, la, ra));
-  return st.finish();
+  const OscP<double> p64 = make_oscp<double>(*P, n);
+  const OscP<float> p32 = make_oscp<float>(*P, n);
+  const TwoLinkP<double> k64 = make_plant<double>(*plant);
+  const TwoLinkP<float> k32 = make_plant<float>(*plant);
+  ra.P = ra.K = nullptr;
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) {
+    RolloutArgs o = ra;
+    o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    o.K = dtype == ABRK_F64 ? (const void*)&k64 : (const void*)&k32;
+    return ops->rollout(dtype, LaunchArgs{rt, (long)B, hs}, o);
+  });
 }
 
 // ------------------------------------------------------------------------------- launch plans
+// A plan is the list of kernel launches recorded between abrk_plan_begin and abrk_plan_end (one control tick: one
+// law, or several secondary controllers accumulating into the buffer the OSC law then filters).  Launching it only
+// enqueues those kernels on the plan's stream - no validation, no pointer classification, no locks, no staging.
 namespace {
-struct OscPlan {
-  bool live = false;
-  int dtype = 0, device = 0;
-  const ArmOps* ops = nullptr;
-  std::vector<unsigned char> rt;  // private copy of the user-arm table
-  OscP<double> p64;
-  OscP<float> p32;
-  OscArgs oa;
-  bool sliding = false;  // a Sliding.generate plan (abrk_sliding_plan_create) instead of an OSC one
-  SlidingP<double> s64;
-  SlidingP<float> s32;
-  SlidingArgs sa;
-  LaunchArgs la;
-  hipError_t enqueue() const { return sliding ? ops->sliding(dtype, la, sa) : ops->osc(dtype, la, oa); }
+struct Plan {
+  int id = -1, device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<std::function<hipError_t()>> steps;
+  std::vector<std::unique_ptr<std::vector<unsigned char>>> tables;
+  hipError_t enqueue() const {
+    for (const auto& f : steps) {
+      hipError_t e = f();
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
   int graph_repeat = 0;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  void drop_graph() {
+    if (graph_exec || graph) {
+      if (hipSetDevice(device) == hipSuccess) {
+        t_current_device = device;
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();
+    }
+    graph_exec = nullptr;
+    graph = nullptr;
+    graph_repeat = 0;
+  }
 };
+// Slot table: abrk_plan_launch reads a slot without taking the lock (hot path of a control loop).  Slots are
+// recycled: a plan id is slot | generation << 12, so a stale id of a destroyed plan never matches the slot's new
+// tenant; the payload of a destroyed plan is freed.  (Destroying a plan while another thread launches it is a
+// caller error, as with any handle.)
+constexpr int kSlotBits = 12, kMaxPlans = 1 << kSlotBits, kGenMask = (1 << (31 - kSlotBits)) - 1;
 std::mutex g_plan_mu;
-// fixed slot table: abrk_plan_launch reads a slot without taking the lock (hot path of a control loop),
-// so slots must never move; creation/destruction are serialised by g_plan_mu
-constexpr int kMaxPlans = 4096;
-OscPlan* g_plans[kMaxPlans] = {};
-int g_n_plans = 0;
+Plan* g_plans[kMaxPlans] = {};
+int g_plan_gen[kMaxPlans] = {};
+std::vector<int> g_plan_free;
+int g_plan_hi = 0;  // slots [0, g_plan_hi) have been handed out at least once
+
+Plan* find_plan(int id) {
+  if (id < 0) return nullptr;
+  Plan* pl = __atomic_load_n(&g_plans[id & (kMaxPlans - 1)], __ATOMIC_ACQUIRE);
+  return (pl && pl->id == id) ? pl : nullptr;
+}
+int register_plan(Plan* pl) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  int slot;
+  if (!g_plan_free.empty()) {
+    slot = g_plan_free.back();
+    g_plan_free.pop_back();
+  } else if (g_plan_hi < kMaxPlans) {
+    slot = g_plan_hi++;
+  } else {
+    delete pl;
+    return fail(ABRK_ENOMEM, "too many live plans (max %d)", kMaxPlans);
+  }
+  pl->id = slot | (g_plan_gen[slot] << kSlotBits);
+  __atomic_store_n(&g_plans[slot], pl, __ATOMIC_RELEASE);
+  return pl->id;
+}
+void abort_recording() {
+  delete t_rec;
+  t_rec = nullptr;
+}
 }  // namespace
 
-namespace { struct OscPlan; }
-static int register_plan(OscPlan* pl);
+extern "C" int abrk_plan_begin(int device, void* stream) {
+  if (t_rec) return fail(ABRK_EINVAL, "this thread is already recording a plan");
+  if (int rc = use_device(device)) return rc;
+  t_rec = new Recorder;
+  t_rec->device = device;
+  t_rec->stream = (hipStream_t)stream;
+  return 0;
+}
 
+extern "C" int abrk_plan_abort(void) {
+  abort_recording();
+  return 0;
+}
+
+extern "C" int abrk_plan_end(void) {
+  if (!t_rec) return fail(ABRK_EINVAL, "abrk_plan_end without abrk_plan_begin");
+  if (t_rec->steps.empty()) {
+    abort_recording();
+    return fail(ABRK_EINVAL, "nothing was recorded (every call had B == 0 or failed)");
+  }
+  Plan* pl = new Plan;
+  pl->device = t_rec->device;
+  pl->stream = t_rec->stream;
+  pl->steps = std::move(t_rec->steps);
+  pl->tables = std::move(t_rec->tables);
+  abort_recording();
+  return register_plan(pl);
+}
+
+// the two original single-law plans: record exactly one call
 extern "C" int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
                                     const void* dq, const void* target, const void* target_velocity,
                                     void* integrated_error, const void* u_null_ext, void* u,
                                     void* training_signal, int device, void* stream) {
-  ArmEntry* a;
-  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
-  const int n = a->desc.n_joints;
-  if (!P) return fail(ABRK_EINVAL, "params is NULL");
-  if (P->ref_frame < 0 || P->ref_frame > 2 * n + 1)
-    return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", P->ref_frame);
-  if (P->n_null < 0 || P->n_null > ABRK_MAX_NULL) return fail(ABRK_EINVAL, "n_null=%d outside 0..%d", P->n_null, ABRK_MAX_NULL);
-  if (P->orientation_algorithm != 0 && P->orientation_algorithm != 1)
-    return fail(ABRK_EINVAL, "Invalid algorithm number %d for calculating orientation error", P->orientation_algorithm);
-  int k = 0;
-  for (int r = 0; r < 6; r++) k += P->ctrlr_dof[r] ? 1 : 0;
-  if (k == 0) return fail(ABRK_EINVAL, "ctrlr_dof selects no task-space dimension");
   if (B <= 0) return fail(ABRK_EINVAL, "a plan needs a positive batch");
-  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
-  if (P->ki != 0 && !integrated_error) return fail(ABRK_EINVAL, "ki != 0 needs the integrated_error state array");
-  if (int rc = use_device(device)) return rc;
-  const void* ptrs[] = {q, dq, target, target_velocity, integrated_error, u_null_ext, u, training_signal};
-  for (const void* p : ptrs)
-    if (p && !is_device_ptr(p)) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
-  OscPlan* pl = new OscPlan;
-  pl->live = true;
-  pl->dtype = dtype;
-  pl->device = device;
-  pl->ops = a->ops;
-  if (!a->builtin) pl->rt = dtype == ABRK_F64 ? a->rt64 : a->rt32;
-  pl->p64 = make_oscp<double>(*P, n);
-  pl->p32 = make_oscp<float>(*P, n);
-  pl->oa.P = dtype == ABRK_F64 ? (const void*)&pl->p64 : (const void*)&pl->p32;
-  pl->oa.q = q;
-  pl->oa.dq = dq;
-  pl->oa.target = target;
-  pl->oa.tv = target_velocity;
-  pl->oa.ierr = (P->ki != 0) ? integrated_error : nullptr;
-  pl->oa.une = u_null_ext;
-  pl->oa.u = u;
-  pl->oa.ts = training_signal;
-  pl->oa.use_C = P->use_C ? 1 : 0;
-  pl->oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
-  pl->la = LaunchArgs{a->builtin ? nullptr : (const void*)pl->rt.data(), (long)B, (hipStream_t)stream};
-  return register_plan(pl);
-}
-
-static int register_plan(OscPlan* pl) {
-  std::lock_guard<std::mutex> lk(g_plan_mu);
-  if (g_n_plans >= kMaxPlans) {
-    delete pl;
-    return fail(ABRK_ENOMEM, "too many plans (max %d)", kMaxPlans);
+  if (int rc = abrk_plan_begin(device, stream)) return rc;
+  if (int rc = abrk_osc_generate_batch(arm_id, dtype, P, B, q, dq, target, target_velocity, integrated_error,
+                                       u_null_ext, u, training_signal, device, stream)) {
+    abort_recording();
+    return rc;
   }
-  g_plans[g_n_plans] = pl;
-  __atomic_thread_fence(__ATOMIC_RELEASE);
-  return g_n_plans++;
+  return abrk_plan_end();
 }
 
 extern "C" int abrk_sliding_plan_create(int arm_id, int dtype, const abrk_sliding_params* P, int64_t B, const void* q,
                                         const void* dq, const void* target, const void* target_velocity,
                                         const void* target_acc, void* u, void* s_out, int device, void* stream) {
-  ArmEntry* a;
-  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
-  const int n = a->desc.n_joints;
-  if (!P) return fail(ABRK_EINVAL, "params is NULL");
-  if (P->ref_frame < 0 || P->ref_frame > 2 * n + 1)
-    return fail(ABRK_EFRAME, "Invalid transformation name: frame id %d", P->ref_frame);
   if (B <= 0) return fail(ABRK_EINVAL, "a plan needs a positive batch");
-  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
-  if (int rc = use_device(device)) return rc;
-  const void* ptrs[] = {q, dq, target, target_velocity, target_acc, u, s_out};
-  for (const void* p : ptrs)
-    if (p && !is_device_ptr(p)) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
-  OscPlan* pl = new OscPlan;
-  pl->live = true;
-  pl->sliding = true;
-  pl->dtype = dtype;
-  pl->device = device;
-  pl->ops = a->ops;
-  if (!a->builtin) pl->rt = dtype == ABRK_F64 ? a->rt64 : a->rt32;
-  pl->s64 = make_slidingp<double>(*P, n);
-  pl->s32 = make_slidingp<float>(*P, n);
-  pl->sa.P = dtype == ABRK_F64 ? (const void*)&pl->s64 : (const void*)&pl->s32;
-  pl->sa.q = q;
-  pl->sa.dq = dq;
-  pl->sa.target = target;
-  pl->sa.tv = target_velocity;
-  pl->sa.ta = target_acc;
-  pl->sa.u = u;
-  pl->sa.s = s_out;
-  pl->la = LaunchArgs{a->builtin ? nullptr : (const void*)pl->rt.data(), (long)B, (hipStream_t)stream};
-  return register_plan(pl);
+  if (int rc = abrk_plan_begin(device, stream)) return rc;
+  if (int rc = abrk_sliding_generate_batch(arm_id, dtype, P, B, q, dq, target, target_velocity, target_acc, u, s_out,
+                                           device, stream)) {
+    abort_recording();
+    return rc;
+  }
+  return abrk_plan_end();
 }
 
 extern "C" int abrk_plan_launch(int plan) {
-  // slots are append-only and never move: reading one needs no lock once its id has been handed out
-  if (plan < 0 || plan >= kMaxPlans || !g_plans[plan] || !g_plans[plan]->live)
-    return fail(ABRK_EINVAL, "unknown plan %d", plan);
-  OscPlan* pl = g_plans[plan];
+  Plan* pl = find_plan(plan);
+  if (!pl) return fail(ABRK_EINVAL, "unknown plan %d", plan);
   if (t_current_device != pl->device) {
     HIPCHK(hipSetDevice(pl->device));
     t_current_device = pl->device;
@@ -1147,53 +1166,45 @@ extern "C" int abrk_plan_launch(int plan) {
 }
 
 extern "C" int abrk_plan_launch_graph(int plan, int repeat) {
-  if (plan < 0 || plan >= kMaxPlans || !g_plans[plan] || !g_plans[plan]->live)
-    return fail(ABRK_EINVAL, "unknown plan %d", plan);
+  Plan* pl = find_plan(plan);
+  if (!pl) return fail(ABRK_EINVAL, "unknown plan %d", plan);
   if (repeat < 1) return fail(ABRK_EINVAL, "repeat must be >= 1");
-  OscPlan* pl = g_plans[plan];
   if (t_current_device != pl->device) {
     HIPCHK(hipSetDevice(pl->device));
     t_current_device = pl->device;
   }
-  if (!pl->la.stream) return fail(ABRK_EINVAL, "graph launches need a plan created on an explicit stream");
+  if (!pl->stream) return fail(ABRK_EINVAL, "graph launches need a plan created on an explicit stream");
   if (pl->graph_repeat != repeat) {
-    if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
-    if (pl->graph) (void)hipGraphDestroy(pl->graph);
-    pl->graph_exec = nullptr;
-    pl->graph = nullptr;
-    pl->graph_repeat = 0;
-    HIPCHK(hipStreamBeginCapture(pl->la.stream, hipStreamCaptureModeThreadLocal));
+    pl->drop_graph();
+    HIPCHK(hipStreamBeginCapture(pl->stream, hipStreamCaptureModeThreadLocal));
     hipError_t le = hipSuccess;
     for (int i = 0; i < repeat && le == hipSuccess; i++) le = pl->enqueue();
-    hipError_t ce = hipStreamEndCapture(pl->la.stream, &pl->graph);
+    hipError_t ce = hipStreamEndCapture(pl->stream, &pl->graph);
     if (le != hipSuccess || ce != hipSuccess)
       return fail(ABRK_ENODEV, "graph capture failed: %s", hipGetErrorString(le != hipSuccess ? le : ce));
     HIPCHK(hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0));
     pl->graph_repeat = repeat;
   }
-  HIPCHK(hipGraphLaunch(pl->graph_exec, pl->la.stream));
+  HIPCHK(hipGraphLaunch(pl->graph_exec, pl->stream));
   return 0;
 }
 
 extern "C" int abrk_plan_destroy(int plan) {
   std::lock_guard<std::mutex> lk(g_plan_mu);
-  if (plan < 0 || plan >= kMaxPlans || !g_plans[plan] || !g_plans[plan]->live)
-    return fail(ABRK_EINVAL, "unknown plan %d", plan);
-  OscPlan* pl = g_plans[plan];
-  pl->live = false;
-  // the slot stays (ids are never reused); the captured graph and its executable are released
-  if (pl->graph_exec || pl->graph) {
-    if (hipSetDevice(pl->device) == hipSuccess) {
-      t_current_device = pl->device;
-      if (pl->graph_exec) (void)hipGraphExecDestroy(pl->graph_exec);
-      if (pl->graph) (void)hipGraphDestroy(pl->graph);
-    }
-    (void)hipGetLastError();
-    pl->graph_exec = nullptr;
-    pl->graph = nullptr;
-    pl->graph_repeat = 0;
-  }
+  Plan* pl = find_plan(plan);
+  if (!pl) return fail(ABRK_EINVAL, "unknown plan %d", plan);
+  const int slot = plan & (kMaxPlans - 1);
+  __atomic_store_n(&g_plans[slot], (Plan*)nullptr, __ATOMIC_RELEASE);
+  g_plan_gen[slot] = (g_plan_gen[slot] + 1) & kGenMask;
+  g_plan_free.push_back(slot);
+  pl->drop_graph();
+  delete pl;
   return 0;
+}
+
+extern "C" int abrk_plan_count(void) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  return g_plan_hi - (int)g_plan_free.size();
 }
 
 // ------------------------------------------------------------------------------- inverse kinematics
@@ -1226,9 +1237,12 @@ extern "C" int abrk_ik_generate_path_batch(int arm_id, int dtype, const abrk_ik_
   IkP<double> p64{P->max_dx * P->dt, P->max_dr * P->dt, P->max_dq * P->dt, P->n_timesteps, P->method};
   IkP<float> p32{(float)(P->max_dx * P->dt), (float)(P->max_dr * P->dt), (float)(P->max_dq * P->dt), P->n_timesteps,
                  P->method};
-  ia.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
-  LaunchArgs la{a->builtin ? nullptr : (dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data()),
-                (long)B, (hipStream_t)stream};
-  HIPCHK(a->ops->ik(dtype, la, ia));
-  return st.finish();
+  ia.P = nullptr;
+  const ArmOps* ops = a->ops;
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void* rt) {
+    IkArgs o = ia;
+    o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return ops->ik(dtype, LaunchArgs{rt, (long)B, hs}, o);
+  });
 }

@@ -336,28 +336,40 @@ def osc_rollout_twolink(arm_id, params, plant, q, dq, target, n_steps, every=0, 
     return outs if want_traj else None
 
 
-class OscPlan:
-    """A validated, pre-converted OSC launch on fixed device buffers (abrk_osc_plan_create): `launch()`
-    only enqueues the kernel on the plan's stream - the per-tick cost of a control loop whose state lives
-    on the GPU.  All arrays must be DeviceArrays; update their contents between launches."""
+class Plan:
+    """One control tick recorded as a launch plan (abrk_plan_begin .. abrk_plan_end): every engine call made inside
+    the `with` block - on DeviceArrays, with this plan's device and stream - is validated and converted once and its
+    kernel launch kept; `launch()` then only enqueues the recorded kernels, `launch_graph(repeat)` replays `repeat`
+    ticks as one hipGraph launch.
 
-    def __init__(self, arm_id, n, params, q, dq, target, u, target_velocity=None, integrated_error=None,
-                 u_null_ext=None, training_signal=None, dtype=np.float64, device=0, stream=None):
-        a = _Args(dtype)
-        B = q.shape[0]
-        arrs = dict(q=(q, (B, n)), dq=(dq, (B, n)), target=(target, (B, 6)), target_velocity=(target_velocity, (B, 6)),
-                    integrated_error=(integrated_error, (B, 6)), u_null_ext=(u_null_ext, (B, n)), u=(u, (B, n)),
-                    training_signal=(training_signal, (B, n)))
-        ptr = {}
-        for name, (arr, shape) in arrs.items():
-            if arr is not None and not isinstance(arr, DeviceArray):
-                raise TypeError(f"{name}: launch plans take DeviceArrays")
-            ptr[name] = a.inp(arr, shape, name)
-        self._keep = [v[0] for v in arrs.values()] + [params, stream]
+        with engine.Plan(device, stream) as tick:
+            engine.avoid_joint_limits_generate(n, lim, q, u=une, dtype=dt, device=device, stream=stream)
+            engine.avoid_obstacles_generate(arm, n, obs, q, u=une, accumulate=True, ..., stream=stream)
+            engine.osc_generate(arm, n, params, q, dq, target, u_null_ext=une, u=u, ..., stream=stream)
+        tick.launch()
+
+    The arrays must stay alive as long as the plan (results the engine allocates are returned to the caller as
+    usual; `keep()` parks references on the plan)."""
+
+    def __init__(self, device=0, stream=None):
+        self.device, self.stream, self.id = device, stream, None
+        self._keep = [stream]
         self._launch = lib().abrk_plan_launch
-        self.id = check(lib().abrk_osc_plan_create(
-            arm_id, a.code, C.byref(params), B, ptr["q"], ptr["dq"], ptr["target"], ptr["target_velocity"],
-            ptr["integrated_error"], ptr["u_null_ext"], ptr["u"], ptr["training_signal"], device, _sp(stream)))
+
+    def __enter__(self):
+        check(lib().abrk_plan_begin(self.device, _sp(self.stream)))
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is not None:
+            lib().abrk_plan_abort()
+            return False
+        self.id = check(lib().abrk_plan_end())
+        return False
+
+    def keep(self, *objs):
+        self._keep.extend(objs)
+        return self
 
     def launch(self):
         rc = self._launch(self.id)
@@ -368,18 +380,48 @@ class OscPlan:
         """`repeat` consecutive launches as one hipGraph launch (needs a plan on an explicit stream)"""
         check(lib().abrk_plan_launch_graph(self.id, int(repeat)))
 
+    def close(self):
+        pid, self.id = self.id, None
+        if pid is not None:
+            lib().abrk_plan_destroy(pid)
+
     def __del__(self):
         try:
-            lib().abrk_plan_destroy(self.id)
-        except Exception:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
 
-class SlidingPlan(OscPlan):
+class OscPlan(Plan):
+    """A validated, pre-converted OSC launch on fixed device buffers (abrk_osc_plan_create): `launch()`
+    only enqueues the kernel on the plan's stream - the per-tick cost of a control loop whose state lives
+    on the GPU.  All arrays must be DeviceArrays; update their contents between launches."""
+
+    def __init__(self, arm_id, n, params, q, dq, target, u, target_velocity=None, integrated_error=None,
+                 u_null_ext=None, training_signal=None, dtype=np.float64, device=0, stream=None):
+        Plan.__init__(self, device, stream)
+        a = _Args(dtype)
+        B = q.shape[0]
+        arrs = dict(q=(q, (B, n)), dq=(dq, (B, n)), target=(target, (B, 6)), target_velocity=(target_velocity, (B, 6)),
+                    integrated_error=(integrated_error, (B, 6)), u_null_ext=(u_null_ext, (B, n)), u=(u, (B, n)),
+                    training_signal=(training_signal, (B, n)))
+        ptr = {}
+        for name, (arr, shape) in arrs.items():
+            if arr is not None and not isinstance(arr, DeviceArray):
+                raise TypeError(f"{name}: launch plans take DeviceArrays")
+            ptr[name] = a.inp(arr, shape, name)
+        self._keep += [v[0] for v in arrs.values()] + [params]
+        self.id = check(lib().abrk_osc_plan_create(
+            arm_id, a.code, C.byref(params), B, ptr["q"], ptr["dq"], ptr["target"], ptr["target_velocity"],
+            ptr["integrated_error"], ptr["u_null_ext"], ptr["u"], ptr["training_signal"], device, _sp(stream)))
+
+
+class SlidingPlan(Plan):
     """The same for Sliding.generate (abrk_sliding_plan_create): launch(), launch_graph(repeat)"""
 
     def __init__(self, arm_id, n, params, q, dq, target, u, target_velocity=None, target_acc=None, s=None,
                  dtype=np.float64, device=0, stream=None):
+        Plan.__init__(self, device, stream)
         a = _Args(dtype)
         B = q.shape[0]
         nt = 3 if params.cartesian else n
@@ -390,8 +432,7 @@ class SlidingPlan(OscPlan):
             if arr is not None and not isinstance(arr, DeviceArray):
                 raise TypeError(f"{name}: launch plans take DeviceArrays")
             ptr[name] = a.inp(arr, shape, name)
-        self._keep = [v[0] for v in arrs.values()] + [params, stream]
-        self._launch = lib().abrk_plan_launch
+        self._keep += [v[0] for v in arrs.values()] + [params]
         self.id = check(lib().abrk_sliding_plan_create(
             arm_id, a.code, C.byref(params), B, ptr["q"], ptr["dq"], ptr["target"], ptr["target_velocity"],
             ptr["target_acc"], ptr["u"], ptr["s"], device, _sp(stream)))

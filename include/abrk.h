@@ -245,6 +245,19 @@ int abrk_osc_plan_create(int arm_id, int dtype, const abrk_osc_params* params, i
                          const void* dq, const void* target, const void* target_velocity,
                          void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
                          int device, void* stream);
+/* General form: RECORD one control tick.  Between abrk_plan_begin and abrk_plan_end every abrk_*_batch call made by
+ * this thread (dynamics, OSC, OSC law, Sliding, Joint / Damping / RestingConfig, AvoidJointLimits, Floating,
+ * AvoidObstacles, inverse kinematics, the two-link plant step and rollout) is validated and converted as usual but
+ * its kernel launch is kept in the plan instead of being enqueued - e.g. AvoidJointLimits and AvoidObstacles
+ * accumulating into the buffer that the OSC call then takes as u_null_ext (osc.py:310-318) become ONE plan of
+ * three kernels.  Each recorded call must pass device pointers only and the device and stream given to
+ * abrk_plan_begin.  abrk_plan_end returns the plan id (>= 0); abrk_plan_abort drops the recording.  Ids of
+ * destroyed plans are never valid again (generation-tagged), their slots and memory are recycled: a loop that
+ * re-plans whenever gains, targets or buffers change can do so indefinitely; up to 4096 plans live at a time. */
+int abrk_plan_begin(int device, void* stream);
+int abrk_plan_end(void);
+int abrk_plan_abort(void);
+int abrk_plan_count(void); /* live plans */
 int abrk_plan_launch(int plan);
 /* `repeat` consecutive launches of the plan as ONE hipGraph launch (captured on first use and cached per
  * repeat count): removes the per-launch host work and tightens the dependent-launch gaps of short kernels. */

@@ -975,3 +975,176 @@ def test_gpu_truncated_pinv_rows_are_compared():
 def test_gpu_quaternion_every_frame(arm):
     """power-iteration quaternion vs the reference's eigh on every frame, incl. Jaco2's non-orthogonal late frames"""
     cases.check_quaternions_all_frames(cases.GpuBackend(arm, "static"), arm, golden(f"quat_{arm}"))
+
+
+# ---------------------------------------------------------------------------- recorded launch plans (abrk_plan_begin/end)
+def _dev(*arrays):
+    import abr_control_amd as a
+
+    return [a.DeviceArray.from_numpy(np.ascontiguousarray(x)) for x in arrays]
+
+
+def _zero(arr):
+    """memset on the null stream, completed before anything is enqueued on the (non-blocking) plan stream"""
+    from abr_control_amd._lib import check, lib
+
+    arr.zero_()
+    check(lib().abrk_device_sync(arr.device))
+
+
+def test_gpu_recorded_plans_equal_direct_calls():
+    """Joint / Damping / RestingConfig / Floating / AvoidJointLimits / AvoidObstacles / inverse kinematics / dynamics:
+    the recorded plan (launch and hipGraph replay) writes exactly what the direct call writes"""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+
+    be = cases.GpuBackend("ur5")
+    arm, n, B = be.arm_id, 6, 4096
+    q, dq, t = draw(71, B, n)
+    g = golden("sec_ur5")
+    lim = cases.secondary_limit_params(g, "limA", n)
+    obs = cases.secondary_obstacle_params(g)
+    ikp = _abi.make_ik_params(n_timesteps=20)
+    s = a.Stream(0)
+    qd, dqd, td = _dev(q, dq, t)
+    calls = {
+        "joint": lambda u: engine.joint_generate(arm, n, _abi.make_joint(30, 6), True, qd, dqd, td, None, u=u, stream=s),
+        "damping": lambda u: engine.joint_generate(arm, n, _abi.make_damping(7), False, qd, dqd, u=u, stream=s),
+        "resting": lambda u: engine.joint_generate(arm, n, _abi.make_resting([None, 0.5, 1, None, 2, None], kp=20, kv=4),
+                                                   False, qd, dqd, u=u, stream=s),
+        "floating": lambda u: engine.floating_generate(arm, n, 1, 1, qd, dqd, u=u, stream=s),
+        "limits": lambda u: engine.avoid_joint_limits_generate(n, lim, qd, u=u, stream=s),
+        "obstacles": lambda u: engine.avoid_obstacles_generate(arm, n, obs, qd, u=u, stream=s),
+    }
+    for name, call in calls.items():
+        u_direct, u_plan = a.DeviceArray((B, n)), a.DeviceArray((B, n))
+        call(u_direct)
+        s.sync()
+        with engine.Plan(0, s) as plan:
+            call(u_plan)
+        _zero(u_plan)
+        plan.launch()
+        s.sync()
+        assert np.array_equal(u_plan.numpy(), u_direct.numpy()), name
+        _zero(u_plan)
+        plan.launch_graph(4)
+        s.sync()
+        assert np.array_equal(u_plan.numpy(), u_direct.numpy()), name
+        assert np.abs(u_direct.numpy()).max() > 0, name
+        plan.close()
+    # inverse kinematics and the robot_config outputs
+    pp, vp = engine.ik_generate_path(arm, n, ikp, qd, td, stream=s)
+    pp2, vp2 = a.DeviceArray((B, 20, n)), a.DeviceArray((B, 20, n))
+    with engine.Plan(0, s) as plan:
+        engine.ik_generate_path(arm, n, ikp, qd, td, stream=s, position_path=pp2, velocity_path=vp2)
+        r2 = engine.dynamics(arm, n, qd, dqd, _abi.frame_id("EE", n), None, ("Tx", "J", "M", "g", "C"), np.float64, 0,
+                             stream=s)
+    plan.launch_graph(2)
+    s.sync()
+    assert np.array_equal(pp.numpy(), pp2.numpy()) and np.array_equal(vp.numpy(), vp2.numpy())
+    r1 = engine.dynamics(arm, n, q, dq, _abi.frame_id("EE", n), None, ("Tx", "J", "M", "g", "C"), np.float64, 0)
+    for k in r1:
+        assert np.array_equal(r1[k], r2[k].numpy()), k
+
+
+def test_gpu_recorded_tick_of_three_kernels_equals_the_controller_classes():
+    """one plan = AvoidJointLimits -> AvoidObstacles (accumulate) -> OSC with the sum behind its null-space filter
+    (osc.py:310-318) == OSC(null_controllers=[limits, obstacles, Damping]).generate of the public classes"""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC, AvoidJointLimits, AvoidObstacles, Damping
+
+    g = golden("sec_ur5")
+    n, B = 6, 2048
+    q, dq, t = draw(72, B, n)
+    rc = ur5.Config()
+    limits = AvoidJointLimits(rc, min_joint_angles=[0.8, None, 1.0, 0.5, None, 2.0],
+                              max_joint_angles=[5.0, 4.0, None, 5.5, 3.0, 4.5], max_torque=[30, 20, 10, 5, 5, 2],
+                              cross_zero=[False] * 6, gradient=[False, True, False, True, False, False])
+    obstacles = AvoidObstacles(rc, obstacles=g["obs_obstacles"], threshold=float(g["obs_threshold"]),
+                               gain=float(g["obs_gain"]))
+    ctrlr = OSC(rc, kp=100, null_controllers=[limits, obstacles, Damping(rc, kv=10)])
+    ref = ctrlr.generate(q, dq, t)
+    s = a.Stream(0)
+    qd, dqd, td = _dev(q, dq, t)
+    une, u = a.DeviceArray((B, n)), a.DeviceArray((B, n))
+    params = _abi.make_osc_params(n, kp=100, null_controllers=[_abi.make_damping(10)])
+    with engine.Plan(0, s) as tick:
+        engine.avoid_joint_limits_generate(n, limits._params, qd, u=une, stream=s)
+        engine.avoid_obstacles_generate(rc.arm_id, n, obstacles._params(), qd, u=une, accumulate=True, stream=s)
+        engine.osc_generate(rc.arm_id, n, params, qd, dqd, td, u_null_ext=une, u=u, stream=s)
+    for launch in (tick.launch, lambda: tick.launch_graph(3)):
+        _zero(u)
+        launch()
+        s.sync()
+        assert np.array_equal(u.numpy(), ref)
+
+
+def test_gpu_plan_slots_are_recycled_and_stale_ids_rejected():
+    """re-planning in a loop (gains / targets / buffers change) never exhausts the registry; the payload of a
+    destroyed plan is freed, its id stays invalid after the slot has a new tenant"""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+    from abr_control_amd._lib import AbrkError, lib
+
+    be = cases.GpuBackend("ur5")
+    q, dq, t = draw(73, 64, 6)
+    qd, dqd, td = _dev(q, dq, t)
+    u = a.DeviceArray((64, 6))
+    s = a.Stream(0)
+    base = lib().abrk_plan_count()
+    first = engine.OscPlan(be.arm_id, 6, _abi.make_osc_params(6, kp=1.0), qd, dqd, td, u, stream=s)
+    stale = first.id
+    first.close()
+    for i in range(6000):  # more than the 4096 slots
+        p = engine.OscPlan(be.arm_id, 6, _abi.make_osc_params(6, kp=float(1 + i)), qd, dqd, td, u, stream=s)
+        if i % 1500 == 0:
+            p.launch()
+        p.close()
+    assert lib().abrk_plan_count() == base
+    keep = engine.OscPlan(be.arm_id, 6, _abi.make_osc_params(6, kp=5.0), qd, dqd, td, u, stream=s)
+    assert (keep.id & 4095) == (stale & 4095) and keep.id != stale  # same slot, new generation
+    assert lib().abrk_plan_launch(stale) < 0 and lib().abrk_plan_destroy(stale) < 0
+    keep.launch()
+    s.sync()
+    assert np.array_equal(u.numpy(), be.osc(_abi.make_osc_params(6, kp=5.0), q, dq, t)[0])
+    # host pointers cannot be recorded; the failed recording leaves the thread usable
+    with pytest.raises(AbrkError):
+        with engine.Plan(0, s):
+            engine.osc_generate(be.arm_id, 6, _abi.make_osc_params(6), q, dq, t, stream=s)
+    assert lib().abrk_plan_count() == base + 1
+    with engine.Plan(0, s) as ok:
+        engine.osc_generate(be.arm_id, 6, _abi.make_osc_params(6), qd, dqd, td, u=u, stream=s)
+    ok.launch()
+    s.sync()
+
+
+def test_gpu_rollout_refuses_unfused_null_controllers_and_gains_are_live():
+    """ArmSim.rollout must not silently drop AvoidJointLimits / AvoidObstacles / Floating; the fused
+    Damping / RestingConfig gains are read at every generate() (gain scheduling), as the reference does by calling
+    null_controller.generate() every tick (osc.py:311-313); more than ABRK_MAX_NULL of them overflow to u_null_ext"""
+    from abr_control_amd.arms import twojoint, ur5
+    from abr_control_amd.arms.twojoint import ArmSim
+    from abr_control_amd.controllers import OSC, AvoidJointLimits, Damping
+    from oracle.oracle import Oracle
+
+    rc = twojoint.Config()
+    sim = ArmSim(rc, q_init=np.tile(rc.START_ANGLES, (4, 1)))
+    lim = AvoidJointLimits(rc, [0.1, 0.1], [3.0, 3.0], [5, 5])
+    with pytest.raises(TypeError):
+        sim.rollout(OSC(rc, kp=10, ctrlr_dof=cases.XY, null_controllers=[lim]), np.zeros(6), 10)
+    with pytest.raises(ValueError):
+        sim.rollout(OSC(twojoint.Config(), kp=10, ctrlr_dof=cases.XY), np.zeros(6), 10)
+    rc6 = ur5.Config()
+    q, dq, t = draw(74, 256, 6)
+    damp = Damping(rc6, kv=10)
+    c = OSC(rc6, kp=200, null_controllers=[damp])
+    o = Oracle(_abi.load_table("ur5"))
+    for kv in (10.0, 3.0):
+        damp.kv = kv
+        ref = o.osc_batch(_abi.make_osc_params(6, kp=200, null_controllers=[_abi.make_damping(kv)]), q, dq, t)
+        assert cases.rel_err(c.generate(q, dq, t), ref).max() < 1e-9
+    six = [Damping(rc6, kv=k) for k in (1.0, 2.0, 3.0, 4.0, 5.0, 6.0)]  # 4 fused + 2 through u_null_ext
+    ref = o.osc_batch(_abi.make_osc_params(6, kp=200, null_controllers=[_abi.make_damping(21.0)]), q, dq, t)
+    assert cases.rel_err(OSC(rc6, kp=200, null_controllers=six).generate(q, dq, t), ref).max() < 1e-9
