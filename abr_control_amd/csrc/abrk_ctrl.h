@@ -719,45 +719,41 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
 // FEAT selects which optional inputs are compiled in: 0 = none (the plain law: ~70 registers fewer,
 // two waves per SIMD), 1 = fused secondary controllers only (Damping / RestingConfig, BASELINE config 3),
 // 2 = everything (target velocity, integral state, caller-evaluated null signal).
-template <class A, class T, int KM, bool USE_C, int FEAT, class Late>
+template <class A, class T, int KM, bool USE_C, int FEAT, class Late, class Scr>
 ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
                       bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
-                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late) {
+                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late, Scr& scr) {
   constexpr int N = A::N;
   constexpr bool FAST = (KM <= 3);
-  // OSC(use_C) on orthogonal chains in two passes over the same state (ABRK_C_TWO_PASS): first the Coriolis vector
-  // alone (body recursion; keeps sin/cos), then the plain dynamics pass from the kept sin/cos.  The second forward
-  // kinematics costs ~90 instructions; in exchange the register peak stays at the plain law's level (two waves per
-  // SIMD instead of one with 144 parked registers; the six-row kernels stop spilling).
+  // OSC(use_C) on orthogonal chains (ABRK_C_TWO_PASS): the Coriolis vector rides on the dynamics pass.  The link
+  // visitor of the forward kinematics also advances a body recursion (rne_forward_step) and parks each link's wrench
+  // in `scr` - LDS on the GPU, so the 12 N registers they would take stay free and the kernel keeps two waves per
+  // SIMD -; one backward sweep (rne_backward) then projects the sums onto the joint axes.  (Until round 2 the
+  // recursion ran as a pass of its own with a second forward kinematics: +128 instructions per row.)
   constexpr bool TWO_PASS = USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0);
   Joints<A, T> jt;
   Dyn<A, T, (USE_C && !TWO_PASS) ? CMODE_VEC : CMODE_NONE> d;
   T XR[9], xo[3];
   T p[3], RF[9];
-  T cv2[TWO_PASS ? N : 1], sv[TWO_PASS ? N : 1][2];
+  T cv2[TWO_PASS ? N : 1];
+  RneState<T> rne;
   int m = N;
-  if constexpr (TWO_PASS) {
-    {
-      Joints<A, T> jt1;
-      Dyn<A, T, CMODE_CVONLY> d1;
-      T XR1[9], xo1[3];
-      NoCap nc1;
-      sincos_all<N>(q, sv);
-      kin_dyn_hook(arm, q, dq, jt1, d1, XR1, xo1, nc1, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScUse<T, N>{sv});
-      sfor<N>([&](auto i) ABRK_LAMBDA { cv2[i()] = d1.cv[i()]; });
-    }
-    // the second pass must not be merged with the first (that would keep both register sets alive)
-    sfor<N>([&](auto i) ABRK_LAMBDA {
-      opaque(sv[i()][0]);
-      opaque(sv[i()][1]);
-      opaque(cv2[i()]);
-    });
-  }
   auto dynamics_pass = [&](auto& cap_) ABRK_LAMBDA {
-    if constexpr (TWO_PASS)
-      kin_dyn_hook(arm, q, dq, jt, d, XR, xo, cap_, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScUse<T, N>{sv});
-    else
+    if constexpr (TWO_PASS) {
+      rne_init(rne);
+      kin_dyn_hook(arm, q, dq, jt, d, XR, xo, cap_, [&](auto L, const T(&pl)[3]) ABRK_LAMBDA {
+        ABRK_SCHED_FENCE();  // the link's Jacobian columns (M, g) are retired before the recursion's transients start
+        rne_forward_step<L()>(arm, jt, pl, dq, rne, scr);
+        ABRK_SCHED_FENCE();
+      });
+      rne_backward(jt, scr, cv2);
+      // the result is only consumed at the very end of the law: without this the scheduler reads the slab here and
+      // carries (spills) the 6 N values until then
+      sfor<N>([&](auto i) ABRK_LAMBDA { opaque(cv2[i()]); });
+      ABRK_SCHED_FENCE();
+    } else {
       kin_dyn(arm, q, dq, jt, d, XR, xo, cap_);
+    }
   };
   if constexpr (FAST) {
     NoCap nc;

@@ -880,6 +880,133 @@ ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, 
   }
 }
 
+// ---------------------------------------------------------------- Coriolis vector from the kept frames
+// Per-lane scratch that carries the link wrenches from the forward to the backward sweep of coriolis_rne.
+// RegScratch: plain arrays (host check build, small arms).  The GPU kernels use LdsScratch (abrk_kernels.h): 6 values
+// per link parked in the wavefront's LDS slab, which keeps 12 N VGPRs free while the recursion runs.
+template <class T, int N>
+struct RegScratch {
+  T f[N][3], t[N][3];
+  template <int K>
+  ABRK_INL void put(ic<K>, const T (&fv)[3], const T (&tv)[3]) {
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      f[K][r()] = fv[r()];
+      t[K][r()] = tv[r()];
+    });
+  }
+  ABRK_INL void seal() const {}
+  template <int K>
+  ABRK_INL void get(ic<K>, T (&fv)[3], T (&tv)[3]) const {
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      fv[r()] = f[K][r()];
+      tv[r()] = t[K][r()];
+    });
+  }
+};
+
+// a + al x d + w (w . d) - w2 d : acceleration of a point at offset d from a point of the same body whose
+// acceleration is a (w = angular velocity, w2 = |w|^2, al = angular acceleration).  w x (w x d) is taken as
+// w (w . d) - |w|^2 d: 15 instructions for the whole expression instead of 24.
+template <class T>
+ABRK_INL void point_accel(const T (&a)[3], const T (&al)[3], const T (&w)[3], T w2, const T (&d)[3], T (&out)[3]) {
+  const T s = dot3(w, d);
+  T x0 = Rm<T>::fma(al[1], d[2], a[0]), x1 = Rm<T>::fma(al[2], d[0], a[1]), x2 = Rm<T>::fma(al[0], d[1], a[2]);
+  x0 = Rm<T>::fma(-al[2], d[1], x0);
+  x1 = Rm<T>::fma(-al[0], d[2], x1);
+  x2 = Rm<T>::fma(-al[1], d[0], x2);
+  x0 = Rm<T>::fma(w[0], s, x0);
+  x1 = Rm<T>::fma(w[1], s, x1);
+  x2 = Rm<T>::fma(w[2], s, x2);
+  out[0] = Rm<T>::fma(-w2, d[0], x0);
+  out[1] = Rm<T>::fma(-w2, d[1], x1);
+  out[2] = Rm<T>::fma(-w2, d[2], x2);
+}
+
+// C(q,dq) dq of an orthogonal chain (base_config.py:678-727 applied to dq) alongside the dynamics pass - the same
+// forward kinematics serves both.  Recursive Newton-Euler with the reference's world-frame inertia diagonals
+// (base_config.py:628):
+//   forward, joint i:  a_o moves from o_{i-1} to o_i with the old body's (w, al); then al += (w x z_i) dq_i,
+//                      w += z_i dq_i;  link i+1: f = D_lin a(p), t = p x f + D_ang al + (D_ang w) x w
+//   backward, joint k: c_k = z_k . (sum_{l>k} t_l - o_k x sum_{l>k} f_l)
+// (the sign of the gyroscopic term is opposite to Euler's equation because D_ang is not rotated).
+template <class T>
+struct RneState {  // kinematic state of the body that carries the current link, referred to the last joint origin
+  T w[3], al[3], ao[3], w2;
+};
+template <class T>
+ABRK_INL void rne_init(RneState<T>& st) {
+  sfor<3>([&](auto r) ABRK_LAMBDA { st.w[r()] = st.al[r()] = st.ao[r()] = T(0); });
+  st.w2 = T(0);
+}
+// forward step for joint i = L - 1 and link L (COM at p): called from the link visitor of the forward kinematics,
+// when jt.z[i] / jt.o[i] have just been recorded
+template <int L, class A, class T, class Scr>
+ABRK_INL void rne_forward_step(const A& arm, const Joints<A, T>& jt, const T (&p)[3], const T (&dq)[A::N],
+                               RneState<T>& st, Scr& scr) {
+  static_assert(A::kOrtho, "general affine chains take the per-link form (link_accumulate, CMODE_VEC)");
+  constexpr int i = L - 1;
+  if constexpr (i < A::N) {
+    if constexpr (i > 0) {
+      T d2[3] = {jt.o[i][0] - jt.o[i - 1][0], jt.o[i][1] - jt.o[i - 1][1], jt.o[i][2] - jt.o[i - 1][2]};
+      T an[3];
+      point_accel(st.ao, st.al, st.w, st.w2, d2, an);
+      sfor<3>([&](auto r) ABRK_LAMBDA { st.ao[r()] = an[r()]; });
+      T zd[3];
+      cross3(st.w, jt.z[i], zd);  // d/dt z_i = w x z_i
+      sfor<3>([&](auto r) ABRK_LAMBDA { st.al[r()] = Rm<T>::fma(zd[r()], dq[i], st.al[r()]); });
+    }
+    sfor<3>([&](auto r) ABRK_LAMBDA { st.w[r()] = Rm<T>::fma(jt.z[i][r()], dq[i], st.w[r()]); });
+    st.w2 = dot3(st.w, st.w);
+    T f[3] = {T(0), T(0), T(0)}, t[3] = {T(0), T(0), T(0)};
+    if constexpr (L < A::NL) {
+      if constexpr (link_has_linear_mass<A, L>()) {
+        T dl[3] = {p[0] - jt.o[i][0], p[1] - jt.o[i][1], p[2] - jt.o[i][2]};
+        T a[3];
+        point_accel(st.ao, st.al, st.w, st.w2, dl, a);
+        f[0] = AccMD<A, T, L, 0>::get(arm) * a[0];
+        f[1] = AccMD<A, T, L, 1>::get(arm) * a[1];
+        f[2] = AccMD<A, T, L, 2>::get(arm) * a[2];
+        cross3(p, f, t);
+      }
+      if constexpr (A::MD(L, 3) != 0.0 || A::MD(L, 4) != 0.0 || A::MD(L, 5) != 0.0) {
+        const T I0 = AccMD<A, T, L, 3>::get(arm), I1 = AccMD<A, T, L, 4>::get(arm), I2 = AccMD<A, T, L, 5>::get(arm);
+        if constexpr (A::MD(L, 3) == A::MD(L, 4) && A::MD(L, 4) == A::MD(L, 5)) {
+          // isotropic inertia: (D w) x w vanishes
+          sfor<3>([&](auto r) ABRK_LAMBDA { t[r()] = Rm<T>::fma(I0, st.al[r()], t[r()]); });
+        } else {
+          const T Lw[3] = {I0 * st.w[0], I1 * st.w[1], I2 * st.w[2]};
+          T n[3];
+          cross3(Lw, st.w, n);
+          t[0] += Rm<T>::fma(I0, st.al[0], n[0]);
+          t[1] += Rm<T>::fma(I1, st.al[1], n[1]);
+          t[2] += Rm<T>::fma(I2, st.al[2], n[2]);
+        }
+      }
+    }
+    scr.put(ic<i>{}, f, t);
+  }
+}
+// backward sweep: c_k = z_k . (sum_{l>k} t_l - o_k x sum_{l>k} f_l)
+template <class A, class T, class Scr>
+ABRK_INL void rne_backward(const Joints<A, T>& jt, Scr& scr, T (&cv)[A::N]) {
+  constexpr int N = A::N;
+  T F[3] = {T(0), T(0), T(0)}, Nm[3] = {T(0), T(0), T(0)};
+  scr.seal();
+  sfor<N>([&](auto kr) ABRK_LAMBDA {
+    constexpr int k = N - 1 - kr();
+    T f[3], t[3];
+    scr.get(ic<k>{}, f, t);
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      F[r()] += f[r()];
+      Nm[r()] += t[r()];
+    });
+    T of[3];
+    cross3(jt.o[k], F, of);
+    const T wv[3] = {Nm[0] - of[0], Nm[1] - of[1], Nm[2] - of[2]};
+    cv[k] = dot3(jt.z[k], wv);
+  });
+}
+
 // FK + M, g (+C).  Returns joint state for Jacobians; (XR, xo) = last rotated joint frame.
 // `extra(ic<l>, p)` runs once per link l = 1..N (p = origin of its frame) while XR still holds the
 // rotation of joint_{l-1} after its Rz - callers that need per-link frames hook in here.

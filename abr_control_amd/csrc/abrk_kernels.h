@@ -83,13 +83,56 @@ constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho) {
              : ABRK_MIN_WAVES;
 }
 
+// Scratch of the Coriolis recursion in LDS: per link one force and one moment (6 values), laid out [link][pair][lane]
+// so that every access is a 16-byte (fp64) / 8-byte (fp32) piece per lane, contiguous across the wavefront (no bank
+// conflicts).  6 N values per lane: 18 KiB per wavefront for a six-joint arm in fp64 - eight wavefronts per CU (two
+// per SIMD) fit the 160 KiB.  Rows never share data, so no barrier is needed: each lane reads what it wrote.
+#ifndef ABRK_C_LDS
+#define ABRK_C_LDS 1
+#endif
+template <class T, int N>
+struct LdsScratch {
+  using V2 = T __attribute__((ext_vector_type(2)));
+  V2* slab;  // [N][3][kBlock]
+  int lane;
+  template <int K>
+  __device__ __forceinline__ void put(ic<K>, const T (&fv)[3], const T (&tv)[3]) {
+    slab[(K * 3 + 0) * kBlock + lane] = V2{fv[0], fv[1]};
+    slab[(K * 3 + 1) * kBlock + lane] = V2{fv[2], tv[0]};
+    slab[(K * 3 + 2) * kBlock + lane] = V2{tv[1], tv[2]};
+  }
+  // called once before the backward sweep: without it the compiler forwards the stored values to the loads, i.e. keeps
+  // all 6 N of them in registers (and spills) - the very thing the slab is there to avoid
+  // (the slab's address is an operand so that the slab counts as escaped)
+  __device__ __forceinline__ void seal() const { asm volatile("" ::"v"(slab) : "memory"); }
+  template <int K>
+  __device__ __forceinline__ void get(ic<K>, T (&fv)[3], T (&tv)[3]) const {
+    const V2 a = slab[(K * 3 + 0) * kBlock + lane], b = slab[(K * 3 + 1) * kBlock + lane],
+             c = slab[(K * 3 + 2) * kBlock + lane];
+    fv[0] = a.x;
+    fv[1] = a.y;
+    fv[2] = b.x;
+    tv[0] = b.y;
+    tv[1] = c.x;
+    tv[2] = c.y;
+  }
+};
+
 template <class A, class T, int KM, bool USE_C, int FEAT>
 __global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
-  ABRK_ROW_INDEX
-  osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg);
+  if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
+    using V2 = typename LdsScratch<T, A::N>::V2;
+    __shared__ V2 slab[A::N * 3 * kBlock];
+    ABRK_ROW_INDEX
+    LdsScratch<T, A::N> scr{slab, (int)threadIdx.x};
+    osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+  } else {
+    ABRK_ROW_INDEX
+    osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg);
+  }
 }
 
 template <class A, class T>

@@ -5,8 +5,11 @@
 #pragma once
 #include "abrk_ctrl.h"
 
-namespace abrk {
+#ifndef ABRK_LATE_TARGET
+#define ABRK_LATE_TARGET 1
+#endif
 
+namespace abrk {
 
 template <class T>
 struct DynOutP {
@@ -137,10 +140,11 @@ ABRK_INL void dyn_body(long b, bool active, St& st, const A& arm, int frame, int
 }
 
 // ---- OSC.generate for B states (osc.py:217-320)
-template <class A, class T, int KM, bool USE_C, int FEAT>
+// `scr`: per-lane scratch of the Coriolis recursion (RegScratch, or the wavefront's LDS slab on the GPU)
+template <class A, class T, int KM, bool USE_C, int FEAT, class Scr>
 ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
-           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
+           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, Scr& scr) {
   constexpr int N = A::N;
   T q[N], dq[N], tgt[6], tv[6], ierr[6], une[N], u[N], ts[N];
   const bool tv_given = FEAT >= 2 && tvg != nullptr, have_ierr = FEAT >= 2 && ierrg != nullptr,
@@ -150,11 +154,14 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
   // kinematics to keep that kernel's register peak down.
   constexpr bool EARLY = FEAT < 2;
+  // (with the Coriolis recursion riding on the kinematics the target waits: its 12 registers are the difference
+  //  between fitting the two-wave budget and spilling)
+  constexpr bool EARLY_T = EARLY && !(USE_C && ABRK_LATE_TARGET);
   if constexpr (USE_C || EARLY) load_row<N>(dqg, b, dq);
-  if constexpr (EARLY) load_row<6>(tg, b, tgt);
+  if constexpr (EARLY_T) load_row<6>(tg, b, tgt);
   auto late = [&]() ABRK_LAMBDA {
     if constexpr (!USE_C && !EARLY) load_row<N>(dqg, b, dq);
-    if constexpr (!EARLY) load_row<6>(tg, b, tgt);
+    if constexpr (!EARLY_T) load_row<6>(tg, b, tgt);
     if (tv_given) load_row<6>(tvg, b, tv);
     else sfor<6>([&](auto r) ABRK_LAMBDA { tv[r()] = T(0); });
     if (have_ierr) load_row<6>(ierrg, b, ierr);
@@ -162,10 +169,17 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
     if (have_ext) load_row<N>(uneg, b, une);
     else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
   };
-  osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late);
+  osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr);
   store_row<N>(ug, b, u);
   if (tsg) store_row<N>(tsg, b, ts);
   if (have_ierr) store_row<6>(ierrg, b, ierr);
+}
+template <class A, class T, int KM, bool USE_C, int FEAT>
+ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+           const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
+           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
+  RegScratch<T, A::N> scr;
+  osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
 }
 
 // ---- OSC control law on caller-supplied dynamics (osc.py:244-318): for robot_configs whose
@@ -310,8 +324,9 @@ ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLink
   une[0] = une[1] = T(0);
   const int n_chk = every > 0 ? n_steps / every : 0;
   int chk = 0, until = every;
+  RegScratch<T, 2> scr;
   for (int t = 0; t < n_steps; t++) {
-    osc_row<A, T, KM, USE_C, 2>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {});
+    osc_row<A, T, KM, USE_C, 2>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {}, scr);
     twolink_step(K, q, dq, u);
     if (every > 0 && --until == 0) {
       until = every;
