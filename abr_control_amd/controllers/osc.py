@@ -149,14 +149,20 @@ class OSC(Controller):
         out = out.astype(np.float64)
         return out[0] if single else out
 
-    def generate(self, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None):
+    def generate(self, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None, return_dynamics=None):
         """Control signal(s) moving `ref_frame` to `target` (osc.py:217-320).
+
+        return_dynamics (extension): a subset of ("Tx", "J", "M", "g") -> returns (u, {name: array}) with the
+        robot_config outputs of `ref_frame` / `xyz_offset` that the law consumed, from the same kernel launch
+        (one forward kinematics instead of two; full precision, kernel dtype).
 
         q, dq: (n,) or (B, n); target: (6,) or (B, 6) [x,y,z,alpha,beta,gamma];
         target_velocity: None, (6,) or (B, 6).  Returns float64 (n,) or (B, n)
         (kernel dtype for a float32 config / DeviceArrays)."""
         rc = self.robot_config
         if not self._fused_config:
+            if return_dynamics:
+                raise TypeError("return_dynamics needs an abr_control_amd arm config (a foreign config's J/M/g are its own)")
             return self._generate_foreign(q, dq, target, target_velocity, ref_frame, xyz_offset)
         params = self._params(ref_frame, xyz_offset)
         (q2, dq2, t2, tv2), single = self._rows(q, dq, target, target_velocity)
@@ -189,16 +195,25 @@ class OSC(Controller):
                        else np.zeros((B, rc.N_JOINTS), rc.dtype))
             for nc in self._device:
                 nc._accumulate(q2, dq2, une)
-        u, ts = engine.osc_generate(rc.arm_id, rc.N_JOINTS, params, q2, dq2, t2, tv2, ie, une,
-                                    training_signal=True, dtype=rc.dtype, device=rc.device)
+        dyn = None
+        if return_dynamics:
+            u, ts, dyn = engine.osc_generate(rc.arm_id, rc.N_JOINTS, params, q2, dq2, t2, tv2, ie, une,
+                                             training_signal=True, dtype=rc.dtype, device=rc.device,
+                                             want=tuple(return_dynamics))
+        else:
+            u, ts = engine.osc_generate(rc.arm_id, rc.N_JOINTS, params, q2, dq2, t2, tv2, ie, une,
+                                        training_signal=True, dtype=rc.dtype, device=rc.device)
         if on_device:
             self.training_signal = ts
-            return u
+            return (u, dyn) if dyn is not None else u
         if self.ki != 0:
             self.integrated_error = ie[0] if single else ie
         if rc.reference_dtypes:
             u, ts = u.astype(np.float64), ts.astype(np.float64)
         self.training_signal = ts[0] if single else ts
+        if dyn is not None:
+            dyn = {k: (v[0] if single else v) for k, v in dyn.items()}
+            return (u[0] if single else u), dyn
         return u[0] if single else u
 
     def _generate_foreign(self, q, dq, target, target_velocity, ref_frame, xyz_offset):

@@ -719,10 +719,17 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
 // FEAT selects which optional inputs are compiled in: 0 = none (the plain law: ~70 registers fewer,
 // two waves per SIMD), 1 = fused secondary controllers only (Damping / RestingConfig, BASELINE config 3),
 // 2 = everything (target velocity, integral state, caller-evaluated null signal).
-template <class A, class T, int KM, bool USE_C, int FEAT, class Late, class Scr>
+struct NoEmit {
+  template <class... X>
+  ABRK_INL void operator()(X&&...) const {}
+};
+// `emit(p, Jv, Jw, Ms, gz)` sees the task point, its Jacobian columns, M (packed lower) and the gravity accumulators
+// the law is about to consume - the fused "u + robot_config outputs" kernel stores them from there (SURVEY 8d Mode F).
+template <class A, class T, int KM, bool USE_C, int FEAT, class Late, class Scr, class Emit = NoEmit>
 ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
                       bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
-                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late, Scr& scr) {
+                      const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late, Scr& scr,
+                      Emit&& emit = Emit{}) {
   constexpr int N = A::N;
   constexpr bool FAST = (KM <= 3);
   // OSC(use_C) on orthogonal chains (ABRK_C_TWO_PASS): the Coriolis vector rides on the dynamics pass.  The link
@@ -782,6 +789,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   // task Jacobian, rows masked (osc.py:242-244)
   T Jv[N][3], Jw[N][3];
   jacobian(jt, p, m, Jv, Jw);
+  emit(p, Jv, Jw, d.Ms, d.gz);
   ABRK_SCHED_FENCE();
   late();
   if constexpr (TWO_PASS)

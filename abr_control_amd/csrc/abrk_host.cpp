@@ -529,10 +529,35 @@ extern "C" int abrk_dynamics_batch(int arm_id, int dtype, int64_t B, const void*
 }
 
 // ------------------------------------------------------------------------------- OSC
+static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                             const void* dq, const void* target, const void* target_velocity,
+                             void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
+                             uint32_t want, const abrk_dyn_out* out, int device, void* stream);
+
 extern "C" int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
                                        const void* dq, const void* target, const void* target_velocity,
                                        void* integrated_error, const void* u_null_ext, void* u,
                                        void* training_signal, int device, void* stream) {
+  return osc_generate_impl(arm_id, dtype, P, B, q, dq, target, target_velocity, integrated_error, u_null_ext, u,
+                           training_signal, 0, nullptr, device, stream);
+}
+
+extern "C" int abrk_osc_generate_full_batch(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                                            const void* dq, const void* target, const void* target_velocity,
+                                            void* integrated_error, const void* u_null_ext, void* u,
+                                            void* training_signal, uint32_t want, const abrk_dyn_out* out, int device,
+                                            void* stream) {
+  const uint32_t ok = ABRK_WANT_TX | ABRK_WANT_J | ABRK_WANT_M | ABRK_WANT_G;
+  if (!want || (want & ~ok)) return fail(ABRK_EINVAL, "want must be a non-empty subset of Tx | J | M | g (0x%x)", want);
+  if (!out) return fail(ABRK_EINVAL, "out is NULL");
+  return osc_generate_impl(arm_id, dtype, P, B, q, dq, target, target_velocity, integrated_error, u_null_ext, u,
+                           training_signal, want, out, device, stream);
+}
+
+static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                             const void* dq, const void* target, const void* target_velocity,
+                             void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
+                             uint32_t want, const abrk_dyn_out* out, int device, void* stream) {
   ArmEntry* a;
   if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
   const int n = a->desc.n_joints;
@@ -550,6 +575,9 @@ extern "C" int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_par
   if (k == 0) return fail(ABRK_EINVAL, "ctrlr_dof selects no task-space dimension");
   if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
   if (P->ki != 0 && !integrated_error) return fail(ABRK_EINVAL, "ki != 0 needs the integrated_error state array");
+  void* const wout[4] = {out ? out->Tx : nullptr, out ? out->J : nullptr, out ? out->M : nullptr, out ? out->g : nullptr};
+  for (int i = 0; i < 4; i++)
+    if ((want >> i & 1) && !wout[i]) return fail(ABRK_EINVAL, "output %d requested but its pointer is NULL", i);
   if (B == 0) return 0;
   if (int rc = use_device(device)) return rc;
   const size_t s = esz(dtype);
@@ -563,8 +591,13 @@ extern "C" int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_par
   const void* une_ = st.add(u_null_ext, B * n * s, true, false);
   void* u_ = st.add(u, B * n * s, false, true);
   void* ts_ = st.add(training_signal, B * n * s, false, true);
+  const size_t per[4] = {3, (size_t)6 * n, (size_t)n * n, (size_t)n};
+  void* o_[4];
+  for (int i = 0; i < 4; i++) o_[i] = (want >> i & 1) ? st.add(wout[i], B * per[i] * s, false, true) : nullptr;
   if (int rc = st.reserve()) return rc;
   OscArgs oa;
+  oa.want = want;
+  for (int i = 0; i < 4; i++) oa.out[i] = (want >> i & 1) ? st.fix(o_[i], wout[i]) : nullptr;
   oa.q = st.fix(q_, q);
   oa.dq = st.fix(dq_, dq);
   oa.target = st.fix(t_, target);
@@ -584,6 +617,149 @@ extern "C" int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_par
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
     return ops->osc(dtype, LaunchArgs{rt, (long)B, hs}, o);
   });
+}
+
+// ------------------------------------------------------------------------------- OSC over several devices
+// One call, host arrays, all the devices the caller names: the batch is cut into contiguous row shards
+// (sizes differing by at most one row; BASELINE config 4: 2^20 rows over 8 GPUs), each shard staged to its device's scratch
+// arena, evaluated by the same kernel on that device's own stream, and copied back.  Rows are independent: there is no
+// exchange step and therefore no collective.  All kernels are in flight before the first result is waited for, so
+// the devices overlap; the staging copies themselves run on the calling thread (pageable host memory), which is
+// what bounds this entry point - callers that keep their shards resident use one abrk_osc_generate_batch / plan per
+// device instead (bench.py --gpus N: one process per GPU).
+namespace {
+struct ShardCtx {
+  hipStream_t stream = nullptr;
+  char* base = nullptr;
+  size_t cap = 0;
+};
+std::mutex g_shard_mu;
+// (device, slot on that device) -> context; heap-allocated: the pointers handed out stay valid as the table grows
+std::vector<std::pair<std::pair<int, int>, std::unique_ptr<ShardCtx>>> g_shard_ctx;
+
+ShardCtx* shard_ctx(int device, int slot, size_t need) {
+  ShardCtx* c = nullptr;
+  for (auto& e : g_shard_ctx)
+    if (e.first.first == device && e.first.second == slot) c = e.second.get();
+  if (!c) {
+    g_shard_ctx.emplace_back(std::make_pair(device, slot), std::unique_ptr<ShardCtx>(new ShardCtx));
+    c = g_shard_ctx.back().second.get();
+  }
+  if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (c->cap < need) {
+    if (c->base) (void)hipFree(c->base);
+    c->base = nullptr;
+    c->cap = 0;
+    const size_t cap = need + need / 4;
+    if (hipMalloc((void**)&c->base, cap) != hipSuccess) return nullptr;
+    c->cap = cap;
+  }
+  return c;
+}
+}  // namespace
+
+extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                                         const void* dq, const void* target, const void* target_velocity,
+                                         void* integrated_error, const void* u_null_ext, void* u,
+                                         void* training_signal, int n_shards, const int* devices) {
+  if (n_shards < 1 || !devices) return fail(ABRK_EINVAL, "n_shards must be >= 1 and devices non-NULL");
+  if (recording()) return fail(ABRK_EINVAL, "the sharded entry point cannot be recorded into a plan");
+  // argument checks of the single-device entry point (B = 0 returns right after them)
+  if (int rc = osc_generate_impl(arm_id, dtype, P, 0, q, dq, target, target_velocity, integrated_error, u_null_ext, u,
+                                 training_signal, 0, nullptr, devices[0], nullptr))
+    return rc;
+  if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
+  if (B == 0) return 0;
+  const void* all[] = {q, dq, target, target_velocity, integrated_error, u_null_ext, u, training_signal};
+  for (const void* p : all)
+    if (p && device_view(p) == p)
+      return fail(ABRK_EINVAL, "the sharded entry point takes host arrays (a device pointer lives on one device)");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(ABRK_ENODEV, "no HIP device available; libabrk has no CPU fallback");
+  }
+  for (int g = 0; g < n_shards; g++)
+    if (devices[g] < 0 || devices[g] >= ndev) return fail(ABRK_EINVAL, "device %d outside 0..%d", devices[g], ndev - 1);
+  ArmEntry* a = get_arm(arm_id);
+  const int n = a->desc.n_joints;
+  const size_t s = esz(dtype);
+  void* ie = (P->ki != 0) ? integrated_error : nullptr;
+  const OscP<double> p64 = make_oscp<double>(*P, n);
+  const OscP<float> p32 = make_oscp<float>(*P, n);
+  struct Piece {
+    const void* host_in;
+    void* host_out;
+    size_t per_row;  // bytes
+  };
+  const Piece pieces[8] = {{q, nullptr, n * s},           {dq, nullptr, n * s},        {target, nullptr, 6 * s},
+                           {target_velocity, nullptr, 6 * s}, {ie, ie, 6 * s},          {u_null_ext, nullptr, n * s},
+                           {nullptr, u, n * s},           {nullptr, training_signal, n * s}};
+  std::lock_guard<std::mutex> lk(g_shard_mu);
+  struct Shard {
+    ShardCtx* c;
+    int device;
+    int64_t r0, rows;
+    char* dev[8];
+  };
+  std::vector<Shard> shards;
+  std::vector<int> per_dev(ndev, 0);
+  for (int g = 0; g < n_shards; g++) {
+    // sizes differ by at most one row (abr_control_amd/sharding.py shard_range)
+    const int64_t base = B / n_shards, extra = B % n_shards;
+    const int64_t r0 = g * base + (g < extra ? g : extra), r1 = r0 + base + (g < extra ? 1 : 0);
+    if (r1 == r0) continue;
+    Shard sh{};
+    sh.device = devices[g];
+    sh.r0 = r0;
+    sh.rows = r1 - r0;
+    size_t need = 0;
+    for (const Piece& pc : pieces)
+      if (pc.host_in || pc.host_out) need += (sh.rows * pc.per_row + 255) & ~size_t(255);
+    HIPCHK(hipSetDevice(sh.device));
+    t_current_device = sh.device;
+    sh.c = shard_ctx(sh.device, per_dev[sh.device]++, need);
+    if (!sh.c) {
+      (void)hipGetLastError();
+      return fail(ABRK_ENOMEM, "shard %d: stream / %zu bytes of scratch on device %d", g, need, sh.device);
+    }
+    size_t off = 0;
+    for (int k = 0; k < 8; k++) {
+      const Piece& pc = pieces[k];
+      sh.dev[k] = nullptr;
+      if (!pc.host_in && !pc.host_out) continue;
+      sh.dev[k] = sh.c->base + off;
+      off += (sh.rows * pc.per_row + 255) & ~size_t(255);
+      if (pc.host_in)
+        HIPCHK(hipMemcpyAsync(sh.dev[k], (const char*)pc.host_in + r0 * pc.per_row, sh.rows * pc.per_row,
+                              hipMemcpyHostToDevice, sh.c->stream));
+    }
+    OscArgs oa;
+    oa.q = sh.dev[0];
+    oa.dq = sh.dev[1];
+    oa.target = sh.dev[2];
+    oa.tv = sh.dev[3];
+    oa.ierr = sh.dev[4];
+    oa.une = sh.dev[5];
+    oa.u = sh.dev[6];
+    oa.ts = sh.dev[7];
+    oa.use_C = P->use_C ? 1 : 0;
+    oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
+    oa.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    HIPCHK(a->ops->osc(dtype, LaunchArgs{arm_table(a, dtype), (long)sh.rows, sh.c->stream}, oa));
+    shards.push_back(sh);
+  }
+  // every kernel is enqueued; now collect (a device-to-host copy into pageable memory waits for its shard)
+  for (Shard& sh : shards) {
+    HIPCHK(hipSetDevice(sh.device));
+    t_current_device = sh.device;
+    for (int k = 0; k < 8; k++)
+      if (pieces[k].host_out && sh.dev[k])
+        HIPCHK(hipMemcpyAsync((char*)pieces[k].host_out + sh.r0 * pieces[k].per_row, sh.dev[k],
+                              sh.rows * pieces[k].per_row, hipMemcpyDeviceToHost, sh.c->stream));
+    HIPCHK(hipStreamSynchronize(sh.c->stream));
+  }
+  return 0;
 }
 
 // ------------------------------------------------------------------------------- Sliding

@@ -135,6 +135,29 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
   }
 }
 
+// Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
+// cooperative stores and (use_C) the scratch of the Coriolis recursion, which is dead by the time the first row is
+// parked.  FEAT is 0 (the plain law) or 2 (every optional input).
+template <class A, class T, int KM, bool USE_C, int FEAT>
+__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
+osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
+                const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
+                const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, unsigned want, DynOutP<T> out) {
+  __shared__ __attribute__((aligned(16))) T slab[kBlock * max_row(A::N)];
+  static_assert(max_row(A::N) >= 6 * A::N, "the slab also holds the 6 N scratch values of the Coriolis recursion");
+  const long row0 = (long)blockIdx.x * kBlock;
+  const long b = row0 + threadIdx.x;
+  LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
+  if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
+    using V2 = typename LdsScratch<T, A::N>::V2;
+    LdsScratch<T, A::N> scr{reinterpret_cast<V2*>(slab), (int)threadIdx.x};
+    osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
+  } else {
+    RegScratch<T, A::N> scr;
+    osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
+  }
+}
+
 template <class A, class T>
 __global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 sliding_kernel(A arm, SlidingP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
@@ -298,6 +321,8 @@ struct OscArgs {
   int fast, use_C;  // fast: 0 general six-row kernel, 2 / 3: first two / three position rows of the EE
   const void *q, *dq, *target, *tv, *une;
   void *ierr, *u, *ts;
+  unsigned want = 0;  // != 0: the fused Mode-F kernel also writes Tx / J / M / g (W_TX | W_J | W_M | W_G)
+  void* out[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 struct SlidingArgs {
   const void* P;  // SlidingP<T>
@@ -357,7 +382,36 @@ struct Launch {
     else if (nulls) osc_launch<KM, UC, 1>(la, a);
     else osc_launch<KM, UC, 0>(la, a);
   }
+  template <int KM, bool UC, int FEAT>
+  static void osc_full_launch(const LaunchArgs& la, const OscArgs& a) {
+    DynOutP<T> o{};
+    o.Tx = (T*)a.out[0];
+    o.J = (T*)a.out[1];
+    o.M = (T*)a.out[2];
+    o.g = (T*)a.out[3];
+    hipLaunchKernelGGL((osc_full_kernel<A, T, KM, UC, FEAT>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
+                       *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
+                       (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, a.want, o);
+  }
+  template <int KM, bool UC>
+  static void osc_full_feat(const LaunchArgs& la, const OscArgs& a) {
+    const bool plain = !(a.tv || a.ierr || a.une) && static_cast<const OscP<T>*>(a.P)->n_null == 0;
+    if (plain) osc_full_launch<KM, UC, 0>(la, a);
+    else osc_full_launch<KM, UC, 2>(la, a);
+  }
+  static hipError_t osc_full(const LaunchArgs& la, const OscArgs& a) {
+    // the two-row kernel of the planar examples is not duplicated: x,y control of a small arm takes the six-row form
+    if (a.fast == 3) {
+      if (a.use_C) osc_full_feat<3, true>(la, a);
+      else osc_full_feat<3, false>(la, a);
+    } else {
+      if (a.use_C) osc_full_feat<6, true>(la, a);
+      else osc_full_feat<6, false>(la, a);
+    }
+    return hipGetLastError();
+  }
   static hipError_t osc(const LaunchArgs& la, const OscArgs& a) {
+    if (a.want) return osc_full(la, a);
     if (a.fast == 3) {
       if (a.use_C) osc_launch_feat<3, true>(la, a);
       else osc_launch_feat<3, false>(la, a);

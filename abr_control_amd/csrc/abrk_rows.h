@@ -182,6 +182,64 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
 }
 
+// ---- OSC.generate + the robot_config outputs it consumed, one launch (SURVEY 8d "Mode F"): u [B,n] and, per `want`,
+// Tx [B,3], J [B,6,n], M [B,n,n], g [B,n] of the controller's ref_frame / xyz_offset - what a caller of
+// robot_config.J/M/g/Tx next to ctrlr.generate (osc.py:242-301 consumers, training-signal users) would otherwise
+// pay a second forward kinematics for.  Cooperative stores (St = LdsStore on the GPU): padding lanes of the last
+// wavefront evaluate a clamped row and only take part in the stores.
+template <class A, class T, int KM, bool USE_C, int FEAT, class Scr, class St>
+ABRK_INL void osc_full_body(long b, bool active, St& st, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg,
+                            const T* __restrict__ dqg, const T* __restrict__ tg, const T* __restrict__ tvg,
+                            T* __restrict__ ierrg, const T* __restrict__ uneg, T* __restrict__ ug,
+                            T* __restrict__ tsg, unsigned want, const DynOutP<T>& out, Scr& scr) {
+  constexpr int N = A::N;
+  const long bl = active ? b : B - 1;
+  T q[N], dq[N], tgt[6], tv[6], ierr[6], une[N], u[N], ts[N];
+  const bool tv_given = FEAT >= 2 && tvg != nullptr, have_ierr = FEAT >= 2 && ierrg != nullptr,
+             have_ext = FEAT >= 2 && uneg != nullptr;
+  load_row<N>(qg, bl, q);
+  load_row<N>(dqg, bl, dq);
+  auto late = [&]() ABRK_LAMBDA {
+    load_row<6>(tg, bl, tgt);
+    if (tv_given) load_row<6>(tvg, bl, tv);
+    else sfor<6>([&](auto r) ABRK_LAMBDA { tv[r()] = T(0); });
+    if (have_ierr) load_row<6>(ierrg, bl, ierr);
+    else sfor<6>([&](auto r) ABRK_LAMBDA { ierr[r()] = T(0); });
+    if (have_ext) load_row<N>(uneg, bl, une);
+    else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
+  };
+  auto emit = [&](const T(&p)[3], const T(&Jv)[N][3], const T(&Jw)[N][3], const T(&Ms)[N * (N + 1) / 2],
+                  const T(&gz)[N]) ABRK_LAMBDA {
+    if (want & W_TX) st.template put<3>(out.Tx, b, active, p);
+    if (want & W_J) {
+      T row[6 * N];
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          row[r() * N + i()] = Jv[i()][r()];
+          row[(3 + r()) * N + i()] = Jw[i()][r()];
+        });
+      });
+      st.template put<6 * N>(out.J, b, active, row);
+    }
+    if (want & W_M) {
+      T row[N * N];
+      sfor<N>([&](auto i) ABRK_LAMBDA { sfor<N>([&](auto j) ABRK_LAMBDA { row[i() * N + j()] = Ms[tri(i(), j())]; }); });
+      st.template put<N * N>(out.M, b, active, row);
+    }
+    if (want & W_G) {
+      T row[N];
+      sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = T(-9.81) * gz[i()]; });
+      st.template put<N>(out.g, b, active, row);
+    }
+  };
+  osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr, emit);
+  if (active) {
+    store_row<N>(ug, b, u);
+    if (tsg) store_row<N>(tsg, b, ts);
+    if (have_ierr) store_row<6>(ierrg, b, ierr);
+  }
+}
+
 // ---- OSC control law on caller-supplied dynamics (osc.py:244-318): for robot_configs whose
 // J / M / g / Tx / R come from elsewhere (the reference's duck-typed boundary, e.g. MujocoConfig,
 // abr_control/arms/mujoco_config.py:201-451).  Inputs per row, row-major: J [6,N], M [N,N];

@@ -1,7 +1,7 @@
 // abrk_rt.h - user (runtime-table) arms: table construction on the host and the per-N
 // kernel instantiations.  Each abrk_arm_rt<N>.hip defines ABRK_RT_N and includes this.
 #pragma once
-#include "../../include/abrk.h"
+#include "../../include/abrk_types.h"
 #include "abrk_kernels.h"
 
 namespace abrk {

@@ -114,9 +114,13 @@ def dynamics(arm_id, n, q, dq=None, frame=None, x_off=None, want=("M",), dtype=n
 
 
 def osc_generate(arm_id, n, params, q, dq, target, target_velocity=None, integrated_error=None,
-                 u_null_ext=None, u=None, training_signal=False, dtype=np.float64, device=0, stream=None):
+                 u_null_ext=None, u=None, training_signal=False, dtype=np.float64, device=0, stream=None,
+                 want=None, out=None):
     """OSC.generate for a batch.  `integrated_error` ([B,6]) is updated in place when ki != 0.
-    Returns u, or (u, training_signal) when training_signal is True / an output array."""
+    Returns u, or (u, training_signal) when training_signal is True / an output array.
+    want: subset of ("Tx", "J", "M", "g") -> the fused kernel (abrk_osc_generate_full_batch) also writes those
+    robot_config outputs of the controller's ref_frame / xyz_offset; the return value gains a dict of them
+    (`out`: optional dict of preallocated arrays)."""
     a = _Args(dtype)
     B = q.shape[0]
     qp = a.inp(q, (B, n), "q")
@@ -138,8 +142,51 @@ def osc_generate(arm_id, n, params, q, dq, target, target_velocity=None, integra
     tsp, tso = None, None
     if training_signal is not False and training_signal is not None:
         tsp, tso = a.out(None if training_signal is True else training_signal, (B, n), device, "training_signal")
+    if want:
+        bits, do, res = 0, _abi.DynOut(), {}
+        for name in want:
+            if name not in ("Tx", "J", "M", "g"):
+                raise ValueError(f"the fused kernel offers Tx, J, M, g - not {name!r}")
+            bits |= _WANT_BITS[name]
+            ptr, obj = a.out(None if out is None else out.get(name), (B,) + _OUT_SHAPES[name](n), device, name)
+            setattr(do, name, ptr)
+            res[name] = obj
+        check(lib().abrk_osc_generate_full_batch(arm_id, a.code, C.byref(params), B, qp, dqp, tp, tvp, iep, unp, up,
+                                                 tsp, bits, C.byref(do), device, _sp(stream)))
+        return (uo, tso, res) if tso is not None else (uo, res)
     check(lib().abrk_osc_generate_batch(arm_id, a.code, C.byref(params), B, qp, dqp, tp, tvp, iep, unp, up, tsp,
                                         device, _sp(stream)))
+    return (uo, tso) if tso is not None else uo
+
+
+def osc_generate_sharded(arm_id, n, params, q, dq, target, devices, target_velocity=None, integrated_error=None,
+                         u_null_ext=None, u=None, training_signal=False, dtype=np.float64):
+    """OSC.generate of ONE host batch over several devices (abrk_osc_generate_sharded): contiguous row shards, shard g
+    on devices[g], no collective.  NumPy arrays only.  Returns u or (u, training_signal)."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    for name, arr in (("q", q), ("dq", dq), ("target", target), ("target_velocity", target_velocity),
+                      ("u_null_ext", u_null_ext), ("u", u)):
+        if isinstance(arr, DeviceArray):
+            raise TypeError(f"{name}: the sharded call takes NumPy arrays (a DeviceArray lives on one device)")
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq")
+    tp = a.inp(target, (B, 6), "target")
+    tvp = a.inp(target_velocity, (B, 6), "target_velocity")
+    unp = a.inp(u_null_ext, (B, n), "u_null_ext")
+    iep = None
+    if integrated_error is not None:
+        if (not isinstance(integrated_error, np.ndarray) or integrated_error.dtype != a.np_dtype
+                or integrated_error.shape != (B, 6) or not integrated_error.flags.c_contiguous):
+            raise ValueError("integrated_error must be a C-contiguous ndarray [B,6] of the call dtype")
+        iep = integrated_error.ctypes.data
+    up, uo = a.out(u, (B, n), 0, "u")
+    tsp, tso = None, None
+    if training_signal is not False and training_signal is not None:
+        tsp, tso = a.out(None if training_signal is True else training_signal, (B, n), 0, "training_signal")
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    check(lib().abrk_osc_generate_sharded(arm_id, a.code, C.byref(params), B, qp, dqp, tp, tvp, iep, unp, up, tsp,
+                                          len(devices), devs))
     return (uo, tso) if tso is not None else uo
 
 

@@ -24,3 +24,49 @@ def shard_rows(arrays, rank, world):
     B = next(a.shape[0] for a in arrays if a is not None)
     lo, hi = shard_range(B, rank, world)
     return [None if a is None else a[lo:hi] for a in arrays]
+
+
+class MultiDevice:
+    """All (or the named) devices of this process behind one call: `generate(ctrlr, q, dq, target)` cuts the host
+    batch into contiguous row shards, evaluates shard g on devices[g] (each on a stream of its own, every kernel in
+    flight before the first result is collected) and returns the reassembled NumPy result - BASELINE config 4
+    ("2^20 rows sharded across 8 GPUs") as one call.  No collective: rows are independent.  A device may be named
+    several times (more shards than devices; how the one-GPU tests exercise the path).
+
+        md = MultiDevice()                  # every visible device
+        u = md.generate(ctrlr, Q, dQ, targets)
+
+    `ctrlr`: an abr_control_amd OSC whose secondary controllers are the fused ones (Damping / RestingConfig)."""
+
+    def __init__(self, devices=None):
+        import abr_control_amd as a
+
+        n = a.device_count()
+        if n < 1:
+            raise RuntimeError("MultiDevice needs a HIP device: abr_control_amd has no CPU fallback")
+        self.devices = list(range(n)) if devices is None else [int(d) for d in devices]
+        if not self.devices or any(d < 0 or d >= n for d in self.devices):
+            raise ValueError(f"devices {self.devices} outside 0..{n - 1}")
+
+    def generate(self, ctrlr, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None):
+        import numpy as np
+
+        from . import engine
+
+        rc = ctrlr.robot_config
+        if not getattr(ctrlr, "_fused_config", False) or ctrlr._foreign or ctrlr._device:
+            raise TypeError("MultiDevice.generate needs an abr_control_amd OSC with fused null controllers only")
+        (q2, dq2, t2, tv2), single = ctrlr._rows(q, dq, target, target_velocity)
+        B = q2.shape[0]
+        ie = None
+        if ctrlr.ki != 0:
+            ie = np.asarray(ctrlr.integrated_error, dtype=rc.dtype)
+            ie = np.ascontiguousarray(ie if ie.shape == (B, 6) else np.zeros((B, 6), rc.dtype))
+        u, ts = engine.osc_generate_sharded(rc.arm_id, rc.N_JOINTS, ctrlr._params(ref_frame, xyz_offset), q2, dq2, t2,
+                                            self.devices, tv2, ie, training_signal=True, dtype=rc.dtype)
+        if ctrlr.ki != 0:
+            ctrlr.integrated_error = ie[0] if single else ie
+        if rc.reference_dtypes:
+            u, ts = u.astype(np.float64), ts.astype(np.float64)
+        ctrlr.training_signal = ts[0] if single else ts
+        return u[0] if single else u

@@ -41,6 +41,9 @@ WORKLOADS = {
     # not a BASELINE config: the batched robot_config surface (Tx, J, M, g in one launch) - the
     # HBM-bound "full outputs" mode of SURVEY.md 8d
     "dynF": ("ur5", 4096, "f64", "dyn", dict(want=("Tx", "J", "M", "g")), 2500),
+    # SURVEY 8d "Mode F": the control signal AND the robot_config outputs it consumed (Tx, J, M, g of the EE) from ONE
+    # launch of the fused kernel (abrk_osc_generate_full_batch) - 192 + 648 = 840 B per row, HBM-bound
+    "oscF": ("ur5", 4096, "f64", "osc_full", dict(kp=200), 3500),
     # SURVEY 8f-1 (first "next" row): the examples' closed loop on the device - OSC.generate followed by the
     # two-link plant step (arms/twojoint/arm_sim.py:101-137), `rollout_steps` control steps per launch
     "rollout": ("twojoint", 4096, "f64", "rollout", dict(kp=20, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 0]), 600),
@@ -63,6 +66,8 @@ def algorithmic_bytes(n, esz, kind):
     Full-output dynamics: read q [n], write Tx[3] + J[6,n] + M[n,n] + g[n]."""
     if kind == "dyn":
         return esz * n + esz * (3 + 6 * n + n * n + n)
+    if kind == "osc_full":  # Mode U (q, dq, target in; u out) + Tx, J, M, g out
+        return esz * (2 * n + 6) + esz * n + esz * (3 + 6 * n + n * n + n)
     if kind == "ik":  # per launch and row: q, target in; position + velocity paths out
         return esz * (n + 6) + esz * 2 * 200 * n
     if kind == "rollout":  # per launch and row: q, dq in/out + target; amortised over ROLLOUT_STEPS
@@ -123,11 +128,13 @@ class Runner:
             self.q = a.DeviceArray.from_numpy(q0, device)
             self.dq = a.DeviceArray.from_numpy(np.zeros((B, 2), self.dt), device)
             self.t = a.DeviceArray.from_numpy(t6, device)
-        elif kind == "dyn":
+        elif kind in ("dyn", "osc_full"):
             n = self.n
             shapes = {"Tx": (3,), "J": (6, n), "M": (n, n), "g": (n,)}
-            self.want = kw["want"]
+            self.want = kw.get("want", ("Tx", "J", "M", "g"))
             self.dyn_out = {w: a.DeviceArray((B,) + shapes[w], self.dt, device) for w in self.want}
+            if kind == "osc_full":
+                self.params = _abi.make_osc_params(self.n, **kw)
         elif kind == "sliding":
             self.params = _abi.make_sliding_params(self.n)
         elif kind == "limits":
@@ -147,13 +154,12 @@ class Runner:
         # (abrk_plan_launch_graph; same kernel, same buffers, one node per step).  ABRK_BENCH_GRAPH=0: one
         # hipLaunchKernel per step (4.55 instead of 4.06 us per step at B = 4096)
         self.graph_steps = int(os.environ.get("ABRK_BENCH_GRAPH", "100"))
-        if kind in ("osc", "osc_damp"):
-            # the per-tick launch of a control loop on fixed device buffers: arguments validated once
-            self.plan = engine.OscPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
-                                       dtype=self.dt, device=device, stream=stream)
-        elif kind == "sliding":
-            self.plan = engine.SlidingPlan(self.arm_id, self.n, self.params, self.q, self.dq, self.t, self.u,
-                                           dtype=self.dt, device=device, stream=stream)
+        if kind not in ("rollout", "ik"):
+            # the per-tick launch of a control loop on fixed device buffers: the call is recorded once (arguments
+            # validated and converted, abrk_plan_begin/end); a step then only enqueues the kernel.  (The rollout and
+            # the IK paths already run hundreds of iterations per launch.)
+            with engine.Plan(device, stream) as self.plan:
+                self._enqueue()
         if kind != "rollout":
             # one untimed launch at construction: the first launch of a kernel loads its code object (milliseconds) -
             # initialisation, not a step, whatever --warmup says (the rollout advances its state in place: left alone)
@@ -175,6 +181,8 @@ class Runner:
             return f"osc_kernel<{arm}, {t}, {3 if fast else 6}, {b(p.use_C)}, {1 if p.n_null else 0}>"
         if k == "dyn":
             return f"dyn_kernel<{arm}, {t}, false>"
+        if k == "osc_full":
+            return f"osc_full_kernel<{arm}, {t}, 3, {'true' if self.params.use_C else 'false'}, 0>"
         if k == "limits":
             return f"limits_kernel<{self.n}, {t}>"
         if k == "rollout":
@@ -182,12 +190,20 @@ class Runner:
         return f"{k}_kernel<{arm}, {t}>"
 
     def step(self):
+        if self.plan is not None:
+            self.plan.launch()
+        else:
+            self._enqueue()
+
+    def _enqueue(self):
         if self.kind == "ik":
             self.engine.ik_generate_path(self.arm_id, self.n, self.params, self.q, self.t, dtype=self.dt,
                                          device=self.device, stream=self.stream, position_path=self.ik_out[0],
                                          velocity_path=self.ik_out[1])
-        elif self.plan is not None:
-            self.plan.launch()
+        elif self.kind == "osc_full":
+            self.engine.osc_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
+                                     dtype=self.dt, device=self.device, stream=self.stream, want=self.want,
+                                     out=self.dyn_out)
         elif self.kind == "rollout":
             self.engine.osc_rollout_twolink(self.arm_id, self.params, self.plant, self.q, self.dq, self.t,
                                             ROLLOUT_STEPS, dtype=self.dt, device=self.device, stream=self.stream)
@@ -407,6 +423,9 @@ def cpu_baseline(workload, budget_s=12.0):
     elif kind == "obstacles":
         p = _abi.make_obstacles_params(**kw)
         fn = lambda: o.avoid_obstacles_batch(p, q)
+    elif kind == "osc_full":
+        p = _abi.make_osc_params(o.n, **kw)
+        fn = lambda: (o.osc_batch(p, q, dq, t), [(o.Tx("EE", q[i]), o.J("EE", q[i]), o.M(q[i]), o.g(q[i])) for i in range(Bs)])
     else:
         nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
         p = _abi.make_osc_params(o.n, null_controllers=nulls, **kw)
@@ -539,9 +558,10 @@ def main():
         out["roofline"] = out["roofline_config"]
     if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg:
         # the HBM-bound mode of the same path: every robot_config output of a row (Tx, J, M, g) in one launch
-        full = Runner("dynF", args.roofline_batch // 2, device, stream)
+        full = Runner("oscF", args.roofline_batch // 2, device, stream)
         _, ms_full = full.timed(args.roofline_steps, ROOFLINE_WARMUP)
-        out["roofline_full_outputs"] = roofline(full, ms_full, f"dynF batch={full.B}: Tx,J,M,g per row, 696 B/row")
+        out["roofline_full_outputs"] = roofline(full, ms_full, f"oscF batch={full.B}: u + Tx,J,M,g per row from one "
+                                                               f"launch of the fused kernel, 840 B/row")
         del full
     if rank == 0 and args.also:
         out["also"] = {}

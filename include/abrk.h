@@ -35,54 +35,11 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "abrk_types.h" /* ABRK_VERSION, limits, dtype / error codes, abrk_arm_desc */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
-
-#define ABRK_VERSION 100
-#define ABRK_MAX_JOINTS 7
-#define ABRK_MAX_NULL 4
-
-enum { ABRK_F64 = 0, ABRK_F32 = 1 };
-
-enum {
-  ABRK_OK = 0,
-  ABRK_EINVAL = -1,   /* bad argument (shape, id, dtype, unsupported combination)      */
-  ABRK_ENODEV = -2,   /* no HIP device / HIP runtime error                              */
-  ABRK_ENOMEM = -3,   /* device allocation failed                                       */
-  ABRK_ENOARM = -4,   /* unknown arm id / name                                          */
-  ABRK_EFRAME = -5    /* invalid frame id ("Invalid transformation name", ur5/config.py:337) */
-};
-
-/* ---------------------------------------------------------------------------------
- * Arm description = the constant table a reference `Config.__init__` + `_calc_T`
- * encode symbolically (abr_control/arms/ur5/config.py:35-339, jaco2/config.py:35-356,
- * twojoint/config.py:30-181, threejoint/config.py:32-223, onejoint/config.py:30-133).
- *
- *   T(link0)     = A0
- *   T(joint_i)   = T(link_i) * AJ[i]
- *   T(link_i+1)  = T(joint_i) * Rz(q_i) * B[i]          (all joints revolute about local z)
- *   T(EE)        = T(link_n) * E   if has_ee else T(link_n)
- *
- * Each static transform is a 3x4 row-major affine [R | t] (bottom row 0 0 0 1 implied);
- * R need not be exactly orthogonal (Jaco2's 8-digit constants are not) - the kernels
- * differentiate the affine chain exactly.
- * mdiag[l] = diagonal of the reference's 6x6 `_M_LINKS[l]` (m,m,m,Ixx,Iyy,Izz), applied
- * in the WORLD frame exactly as base_config.py:628 does.  Only links l < n_links_dyn
- * (= the reference's N_LINKS) enter M, g and C (base_config.py:449,626).
- * --------------------------------------------------------------------------------- */
-typedef struct abrk_arm_desc {
-  int32_t n_joints;
-  int32_t n_links_dyn;
-  int32_t has_ee;
-  int32_t reserved;
-  double A0[12];
-  double AJ[ABRK_MAX_JOINTS][12];
-  double B[ABRK_MAX_JOINTS][12];
-  double E[12];
-  double mdiag[ABRK_MAX_JOINTS + 1][6];
-  char name[32];
-} abrk_arm_desc;
 
 /* Built-in arms ("ur5", "jaco2", "twojoint", "threejoint", "onejoint"): compile-time
  * specialised kernels.  Returns an arm id >= 0 or ABRK_ENOARM.                        */
@@ -187,6 +144,31 @@ int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_params* params
                             const void* target_velocity, void* integrated_error,
                             const void* u_null_ext, void* u, void* training_signal,
                             int device, void* stream);
+
+/* OSC.generate AND the robot_config outputs it consumed, in one launch (one forward kinematics): besides u, any of
+ *   Tx [B,3] = robot_config.Tx(ref_frame, q, x=xyz_offset)   (base_config.py:371-392)
+ *   J  [B,6,n] = robot_config.J(ref_frame, q, x=xyz_offset)  (:249-270)
+ *   M  [B,n,n] = robot_config.M(q)                            (:272-285)
+ *   g  [B,n]   = robot_config.g(q)                            (:210-223)
+ * selected by `want` (ABRK_WANT_TX | ABRK_WANT_J | ABRK_WANT_M | ABRK_WANT_G; the other fields of `out` are
+ * ignored), in the kernel's arithmetic type.  For callers that read those next to ctrlr.generate - adaptive terms on
+ * training_signal, logging, a second controller on the same state (the consumers of osc.py:242-301) - and would
+ * otherwise evaluate the kinematics twice.  840 B of algorithmic traffic per UR5 row in fp64: the HBM-bound form of
+ * the path (SURVEY.md 8d "Mode F").  Everything else as abrk_osc_generate_batch.                              */
+int abrk_osc_generate_full_batch(int arm_id, int dtype, const abrk_osc_params* params, int64_t B,
+                                 const void* q, const void* dq, const void* target,
+                                 const void* target_velocity, void* integrated_error,
+                                 const void* u_null_ext, void* u, void* training_signal, uint32_t want,
+                                 const abrk_dyn_out* out, int device, void* stream);
+
+/* The same call over SEVERAL devices (BASELINE config 4: 2^20 rows over the 8 GPUs of a node): host arrays in, host
+ * arrays out; the batch is cut into n_shards contiguous row ranges (sizes differing by at most one row), shard g is
+ * evaluated on devices[g] (a device may appear more than once), each on a stream of its own, all kernels in flight before the first result is collected.  Rows are
+ * independent: no exchange step, no collective.  Per-row state (integrated_error) stays with its shard.            */
+int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_params* params, int64_t B, const void* q,
+                              const void* dq, const void* target, const void* target_velocity,
+                              void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
+                              int n_shards, const int* devices);
 
 /* The same control law (osc.py:244-318) on CALLER-SUPPLIED dynamics: keeps `OSC(robot_config=<any duck
  * type>)` working for configs whose arithmetic lives elsewhere (the reference's MujocoConfig,

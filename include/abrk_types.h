@@ -1,0 +1,56 @@
+/*
+ * abrk_types.h - constants and the arm description of the libabrk C ABI (see abrk.h, which includes this file).
+ * Kept apart so that the runtime-table kernels (abr_control_amd/csrc/abrk_rt.h), which only need the arm
+ * description, do not depend on the list of entry points.
+ */
+#ifndef ABRK_TYPES_H
+#define ABRK_TYPES_H
+
+#include <stdint.h>
+
+#define ABRK_VERSION 100
+#define ABRK_MAX_JOINTS 7
+#define ABRK_MAX_NULL 4
+
+enum { ABRK_F64 = 0, ABRK_F32 = 1 };
+
+enum {
+  ABRK_OK = 0,
+  ABRK_EINVAL = -1,   /* bad argument (shape, id, dtype, unsupported combination)      */
+  ABRK_ENODEV = -2,   /* no HIP device / HIP runtime error                              */
+  ABRK_ENOMEM = -3,   /* device allocation failed                                       */
+  ABRK_ENOARM = -4,   /* unknown arm id / name                                          */
+  ABRK_EFRAME = -5    /* invalid frame id ("Invalid transformation name", ur5/config.py:337) */
+};
+
+/* ---------------------------------------------------------------------------------
+ * Arm description = the constant table a reference `Config.__init__` + `_calc_T`
+ * encode symbolically (abr_control/arms/ur5/config.py:35-339, jaco2/config.py:35-356,
+ * twojoint/config.py:30-181, threejoint/config.py:32-223, onejoint/config.py:30-133).
+ *
+ *   T(link0)     = A0
+ *   T(joint_i)   = T(link_i) * AJ[i]
+ *   T(link_i+1)  = T(joint_i) * Rz(q_i) * B[i]          (all joints revolute about local z)
+ *   T(EE)        = T(link_n) * E   if has_ee else T(link_n)
+ *
+ * Each static transform is a 3x4 row-major affine [R | t] (bottom row 0 0 0 1 implied);
+ * R need not be exactly orthogonal (Jaco2's 8-digit constants are not) - the kernels
+ * differentiate the affine chain exactly.
+ * mdiag[l] = diagonal of the reference's 6x6 `_M_LINKS[l]` (m,m,m,Ixx,Iyy,Izz), applied
+ * in the WORLD frame exactly as base_config.py:628 does.  Only links l < n_links_dyn
+ * (= the reference's N_LINKS) enter M, g and C (base_config.py:449,626).
+ * --------------------------------------------------------------------------------- */
+typedef struct abrk_arm_desc {
+  int32_t n_joints;
+  int32_t n_links_dyn;
+  int32_t has_ee;
+  int32_t reserved;
+  double A0[12];
+  double AJ[ABRK_MAX_JOINTS][12];
+  double B[ABRK_MAX_JOINTS][12];
+  double E[12];
+  double mdiag[ABRK_MAX_JOINTS + 1][6];
+  char name[32];
+} abrk_arm_desc;
+
+#endif /* ABRK_TYPES_H */

@@ -1148,3 +1148,88 @@ def test_gpu_rollout_refuses_unfused_null_controllers_and_gains_are_live():
     six = [Damping(rc6, kv=k) for k in (1.0, 2.0, 3.0, 4.0, 5.0, 6.0)]  # 4 fused + 2 through u_null_ext
     ref = o.osc_batch(_abi.make_osc_params(6, kp=200, null_controllers=[_abi.make_damping(21.0)]), q, dq, t)
     assert cases.rel_err(OSC(rc6, kp=200, null_controllers=six).generate(q, dq, t), ref).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------- fused u + Tx, J, M, g (SURVEY 8d Mode F)
+@pytest.mark.parametrize("arm,kw", [
+    ("ur5", dict(kp=200)),
+    ("ur5", dict(kp=200, use_C=True)),
+    ("ur5", dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6, use_C=True, ref_frame="link5", xyz_offset=[0.05, 0.0, -0.1],
+                 null_controllers=[_abi.make_damping(5)])),
+    ("jaco2", dict(kp=200, null_controllers=[_abi.make_damping(10)])),
+    ("twojoint", dict(kp=10, kv=3, ctrlr_dof=cases.XY, use_C=True)),
+    ("threejoint", dict(kp=50, ctrlr_dof=cases.XY)),
+])
+@pytest.mark.parametrize("variant", ["static", "rt"])
+def test_gpu_fused_full_outputs_equal_separate_calls(arm, kw, variant):
+    """abrk_osc_generate_full_batch: u (and training_signal) bit-equal to abrk_osc_generate_batch, and Tx / J / M / g
+    equal to abrk_dynamics_batch of the same ref_frame / offset - including the last, partial wavefront and the
+    fp32 instantiation"""
+    be = cases.GpuBackend(arm, variant)
+    n = be.n
+    p = _abi.make_osc_params(n, **kw)
+    frame, off = kw.get("ref_frame", "EE"), kw.get("xyz_offset")
+    for B, dtype, tol in ((1000, np.float64, 1e-13), (77, np.float32, 2e-5)):
+        q, dq, t = (x.astype(dtype) for x in draw(81, B, n))
+        u0, ts0 = be.e.osc_generate(be.arm_id, n, p, q, dq, t, training_signal=True, dtype=dtype)
+        u1, ts1, dyn = be.e.osc_generate(be.arm_id, n, p, q, dq, t, training_signal=True, dtype=dtype,
+                                         want=("Tx", "J", "M", "g"))
+        ref = be.e.dynamics(be.arm_id, n, q, None, _abi.frame_id(frame, n), off, ("Tx", "J", "M", "g"), dtype, 0)
+        scale = lambda x: max(1.0, float(np.max(np.abs(x))))
+        # the two kernels schedule the same arithmetic differently (fma contraction): equal to rounding
+        assert np.max(np.abs(u1.astype(float) - u0)) <= tol * scale(u0) * 1e3
+        assert np.max(np.abs(ts1.astype(float) - ts0)) <= tol * scale(ts0) * 1e3
+        for k in ("Tx", "J", "M", "g"):
+            assert dyn[k].shape == ref[k].shape and dyn[k].dtype == dtype
+            assert np.max(np.abs(dyn[k].astype(float) - ref[k])) <= tol * scale(ref[k]), (arm, variant, k)
+        # a subset of outputs leaves the others untouched
+        only = be.e.osc_generate(be.arm_id, n, p, q, dq, t, dtype=dtype, want=("M",))[1]
+        assert list(only) == ["M"] and np.array_equal(only["M"], dyn["M"])
+
+
+def test_gpu_osc_generate_return_dynamics_python_api():
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC
+
+    rc = ur5.Config()
+    c = OSC(rc, kp=200, use_C=True)
+    q, dq, t = draw(82, 300, 6)
+    u, dyn = c.generate(q, dq, t, return_dynamics=("J", "M", "g", "Tx"))
+    assert np.allclose(u, c.generate(q, dq, t), rtol=1e-12, atol=1e-12)
+    assert np.allclose(dyn["J"], rc.J("EE", q), atol=1e-6) and np.allclose(dyn["M"], rc.M(q), atol=1e-5)
+    assert np.allclose(dyn["g"], rc.g(q), atol=1e-5) and np.allclose(dyn["Tx"], rc.Tx("EE", q), atol=1e-12)
+    u1, d1 = c.generate(q[0], dq[0], t[0], return_dynamics=("M",))
+    assert u1.shape == (6,) and d1["M"].shape == (6, 6)
+
+
+# ---------------------------------------------------------------------------- one call over several devices
+def test_gpu_sharded_call_equals_unsharded_bitwise():
+    """abrk_osc_generate_sharded / sharding.MultiDevice: contiguous row shards, each on its own stream; with one GPU
+    every shard maps to device 0 (the multi-GPU placement is the same code with other ordinals).  Bit-equal to the
+    single call, for shard counts that do and do not divide the batch, with per-row state and a training signal"""
+    from abr_control_amd import engine
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC, Damping
+    from abr_control_amd.sharding import MultiDevice
+
+    be = cases.GpuBackend("ur5")
+    B = 10007
+    q, dq, t = draw(91, B, 6)
+    tv = np.random.RandomState(92).uniform(-0.5, 0.5, (B, 6))
+    p = _abi.make_osc_params(6, kp=100, kv=15, ki=0.2, use_C=True, null_controllers=[_abi.make_damping(5)])
+    ie0 = np.zeros((B, 6))
+    u0, ts0 = be.e.osc_generate(be.arm_id, 6, p, q, dq, t, tv, ie0, training_signal=True)
+    for devices in ([0], [0, 0], [0] * 8, [0] * 13):
+        ie = np.zeros((B, 6))
+        u, ts = engine.osc_generate_sharded(be.arm_id, 6, p, q, dq, t, devices, tv, ie, training_signal=True)
+        assert np.array_equal(u, u0) and np.array_equal(ts, ts0) and np.array_equal(ie, ie0), devices
+    # more shards than rows, fp32, and the controller-level API
+    u3 = engine.osc_generate_sharded(be.arm_id, 6, _abi.make_osc_params(6, kp=200), q[:3], dq[:3], t[:3], [0] * 8)
+    assert np.array_equal(u3, be.e.osc_generate(be.arm_id, 6, _abi.make_osc_params(6, kp=200), q[:3], dq[:3], t[:3]))
+    rc = ur5.Config()
+    c = OSC(rc, kp=200, null_controllers=[Damping(rc, kv=10)])
+    md = MultiDevice([0, 0, 0])
+    assert np.array_equal(md.generate(c, q, dq, t), c.generate(q, dq, t))
+    assert md.generate(c, q[0], dq[0], t[0]).shape == (6,)
+    with pytest.raises(Exception):
+        engine.osc_generate_sharded(be.arm_id, 6, p, q, dq, t, [99])
