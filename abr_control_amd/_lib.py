@@ -47,6 +47,8 @@ def lib():
         L.abrk_osc_generate_full_batch.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint32,
             C.POINTER(_abi.DynOut), C.c_int, _vp]
+        L.abrk_osc_generate_coop_batch.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp]
         L.abrk_osc_generate_sharded.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
             C.POINTER(C.c_int)]

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/abrk.h"
+#include "abrk_coop.h"
 #include "abrk_kernels.h"
 #include "abrk_params.h"
 
@@ -616,6 +617,53 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
     OscArgs o = oa;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
     return ops->osc(dtype, LaunchArgs{rt, (long)B, hs}, o);
+  });
+}
+
+// ------------------------------------------------------------------------------- OSC, wave-cooperative mapping
+namespace abrk {
+hipError_t launch_osc_coop_ur5(const LaunchArgs& la, const CoopArgs& a);
+}
+extern "C" int abrk_osc_generate_coop_batch(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                                            const void* dq, const void* target, void* u, void* training_signal,
+                                            int lanes_per_arm, int device, void* stream) {
+  ArmEntry* a;
+  if (int rc = check_common(arm_id, dtype, B, &a)) return rc;
+  const int n = a->desc.n_joints;
+  if (!(a->builtin && strcmp(a->desc.name, "ur5") == 0) || dtype != ABRK_F64)
+    return fail(ABRK_EINVAL, "the wave-cooperative kernels are built for the built-in ur5 arm in fp64 (measurement variant)");
+  if (lanes_per_arm != 4 && lanes_per_arm != 8 && lanes_per_arm != 16)
+    return fail(ABRK_EINVAL, "lanes_per_arm must be 4, 8 or 16");
+  if (!P) return fail(ABRK_EINVAL, "params is NULL");
+  if (osc_fast_rows(*P, n, false) != 3 || P->n_null != 0 || P->use_C || P->ki != 0 || P->xyz_offset[0] != 0 ||
+      P->xyz_offset[1] != 0 || P->xyz_offset[2] != 0)
+    return fail(ABRK_EINVAL, "the wave-cooperative kernels cover the plain law: x,y,z of the EE, no offset, no null "
+                             "controllers, no Coriolis term, ki = 0");
+  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
+  if (B == 0) return 0;
+  if (int rc = use_device(device)) return rc;
+  const size_t s = esz(dtype);
+  Stager st{device, (hipStream_t)stream};
+  const void* q_ = st.add(q, B * n * s, true, false);
+  const void* dq_ = st.add(dq, B * n * s, true, false);
+  const void* t_ = st.add(target, B * 6 * s, true, false);
+  void* u_ = st.add(u, B * n * s, false, true);
+  void* ts_ = st.add(training_signal, B * n * s, false, true);
+  if (int rc = st.reserve()) return rc;
+  CoopArgs ca;
+  ca.P = nullptr;
+  ca.lanes = lanes_per_arm;
+  ca.q = st.fix(q_, q);
+  ca.dq = st.fix(dq_, dq);
+  ca.target = st.fix(t_, target);
+  ca.u = st.fix(u_, u);
+  ca.ts = st.fix(ts_, training_signal);
+  const OscP<double> p64 = make_oscp<double>(*P, n);
+  const hipStream_t hs = (hipStream_t)stream;
+  return dispatch(st, a, dtype, [=](const void*) {
+    CoopArgs o = ca;
+    o.P = &p64;
+    return launch_osc_coop_ur5(LaunchArgs{nullptr, (long)B, hs}, o);
   });
 }
 

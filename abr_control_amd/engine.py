@@ -159,6 +159,24 @@ def osc_generate(arm_id, n, params, q, dq, target, target_velocity=None, integra
     return (uo, tso) if tso is not None else uo
 
 
+def osc_generate_coop(arm_id, n, params, q, dq, target, lanes_per_arm, u=None, training_signal=False, dtype=np.float64,
+                      device=0, stream=None):
+    """The wave-cooperative mapping of the plain OSC law (abrk_osc_generate_coop_batch; ur5, fp64): K = lanes_per_arm
+    lanes per arm instance.  Measurement variant - see profiles/round2/coop_ab.md."""
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp = a.inp(q, (B, n), "q")
+    dqp = a.inp(dq, (B, n), "dq")
+    tp = a.inp(target, (B, 6), "target")
+    up, uo = a.out(u, (B, n), device, "u")
+    tsp, tso = None, None
+    if training_signal is not False and training_signal is not None:
+        tsp, tso = a.out(None if training_signal is True else training_signal, (B, n), device, "training_signal")
+    check(lib().abrk_osc_generate_coop_batch(arm_id, a.code, C.byref(params), B, qp, dqp, tp, up, tsp,
+                                             int(lanes_per_arm), device, _sp(stream)))
+    return (uo, tso) if tso is not None else uo
+
+
 def osc_generate_sharded(arm_id, n, params, q, dq, target, devices, target_velocity=None, integrated_error=None,
                          u_null_ext=None, u=None, training_signal=False, dtype=np.float64):
     """OSC.generate of ONE host batch over several devices (abrk_osc_generate_sharded): contiguous row shards, shard g

@@ -30,6 +30,11 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TF = 78.6   # = 1/2 of the 157.3 TF fp32 vector peak
+# VALU issue peaks at the nominal 2.4 GHz, in wavefront-lane instructions per second: 1024 SIMDs x 16 lanes/clk for
+# fp64 (a wave64 v_fma_f64 issues in 4 cycles), x 32 lanes/clk for fp32 (2 cycles; v_pk_* take 4 - no packed gain).
+# Measured by tools/microbench/valu_rates.hip on a short boost-clock run: 36.7 T (fp64), 65.1 T (fp32).
+ISSUE_PEAK_NOMINAL = {"f64": 1024 * 16 * 2.4e9, "f32": 1024 * 32 * 2.4e9}
+PROFILE_DIRS = ("round2", "round1")  # committed rocprofv3 evidence, newest first
 
 WORKLOADS = {
     # name: (arm, batch per GPU, dtype, kind, params kwargs, algorithmic flops per eval)
@@ -51,6 +56,8 @@ WORKLOADS = {
     "ik": ("ur5", 4096, "f64", "ik", dict(method=3, n_timesteps=200), 2500),
     # position + orientation control (all six task rows, orientation algorithm 0): the masked six-row kernel
     "osc6": ("ur5", 4096, "f64", "osc", dict(kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6), 6000),
+    # Sliding on the six-joint Jaco2 (general affine chain, full Christoffel matrix + dJ): the heaviest kernel of the set
+    "sliding_j2": ("jaco2", 65536, "f64", "sliding", dict(), 12000),
     # the remaining secondary controllers as their own kernels (u [B,n] each)
     "limits": ("ur5", 4096, "f64", "limits", dict(), 60),
     "floating": ("ur5", 4096, "f64", "floating", dict(dynamic=True, task_space=True), 3300),
@@ -289,33 +296,64 @@ def concurrent_streams_rate(workload, B, device, n_streams, steps, graph_steps=1
             "us_per_step_per_stream": round(wall / total_steps * 1e6, 3)}
 
 
+def _profiled(fname, kernel, batch):
+    """(entry, "profiles/<round>/<fname>", commit the profile was taken at) of the committed rocprofv3 evidence for this
+    (kernel, rows per launch) - or (None, None, None)"""
+    key = f"{kernel.replace(' ', '')}:{batch}"
+    for rnd in PROFILE_DIRS:
+        path = os.path.join(REPO, "profiles", rnd, fname)
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if key in d:
+            return d[key], f"profiles/{rnd}/{fname}", d.get("_commit")
+    return None, None, None
+
+
 def profiled_traffic(kernel, batch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/round1/traffic.json, tools/gpu_profiles.sh); None when that (kernel, batch) was not profiled."""
-    try:
-        t = json.load(open(os.path.join(REPO, "profiles", "round1", "traffic.json")))[f"{kernel.replace(' ', '')}:{batch}"]
-        return round(t["read_bytes"] + t["write_bytes"], 1)
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/gpu_profiles.sh ->
+    profiles/<round>/traffic.json): NOT a measurement of the run that prints it - the profile's commit is stamped"""
+    t, src, commit = _profiled("traffic.json", kernel, batch)
+    if t is None:
+        return None, None, None
+    return round(t["read_bytes"] + t["write_bytes"], 1), src, commit
 
 
 def roofline(runner, ms_per_launch, label):
     evals_s = runner.evals_per_launch / (ms_per_launch * 1e-3)
     gbs = runner.B / (ms_per_launch * 1e-3) * runner.bytes_per_eval / 1e9
-    tf = evals_s * runner.flops / 1e12
     kname = runner.kernel_name()
-    return {
+    traffic, tsrc, tcommit = profiled_traffic(kname, runner.B)
+    dts = "f64" if runner.dt == np.float64 else "f32"
+    out = {
         "kernel": kname,
         "workload": label, "batch": runner.B, "bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": profiled_traffic(kname, runner.B),
+        "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_source": None if traffic is None else f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                                       f"FETCH_SIZE x2 on gfx950), profiled at commit {tcommit}",
         "algorithmic_bytes_per_launch": runner.B * runner.bytes_per_eval,
         "bytes_per_eval": runner.bytes_per_eval, "us_per_launch": round(ms_per_launch * 1e3, 3),
         "evals_per_s": round(evals_s, 1),
-        "binding": "fp64_valu" if runner.dt == np.float64 else "fp32_valu",
-        "valu_tflops": round(tf, 3), "valu_peak_tflops": FP64_VALU_PEAK_TF if runner.dt == np.float64 else 157.3,
-        "valu_frac": round(tf / (FP64_VALU_PEAK_TF if runner.dt == np.float64 else 157.3), 5),
-        "traffic_profiled": "profiles/round1/SUMMARY.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
     }
+    # the VALU view from EXECUTED instructions (SQ_INSTS_VALU / row of the committed PMC pass), not from a
+    # reference-derived flop count: lane-instructions per second against the issue peak at the nominal clock
+    c, csrc, ccommit = _profiled("counters.json", kname, runner.B)
+    if c is not None:
+        lane_instr_s = evals_s * c["valu_per_row"]
+        peak = ISSUE_PEAK_NOMINAL[dts]
+        out["valu"] = {
+            "binding": f"{dts}_valu_issue", "valu_instr_per_row": round(c["valu_per_row"], 1),
+            "salu_instr_per_row": round(c["salu_per_row"], 1),
+            "lane_instr_per_s": round(lane_instr_s, 1), "issue_peak_nominal_2p4GHz": peak,
+            "frac_of_nominal_issue_peak": round(lane_instr_s / peak, 4),
+            # an fp64 instruction retires at most one fma per lane: executed flops <= 2 x instructions
+            "executed_tflops_upper_bound": round(2 * lane_instr_s / 1e12, 2),
+            "issue_util_profiled": c.get("issue_util"), "clock_ghz_profiled": c.get("clock_ghz"),
+            "source": f"{csrc}, profiled at commit {ccommit}; rate of THIS run x profiled instructions per row",
+        }
+    out["algorithmic_flops_per_eval_reference_cse"] = runner.flops  # SURVEY 8d (SymPy cse of the reference's expressions)
+    return out
 
 
 def parity_vs_reference(device):
@@ -455,8 +493,16 @@ def cpu_baseline(workload, budget_s=12.0):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(worker, range(cores)))
     dtc = time.perf_counter() - t0
+    ref = None
+    try:
+        rj = json.load(open(os.path.join(REPO, "profiles", "round2", "reference_cython_baseline.json")))
+        if workload in rj["workloads"]:
+            ref = dict(rj["workloads"][workload], cores=rj["cores"], measured_on=rj["measured_on"], what=rj["what"],
+                       script=rj["script"])
+    except (OSError, ValueError, KeyError):
+        pass
     return {"value": round(total * Bs * scale / dtc, 1), "unit": "evals/s", "cores": cores, "kind": "port",
-            "value_1core": round(one, 1),
+            "value_1core": round(one, 1), "reference_cython": ref,
             "sample": f"oracle/abrk_oracle.c (plain-C port of the reference path) on seeded rows of the same "
                       f"workload: {reps} x {Bs} rows{f' x {scale} steps' if scale > 1 else ''} on 1 thread in {dt1:.1f} s; "
                       f"{total} x {Bs} rows on {cores} threads in {dtc:.1f} s"}
@@ -473,6 +519,7 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
+    ap.add_argument("--no-strong-leg", action="store_true", help="skip the strong-scaling leg (cfg4, global batch 2^20)")
     ap.add_argument("--no-streams-leg", action="store_true", help="skip the concurrent_streams leg (rocprofv3's "
                     "kernel tracing crashes inside hipGraphLaunch when 16 streams replay graphs at once)")
     ap.add_argument("--also", default="", help="comma-separated extra workloads: one HBM-sized roofline leg each "
@@ -540,7 +587,41 @@ def main():
                                   if getattr(run, "used_graph", False) else "one kernel launch per step")},
             "roofline_config": roofline(run, ms, f"{args.workload} batch={B} (cache-resident, launch-bound)"),
         }
-    # HBM-sized leg for the roofline (rank 0 only; every rank could, the figure is per GPU)
+    # STRONG scaling (BASELINE config 4: UR5 OSC + gravity + Coriolis, GLOBAL batch 2^20 cut into contiguous row
+    # shards over the ranks): every rank evaluates its shard, same barrier + MAX-over-ranks protocol as `value`.
+    # The weak-scaling `value` above keeps the per-GPU batch fixed; this leg keeps the total fixed.
+    if not args.no_strong_leg:
+        from abr_control_amd.sharding import shard_range
+
+        G = 1 << 20
+        lo, hi = shard_range(G, rank, world)
+        r4 = Runner("cfg4", hi - lo, device, stream)
+        k4 = max(min(args.steps, 400), 8)
+        wall4, ms4 = r4.timed(k4, min(args.warmup, 50), barrier)
+        if dist:
+            tt = torch.tensor([wall4], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall4 = float(tt[0])
+        if rank == 0:
+            out["strong_scaling_cfg4"] = {
+                "workload": "cfg4: ur5 OSC + g + C, global batch 2^20 sharded by contiguous rows, no collective",
+                "global_batch": G, "n_gpus": world, "rows_per_gpu": hi - lo, "steps": k4,
+                "us_per_step": round(wall4 / k4 * 1e6, 3), "evals_per_s": round(G * k4 / wall4, 1),
+                "kernel_us_rank0": round(ms4 * 1e3, 3), "scaling": "strong"}
+        del r4
+    # HBM-sized leg per GPU (every rank; the figures are gathered on rank 0)
+    if world > 1 and not args.no_roofline_leg:
+        rb = args.roofline_batch
+        bigr = Runner(args.workload, rb, device, stream)
+        _, ms_r = bigr.timed(args.roofline_steps, ROOFLINE_WARMUP)
+        mine = roofline(bigr, ms_r, f"{args.workload} batch={rb} on every GPU at once")
+        del bigr
+        gathered = [None] * world
+        dist.all_gather_object(gathered, {"rank": rank, "device": device, "us_per_launch": mine["us_per_launch"],
+                                          "achieved": mine["achieved"], "frac": mine["frac"]})
+        if rank == 0:
+            out["roofline_per_gpu"] = gathered
+    # HBM-sized leg for the roofline (rank 0 only; the figure is per GPU)
     if rank == 0 and not args.no_roofline_leg:
         del run
         # the iterative workloads carry [B, T, n] trajectories (ik: 19 KB per row): keep their leg at 256 k rows

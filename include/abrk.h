@@ -161,6 +161,14 @@ int abrk_osc_generate_full_batch(int arm_id, int dtype, const abrk_osc_params* p
                                  const void* u_null_ext, void* u, void* training_signal, uint32_t want,
                                  const abrk_dyn_out* out, int device, void* stream);
 
+/* The WAVE-COOPERATIVE mapping of the same law (K = lanes_per_arm in {4, 8, 16} lanes per arm instance, frames /
+ * Jacobian columns / M staged in LDS, abr_control_amd/csrc/abrk_coop.h): a measurement variant kept beside the
+ * lane-per-arm kernels for the config-sized batch (profiles/round2/coop_ab.md).  Built-in ur5, fp64, the plain law of
+ * BASELINE config 2 (x,y,z of the EE; no xyz_offset, null controllers, Coriolis term or integral term).      */
+int abrk_osc_generate_coop_batch(int arm_id, int dtype, const abrk_osc_params* params, int64_t B, const void* q,
+                                 const void* dq, const void* target, void* u, void* training_signal,
+                                 int lanes_per_arm, int device, void* stream);
+
 /* The same call over SEVERAL devices (BASELINE config 4: 2^20 rows over the 8 GPUs of a node): host arrays in, host
  * arrays out; the batch is cut into n_shards contiguous row ranges (sizes differing by at most one row), shard g is
  * evaluated on devices[g] (a device may appear more than once), each on a stream of its own, all kernels in flight before the first result is collected.  Rows are

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Times the REFERENCE's own path (abr_control's Cython-loaded generated functions + its NumPy control law, exactly
+what its users run) on the host cores of the machine this script is run on, for the BASELINE workloads.
+
+TEST / MEASUREMENT INFRASTRUCTURE - build container only (needs /root/reference; the GPU box has no reference
+checkout, so bench.py quotes the committed result of this script, labelled with where it was measured).
+
+The reference has no batch API and no multi-core path: "1 core" is its loop over the batch,
+`ctrlr.generate(q[b], dq[b], target[b])` per row; "all cores" is a multiprocessing pool, one reference instance per
+process (one arm per process - its function cache collides across arms, base_config.py:178-191), the sample split
+evenly.  Inputs: the reference benchmark's distribution (examples/timing_plots.py:18-20), seed 1 - the same rows
+bench.py's synthetic inputs start with.
+
+Usage: python oracle/time_reference.py [out.json]     (default profiles/round2/reference_cython_baseline.json)
+"""
+import json
+import multiprocessing as mp
+import os
+import platform
+import shutil
+import subprocess
+import sys
+import time
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+SCRATCH = "/tmp/abrk_ref_scratch_timing"
+
+WORKLOADS = {
+    # name: (arm, controller factory source, n target columns)
+    "cfg1": ("twojoint", "OSC(rc, kp=10, kv=3, ctrlr_dof=[True, True, False, False, False, False])", 6),
+    "cfg2": ("ur5", "OSC(rc, kp=200, ctrlr_dof=[True, True, True, False, False, False])", 6),
+    "cfg3": ("jaco2", "OSC(rc, kp=200, null_controllers=[Damping(rc, kv=10)], ctrlr_dof=[True, True, True, False, False, False])", 6),
+    "cfg4": ("ur5", "OSC(rc, kp=200, use_g=True, use_C=True, ctrlr_dof=[True, True, True, False, False, False])", 6),
+    "cfg5": ("threejoint", "Sliding(rc)", 3),
+}
+
+WORKER = r'''
+import importlib, sys, time
+import numpy as np
+arm, factory, nt, n_rows, budget = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5])
+mod = importlib.import_module(f"abr_control.arms.{arm}")
+from abr_control.controllers import OSC, Damping, Sliding
+rc = mod.Config(use_cython=True)
+ctrlr = eval(factory)
+n = rc.N_JOINTS
+rng = np.random.RandomState(1)
+q, dq, t = rng.uniform(0, 2 * np.pi, (n_rows, n)), rng.uniform(0, 5, (n_rows, n)), rng.uniform(-1, 1, (n_rows, nt))
+ctrlr.generate(q[0], dq[0], t[0])  # first call loads the generated functions (examples/timing_plots.py drops it too)
+kind = type(rc._M).__name__
+done, t0 = 0, time.perf_counter()
+while time.perf_counter() - t0 < budget:
+    for b in range(n_rows):
+        ctrlr.generate(q[b], dq[b], t[b])
+    done += n_rows
+print(done, time.perf_counter() - t0, kind)
+'''
+
+
+def run_workers(name, procs, budget, env):
+    arm, factory, nt = WORKLOADS[name]
+    cmd = [sys.executable, "-c", WORKER, arm, factory, str(nt), "256", str(budget)]
+    t0 = time.perf_counter()
+    ps = [subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(procs)]
+    outs = [p.communicate() for p in ps]
+    wall = time.perf_counter() - t0
+    for p, (o, e) in zip(ps, outs):
+        if p.returncode:
+            raise RuntimeError(f"{name}: reference worker failed:\n{e[-2000:]}")
+    rows = [o.split() for o, _ in outs]
+    rate = sum(int(r[0]) / float(r[1]) for r in rows)  # each worker's own timed region (start-up excluded)
+    return rate, rows[0][2], wall
+
+
+def main():
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "round2", "reference_cython_baseline.json")
+    if not os.path.isdir(REF):
+        sys.exit("time_reference.py needs /root/reference (build container only)")
+    if os.path.isdir(SCRATCH):
+        shutil.rmtree(SCRATCH)
+    shutil.copytree(REF, SCRATCH)
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=SCRATCH, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1",
+               MKL_NUM_THREADS="1")
+    cores = len(os.sched_getaffinity(0))
+    cpu = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), platform.processor())
+    res = {"measured_on": f"build container ({cpu}, {cores} cores) - NOT the GPU box's host",
+           "what": "abr_control's own Cython path: ctrlr.generate(q[b], dq[b], target[b]) per row (no batch API), "
+                   "generated functions loaded from its cache (base_config.py:173-191)",
+           "script": "oracle/time_reference.py", "cores": cores, "workloads": {}}
+    for name in WORKLOADS:
+        r1, kind, _ = run_workers(name, 1, 4.0, env)
+        rall, _, _ = run_workers(name, cores, 4.0, env)
+        res["workloads"][name] = {"evals_per_s_1core": round(r1, 1), "us_per_eval_1core": round(1e6 / r1, 2),
+                                  "evals_per_s_allcores": round(rall, 1), "function_type": kind}
+        print(name, res["workloads"][name], flush=True)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    json.dump(res, open(out, "w"), indent=1)
+    print("wrote", out)
+    shutil.rmtree(SCRATCH, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1233,3 +1233,34 @@ def test_gpu_sharded_call_equals_unsharded_bitwise():
     assert md.generate(c, q[0], dq[0], t[0]).shape == (6,)
     with pytest.raises(Exception):
         engine.osc_generate_sharded(be.arm_id, 6, p, q, dq, t, [99])
+
+
+# ---------------------------------------------------------------------------- the wave-cooperative mapping (north_star)
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+def test_gpu_wave_cooperative_variant_matches_reference_and_lane_per_arm(lanes):
+    """K lanes per arm, frames / Jacobian columns / M staged in LDS (abrk_coop.h): same results as the reference
+    (golden cfg2, incl. its truncated-pinv rows) and as the lane-per-arm kernel, for batches that do not fill the
+    last wavefront; vmax and use_g honoured; unsupported options refused"""
+    from abr_control_amd import engine
+    from abr_control_amd._lib import AbrkError
+
+    be = cases.GpuBackend("ur5")
+    g = golden("ur5")
+    q, dq, t = g["cfg2_q"], g["cfg2_dq"], g["cfg2_target"]
+    p = _abi.make_osc_params(6, kp=200)
+    u, ts = engine.osc_generate_coop(be.arm_id, 6, p, q, dq, t, lanes, training_signal=True)
+    ok = ~cases.threshold_band(g, "cfg2")
+    assert cases.rel_err(u, g["cfg2_uD"])[ok].max() <= cases.TOL_D
+    assert cases.rel_err(ts, g["cfg2_tsD"])[ok].max() <= cases.TOL_D
+    for B, kw in ((1, dict(kp=200)), (67, dict(kp=30, kv=7, use_g=False)), (1003, dict(kp=100, kv=15, vmax=[0.5, 1.0]))):
+        qq, dd, tt = draw(95 + B, B, 6)
+        pp = _abi.make_osc_params(6, **kw)
+        ref = be.osc(pp, qq, dd, tt)[0]
+        got = engine.osc_generate_coop(be.arm_id, 6, pp, qq, dd, tt, lanes)
+        assert cases.rel_err(got, ref).max() <= 1e-9, (B, kw)
+    for bad in (dict(use_C=True), dict(ctrlr_dof=[1] * 6), dict(null_controllers=[_abi.make_damping(5)]), dict(ki=0.1),
+                dict(xyz_offset=[0.1, 0, 0])):
+        with pytest.raises(AbrkError):
+            engine.osc_generate_coop(be.arm_id, 6, _abi.make_osc_params(6, **bad), q[:4], dq[:4], t[:4], lanes)
+    with pytest.raises(AbrkError):
+        engine.osc_generate_coop(cases.GpuBackend("jaco2").arm_id, 6, p, q[:4], dq[:4], t[:4], lanes)

@@ -14,7 +14,7 @@ lines = ["# rocprofv3 evidence (MI355X, ROCm 7.2)", "",
          "Commands: `tools/gpu_profiles.sh` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
          "`--pmc` passes as MI355X_MICROARCH.md prescribes).  `FETCH_SIZE`/`WRITE_SIZE` are in KiB; on gfx950 "
          "FETCH_SIZE counts 64 B per 128-B request, so read bytes = FETCH_SIZE x 1024 x 2.", ""]
-for f in ("pytest_gpu.log", "smoke.log"):
+for f in ("pytest_gpu.log", "smoke.log", "coop_ab.md", "valu_rates.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for f in sorted(os.listdir(src)):
@@ -71,7 +71,39 @@ if rows:
             traffic[f"{k.replace(' ', '')}:{int(gsz)}"] = {
                 "read_bytes": float(r["FETCH_SIZE"] * 1024 * 2), "write_bytes": float(r["WRITE_SIZE"] * 1024),
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
+    commit = os.environ.get("ABRK_PROFILE_COMMIT", "unknown")
+    traffic["_commit"] = commit
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+    # executed instructions per row, issue utilisation and effective clock per (kernel, rows): what bench.py's
+    # `roofline.valu` block is computed from
+    durs = {}
+    ktp = os.path.join(src, "pmc_grbm", "bench_kernel_trace.csv")
+    if not os.path.exists(ktp):
+        import glob as _g
+        cand = _g.glob(os.path.join(src, "pmc_grbm", "**", "*kernel_trace.csv"), recursive=True)
+        ktp = cand[0] if cand else None
+    if ktp:
+        kt2 = pd.read_csv(ktp)
+        kt2["dur"] = kt2["End_Timestamp"] - kt2["Start_Timestamp"]
+        kt2["kernel"] = kt2["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:90]
+        for (k, gsz), grp in kt2.groupby(["kernel", "Grid_Size_X"]):
+            durs[(k, int(gsz))] = float(grp["dur"].mean())
+    counters = {"_commit": commit}
+    for (k, gsz), r in piv.iterrows():
+        if "SQ_WAVES" not in r or r["SQ_WAVES"] != r["SQ_WAVES"] or gsz < 4096:
+            continue
+        w = r["SQ_WAVES"]
+        e = {"valu_per_row": float(r["SQ_INSTS_VALU"] / w), "salu_per_row": float(r["SQ_INSTS_SALU"] / w),
+             "wave_cycles_per_wave": float(4 * r["SQ_WAVE_CYCLES"] / w),
+             "busy_cycles": float(r["SQ_BUSY_CYCLES"]) if "SQ_BUSY_CYCLES" in r else None}
+        if "GRBM_GUI_ACTIVE" in r and r["GRBM_GUI_ACTIVE"] == r["GRBM_GUI_ACTIVE"] and (k, int(gsz)) in durs:
+            e["clock_ghz"] = round(float(r["GRBM_GUI_ACTIVE"]) / durs[(k, int(gsz))], 3)
+            # issue utilisation: executed VALU issue cycles (4 per fp64 wave-instruction, 2 per fp32) of all waves over
+            # the SIMD-cycles the kernel was resident (1024 SIMDs x GRBM_GUI_ACTIVE)
+            cyc = 4 if "double" in k else 2
+            e["issue_util"] = round(float(r["SQ_INSTS_VALU"]) * cyc / (1024 * float(r["GRBM_GUI_ACTIVE"])), 4)
+        counters[f"{k.replace(' ', '')}:{int(gsz)}"] = e
+    json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
     for (k, gsz), r in piv.iterrows():
         if gsz < 100000:
             continue
