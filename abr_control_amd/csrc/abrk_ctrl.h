@@ -745,6 +745,11 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   T cv2[TWO_PASS ? N : 1];
   RneState<T> rne;
   int m = N;
+  // sin/cos of the joint angles: through the kernel's LDS table where it keeps one (fp64 OSC kernels on the GPU)
+  auto sincos_policy = [&]() ABRK_LAMBDA {
+    if constexpr (std::remove_reference<Scr>::type::kHasTab && std::is_same<T, double>::value) return ScTab{scr.sctab};
+    else return ScCompute{};
+  };
   auto dynamics_pass = [&](auto& cap_) ABRK_LAMBDA {
     if constexpr (TWO_PASS) {
       rne_init(rne);
@@ -752,14 +757,14 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
         ABRK_SCHED_FENCE();  // the link's Jacobian columns (M, g) are retired before the recursion's transients start
         rne_forward_step<L()>(arm, jt, pl, dq, rne, scr);
         ABRK_SCHED_FENCE();
-      });
+      }, sincos_policy());
       rne_backward(jt, scr, cv2);
       // the result is only consumed at the very end of the law: without this the scheduler reads the slab here and
       // carries (spills) the 6 N values until then
       sfor<N>([&](auto i) ABRK_LAMBDA { opaque(cv2[i()]); });
       ABRK_SCHED_FENCE();
     } else {
-      kin_dyn(arm, q, dq, jt, d, XR, xo, cap_);
+      kin_dyn_hook(arm, q, dq, jt, d, XR, xo, cap_, [](auto, const T(&)[3]) ABRK_LAMBDA {}, sincos_policy());
     }
   };
   if constexpr (FAST) {

@@ -24,6 +24,7 @@
 #include <utility>
 
 #include "abrk_arms_builtin.h"
+#include "abrk_sincos_table.h"
 
 #ifndef ABRK_HD
 #define ABRK_HD __device__
@@ -115,6 +116,28 @@ struct Rm<double> {
     s = __builtin_bit_cast(double, __builtin_bit_cast(long long, ss) ^ ((long long)(k & 2) << 62));
     c = __builtin_bit_cast(double, __builtin_bit_cast(long long, cs) ^ ((long long)((k + 1) & 2) << 62));
   }
+  // Table-driven form for the kernels that keep sin/cos of k 2pi/128 in LDS (`tab`: [128][2], abrk_sincos_table.h):
+  // x = n (2pi/128) + r with |r| <= pi/128 (two-term Cody-Waite split, n D1 exact for |x| < 1e5), then
+  //   sin x = S cos r + C sin r,  cos x = C cos r - S sin r
+  // with Taylor polynomials of degree 7 / 6 in r (truncation < 1e-20): 16 fp64 + 3 integer instructions and one
+  // 16-byte LDS read against 25 + 10 of the polynomial routine above.  Absolute error <= 3e-16.
+  static ABRK_INL void sincos_tab(double x, const double* tab, double& s, double& c) {
+    const double n = ::rint(x * kSinCosInvStep);
+    double r = ::fma(-n, kSinCosD1, x);
+    r = ::fma(-n, kSinCosD2, r);
+    const int k = (int)n & (kSinCosN - 1);
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 sc = reinterpret_cast<const d2*>(tab)[k];
+    const double z = r * r;
+    double ps = fma_sc(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03);
+    ps = fma_sc(z, ps, -1.66666666666666666667e-01);
+    const double ss = ::fma(z * r, ps, r);
+    double pc = fma_sc(z, -1.38888888888888888889e-03, 4.16666666666666666667e-02);
+    pc = fma_sc(z, pc, -0.5);
+    const double cc = ::fma(z, pc, 1.0);
+    s = ::fma(sc.x, cc, sc.y * ss);
+    c = ::fma(sc.y, cc, -(sc.x * ss));
+  }
   static ABRK_INL double sqrt(double x) { return ::sqrt(x); }
   static ABRK_INL double fabs(double x) { return ::fabs(x); }
   static ABRK_INL double fma(double a, double b, double c) { return ::fma(a, b, c); }
@@ -153,6 +176,7 @@ struct Rm<float> {
   static ABRK_INL void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }  // a custom routine measured no faster
   static ABRK_INL bool sincos_in_range(float) { return true; }
   static ABRK_INL void sincos_fast(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
+  static ABRK_INL void sincos_tab(float x, const double*, float& s, float& c) { ::sincosf(x, &s, &c); }
   static ABRK_INL float sqrt(float x) { return ::sqrtf(x); }
   static ABRK_INL float fabs(float x) { return ::fabsf(x); }
   static ABRK_INL float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
@@ -470,6 +494,10 @@ struct ScUse {
   }
 };
 
+// sin/cos through the LDS table of the calling kernel (Rm<double>::sincos_tab); fp32 rows keep the library routine
+struct ScTab {
+  const double* tab;
+};
 // sin/cos of all joint angles ahead of the chain: one straight-line block of N independent polynomial
 // evaluations (the per-joint range check would split the forward kinematics into N basic blocks and serialise
 // them); angles beyond the fast routine's range are redone by the library afterwards (one rarely taken branch)
@@ -479,6 +507,15 @@ ABRK_INL void sincos_all(const T (&q)[N], T (&sv)[N][2]) {
   sfor<N>([&](auto i) ABRK_LAMBDA {
     all_in = all_in && Rm<T>::sincos_in_range(q[i()]);
     Rm<T>::sincos_fast(q[i()], sv[i()][0], sv[i()][1]);
+  });
+  if (!all_in) sfor<N>([&](auto i) ABRK_LAMBDA { Rm<T>::sincos(q[i()], sv[i()][0], sv[i()][1]); });
+}
+template <int N, class T>
+ABRK_INL void sincos_all_tab(const T (&q)[N], T (&sv)[N][2], const double* tab) {
+  bool all_in = true;
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    all_in = all_in && Rm<T>::sincos_in_range(q[i()]);
+    Rm<T>::sincos_tab(q[i()], tab, sv[i()][0], sv[i()][1]);
   });
   if (!all_in) sfor<N>([&](auto i) ABRK_LAMBDA { Rm<T>::sincos(q[i()], sv[i()][0], sv[i()][1]); });
 }
@@ -886,6 +923,7 @@ ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, 
 // per link parked in the wavefront's LDS slab, which keeps 12 N VGPRs free while the recursion runs.
 template <class T, int N>
 struct RegScratch {
+  static constexpr bool kHasTab = false;  // no sin/cos table: the polynomial routine
   T f[N][3], t[N][3];
   template <int K>
   ABRK_INL void put(ic<K>, const T (&fv)[3], const T (&tv)[3]) {
@@ -1021,7 +1059,11 @@ ABRK_INL void kin_dyn_hook(const A& arm, const T (&q)[A::N], const T (&dq)[A::N]
     angular_link_coriolis<L()>(arm, jt, d);
     extra(L, p);
   };
-  if constexpr (std::is_same<Sc, ScCompute>::value && ABRK_SINCOS_AHEAD) {
+  if constexpr (std::is_same<Sc, ScTab>::value) {
+    T sv[A::N][2];
+    sincos_all_tab<A::N>(q, sv, scp.tab);
+    fk_forward(arm, q, jt, XR, xo, cap, visit, ScUse<T, A::N>{sv});
+  } else if constexpr (std::is_same<Sc, ScCompute>::value && ABRK_SINCOS_AHEAD) {
     T sv[A::N][2];
     sincos_all<A::N>(q, sv);
     fk_forward(arm, q, jt, XR, xo, cap, visit, ScUse<T, A::N>{sv});

@@ -90,11 +90,32 @@ constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho) {
 #ifndef ABRK_C_LDS
 #define ABRK_C_LDS 1
 #endif
+#ifndef ABRK_SINCOS_TABLE
+#define ABRK_SINCOS_TABLE 1
+#endif
+// The wavefront's copy of the sin/cos table (abrk_sincos_table.h, 2 KiB): two entries per lane, from L2
+__device__ __forceinline__ void load_sincos_table(double* tab, int lane) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  const d2* src = reinterpret_cast<const d2*>(&kSinCosTab[0][0]);
+  d2* dst = reinterpret_cast<d2*>(tab);
+  dst[lane] = src[lane];
+  dst[lane + kBlock] = src[lane + kBlock];
+  __syncthreads();
+}
+static_assert(kBlock == 64 && kSinCosN == 128, "two table entries per lane");
+// scratch of kernels without a Coriolis recursion: nothing but the table pointer
+template <class T, int N>
+struct TabScratch : RegScratch<T, N> {
+  static constexpr bool kHasTab = true;
+  const double* sctab;
+};
 template <class T, int N>
 struct LdsScratch {
+  static constexpr bool kHasTab = (ABRK_SINCOS_TABLE != 0);
   using V2 = T __attribute__((ext_vector_type(2)));
   V2* slab;  // [N][3][kBlock]
   int lane;
+  const double* sctab;
   template <int K>
   __device__ __forceinline__ void put(ic<K>, const T (&fv)[3], const T (&tv)[3]) {
     slab[(K * 3 + 0) * kBlock + lane] = V2{fv[0], fv[1]};
@@ -123,11 +144,19 @@ __global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrt
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
+  constexpr bool kTab = std::is_same<T, double>::value && (ABRK_SINCOS_TABLE != 0);
+  __shared__ double sctab[kTab ? 2 * kSinCosN : 1];
+  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);  // every lane takes part: before the row-index exit
   if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
     using V2 = typename LdsScratch<T, A::N>::V2;
     __shared__ V2 slab[A::N * 3 * kBlock];
     ABRK_ROW_INDEX
-    LdsScratch<T, A::N> scr{slab, (int)threadIdx.x};
+    LdsScratch<T, A::N> scr{slab, (int)threadIdx.x, sctab};
+    osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+  } else if constexpr (kTab) {
+    ABRK_ROW_INDEX
+    TabScratch<T, A::N> scr;
+    scr.sctab = sctab;
     osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
   } else {
     ABRK_ROW_INDEX
@@ -148,9 +177,16 @@ osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __r
   const long row0 = (long)blockIdx.x * kBlock;
   const long b = row0 + threadIdx.x;
   LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
+  constexpr bool kTab = std::is_same<T, double>::value && (ABRK_SINCOS_TABLE != 0);
+  __shared__ double sctab[kTab ? 2 * kSinCosN : 1];
+  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);
   if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
     using V2 = typename LdsScratch<T, A::N>::V2;
-    LdsScratch<T, A::N> scr{reinterpret_cast<V2*>(slab), (int)threadIdx.x};
+    LdsScratch<T, A::N> scr{reinterpret_cast<V2*>(slab), (int)threadIdx.x, sctab};
+    osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
+  } else if constexpr (kTab) {
+    TabScratch<T, A::N> scr;
+    scr.sctab = sctab;
     osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
   } else {
     RegScratch<T, A::N> scr;

@@ -6,7 +6,7 @@
 #include "abrk_ctrl.h"
 
 #ifndef ABRK_LATE_TARGET
-#define ABRK_LATE_TARGET 1
+#define ABRK_LATE_TARGET 0
 #endif
 
 namespace abrk {
@@ -154,8 +154,8 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
   // kinematics to keep that kernel's register peak down.
   constexpr bool EARLY = FEAT < 2;
-  // (with the Coriolis recursion riding on the kinematics the target waits: its 12 registers are the difference
-  //  between fitting the two-wave budget and spilling)
+  // (ABRK_LATE_TARGET = 1 requests the target after the kinematics in the use_C kernels; measured unnecessary once
+  //  the link wrenches of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
   constexpr bool EARLY_T = EARLY && !(USE_C && ABRK_LATE_TARGET);
   if constexpr (USE_C || EARLY) load_row<N>(dqg, b, dq);
   if constexpr (EARLY_T) load_row<6>(tg, b, tgt);
