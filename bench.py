@@ -299,7 +299,8 @@ def concurrent_streams_rate(workload, B, device, n_streams, steps, graph_steps=1
 def _profiled(fname, kernel, batch):
     """(entry, "profiles/<round>/<fname>", commit the profile was taken at) of the committed rocprofv3 evidence for this
     (kernel, rows per launch) - or (None, None, None)"""
-    key = f"{kernel.replace(' ', '')}:{batch}"
+    kn = kernel.replace(' ', '')
+    key = f"{kn}:{batch}"
     for rnd in PROFILE_DIRS:
         path = os.path.join(REPO, "profiles", rnd, fname)
         try:
@@ -307,7 +308,11 @@ def _profiled(fname, kernel, batch):
         except (OSError, ValueError):
             continue
         if key in d:
-            return d[key], f"profiles/{rnd}/{fname}", d.get("_commit")
+            return dict(d[key], rows=batch), f"profiles/{rnd}/{fname}", d.get("_commit")
+        # the same kernel profiled at another HBM-sized batch: per-row figures carry over (the caller rescales)
+        same = sorted(((int(k.rsplit(":", 1)[1]), k) for k in d if k.startswith(kn + ":")), reverse=True)
+        if same and same[0][0] >= (1 << 20) and batch >= (1 << 20):
+            return dict(d[same[0][1]], rows=same[0][0]), f"profiles/{rnd}/{fname} (profiled at {same[0][0]} rows)", d.get("_commit")
     return None, None, None
 
 
@@ -317,7 +322,7 @@ def profiled_traffic(kernel, batch):
     t, src, commit = _profiled("traffic.json", kernel, batch)
     if t is None:
         return None, None, None
-    return round(t["read_bytes"] + t["write_bytes"], 1), src, commit
+    return round((t["read_bytes"] + t["write_bytes"]) * batch / t["rows"], 1), src, commit
 
 
 def roofline(runner, ms_per_launch, label):

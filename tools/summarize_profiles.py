@@ -97,11 +97,14 @@ if rows:
              "wave_cycles_per_wave": float(4 * r["SQ_WAVE_CYCLES"] / w),
              "busy_cycles": float(r["SQ_BUSY_CYCLES"]) if "SQ_BUSY_CYCLES" in r else None}
         if "GRBM_GUI_ACTIVE" in r and r["GRBM_GUI_ACTIVE"] == r["GRBM_GUI_ACTIVE"] and (k, int(gsz)) in durs:
-            e["clock_ghz"] = round(float(r["GRBM_GUI_ACTIVE"]) / durs[(k, int(gsz))], 3)
+            # GRBM_GUI_ACTIVE is summed over the 8 XCDs: shader clock = counter / 8 / kernel duration (of these short
+            # PMC passes - the first launches after idle run above the sustained clock)
+            gui = float(r["GRBM_GUI_ACTIVE"]) / 8.0
+            e["clock_ghz"] = round(gui / durs[(k, int(gsz))], 3)
             # issue utilisation: executed VALU issue cycles (4 per fp64 wave-instruction, 2 per fp32) of all waves over
-            # the SIMD-cycles the kernel was resident (1024 SIMDs x GRBM_GUI_ACTIVE)
+            # the SIMD-cycles the kernel was resident (1024 SIMDs x active cycles)
             cyc = 4 if "double" in k else 2
-            e["issue_util"] = round(float(r["SQ_INSTS_VALU"]) * cyc / (1024 * float(r["GRBM_GUI_ACTIVE"])), 4)
+            e["issue_util"] = round(float(r["SQ_INSTS_VALU"]) * cyc / (1024 * gui), 4)
         counters[f"{k.replace(' ', '')}:{int(gsz)}"] = e
     json.dump(counters, open(os.path.join(dst, "counters.json"), "w"), indent=1)
     for (k, gsz), r in piv.iterrows():
