@@ -525,7 +525,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
                       const T (&cvec)[N], const T (&Jv)[N][3], const T (&Jw)[N][3], const T (&p)[3],
                       const T (&RF)[9], const T (&q)[N], const T (&dq)[N], const T (&tgt)[6], bool tv_given,
                       const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext, const T (&une)[N],
-                      T (&u)[N], T (&ts)[N]) {
+                      T (&u)[N], T (&ts)[N], bool* defer = nullptr) {
   constexpr bool FAST = (KM <= 3);
   T Jr[N][KM];
   bool sel[KM];
@@ -583,6 +583,11 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
         truncates = false;
         mx_explicit = true;
       }
+    }
+    if (truncates && defer) {
+      // the caller works such rows off in a second, dense pass (u, ts, ierr are left untouched here)
+      *defer = true;
+      return;
     }
     if (truncates) {
       T S[KM * (KM + 1) / 2], V[KM][KM], lam[KM];
@@ -799,13 +804,13 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   late();
   if constexpr (TWO_PASS)
     osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
-                                  ierr, have_ext, une, u, ts);
+                                  ierr, have_ext, une, u, ts, scr.defer_ptr());
   else if constexpr (USE_C)
     osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
-                                  ierr, have_ext, une, u, ts);
+                                  ierr, have_ext, une, u, ts, scr.defer_ptr());
   else  // no Coriolis vector: the slot is not read (d.gz stands in for the array type)
     osc_law<N, T, KM, false, FEAT>(P, d.Ms, d.gz, T(9.81), d.gz, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin,
-                                   have_ierr, ierr, have_ext, une, u, ts);
+                                   have_ierr, ierr, have_ext, une, u, ts, scr.defer_ptr());
 }
 
 // ---------------------------------------------------------------- Sliding.generate, one row (sliding.py:34-99)

@@ -921,8 +921,16 @@ ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, 
 // Per-lane scratch that carries the link wrenches from the forward to the backward sweep of coriolis_rne.
 // RegScratch: plain arrays (host check build, small arms).  The GPU kernels use LdsScratch (abrk_kernels.h): 6 values
 // per link parked in the wavefront's LDS slab, which keeps 12 N VGPRs free while the recursion runs.
+// Deferral of the rare expensive branch of the law (the Jacobi eigen-decomposition behind a truncating pinv): when the
+// kernel allows it, the row program raises `deferred` instead of running the sweeps; the kernel then parks the row
+// index in a worklist that a second, densely packed pass works off (abrk_kernels.h osc_kernel, modes 1 / 2).  Lanes
+// diverge otherwise: one such row makes its whole wavefront run the sweeps.
+struct ScratchBase {
+  bool allow_defer = false, deferred = false;
+  ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
+};
 template <class T, int N>
-struct RegScratch {
+struct RegScratch : ScratchBase {
   static constexpr bool kHasTab = false;  // no sin/cos table: the polynomial routine
   T f[N][3], t[N][3];
   template <int K>

@@ -451,6 +451,7 @@ struct Recorder {
   hipStream_t stream = nullptr;
   std::vector<std::function<hipError_t()>> steps;
   std::vector<std::unique_ptr<std::vector<unsigned char>>> tables;  // stable addresses
+  std::vector<void*> dev_bufs;  // device scratch owned by the plan (worklists of the six-row OSC kernels)
 };
 thread_local Recorder* t_rec = nullptr;
 bool recording() { return t_rec != nullptr; }
@@ -478,6 +479,58 @@ int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn) {
   }
   HIPCHK(fn(arm_table(a, dtype)));
   return st.finish();
+}
+
+// Worklist of the six-row OSC kernels (rows whose law needs the Jacobi sweeps are deferred to a dense second pass,
+// abrk_kernels.h): wl_ints(B) ~ B + 20 k ints of device scratch.  Immediate calls take it from a cache keyed by (device, stream) -
+// calls on one stream are ordered, so the buffer can be reused; a recorded plan owns its own.
+struct WorklistSlot {
+  int device;
+  hipStream_t stream;
+  int* buf;
+  size_t cap;
+};
+std::mutex g_wl_mu;
+std::vector<WorklistSlot> g_wl_cache;
+int* worklist_for(int device, hipStream_t stream, int64_t B) {
+  static const bool off = getenv("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
+  // below ~16 k rows the second launch costs more than the divergence it removes (B = 4096: 32 -> 38 us per step)
+  if (off || B < 16384) return nullptr;
+  const size_t need = (size_t)wl_ints(B) * sizeof(int);
+  if (Recorder* r = t_rec) {
+    void* p = nullptr;
+    if (hipMalloc(&p, need) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;  // no scratch: the kernel runs the sweeps inline
+    }
+    r->dev_bufs.push_back(p);
+    return (int*)p;
+  }
+  std::lock_guard<std::mutex> lk(g_wl_mu);
+  WorklistSlot* s = nullptr;
+  for (auto& e : g_wl_cache)
+    if (e.device == device && e.stream == stream) s = &e;
+  if (!s) {
+    if (g_wl_cache.size() >= 64) return nullptr;  // many short-lived streams: do not hoard scratch
+    g_wl_cache.push_back({device, stream, nullptr, 0});
+    s = &g_wl_cache.back();
+  }
+  if (s->cap < need) {
+    if (s->buf) {
+      (void)hipStreamSynchronize(stream);  // a launch in flight may still use the old buffer
+      (void)hipFree(s->buf);
+    }
+    s->buf = nullptr;
+    s->cap = 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, need + need / 4) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    s->buf = (int*)p;
+    s->cap = need + need / 4;
+  }
+  return s->buf;
 }
 
 int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
@@ -609,6 +662,7 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   oa.ts = st.fix(ts_, training_signal);
   oa.use_C = P->use_C ? 1 : 0;
   oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
+  if (oa.fast == 0 && !want) oa.wl = worklist_for(device, (hipStream_t)stream, B);
   const OscP<double> p64 = make_oscp<double>(*P, n);
   const OscP<float> p32 = make_oscp<float>(*P, n);
   const ArmOps* ops = a->ops;
@@ -1259,6 +1313,7 @@ struct Plan {
   hipStream_t stream = nullptr;
   std::vector<std::function<hipError_t()>> steps;
   std::vector<std::unique_ptr<std::vector<unsigned char>>> tables;
+  std::vector<void*> dev_bufs;
   hipError_t enqueue() const {
     for (const auto& f : steps) {
       hipError_t e = f();
@@ -1315,7 +1370,17 @@ int register_plan(Plan* pl) {
   __atomic_store_n(&g_plans[slot], pl, __ATOMIC_RELEASE);
   return pl->id;
 }
+void free_dev_bufs(int device, std::vector<void*>& bufs) {
+  if (bufs.empty()) return;
+  if (hipSetDevice(device) == hipSuccess) {
+    t_current_device = device;
+    for (void* p : bufs) (void)hipFree(p);
+  }
+  (void)hipGetLastError();
+  bufs.clear();
+}
 void abort_recording() {
+  if (t_rec) free_dev_bufs(t_rec->device, t_rec->dev_bufs);
   delete t_rec;
   t_rec = nullptr;
 }
@@ -1346,6 +1411,8 @@ extern "C" int abrk_plan_end(void) {
   pl->stream = t_rec->stream;
   pl->steps = std::move(t_rec->steps);
   pl->tables = std::move(t_rec->tables);
+  pl->dev_bufs = std::move(t_rec->dev_bufs);
+  t_rec->dev_bufs.clear();
   abort_recording();
   return register_plan(pl);
 }
@@ -1422,6 +1489,7 @@ extern "C" int abrk_plan_destroy(int plan) {
   g_plan_gen[slot] = (g_plan_gen[slot] + 1) & kGenMask;
   g_plan_free.push_back(slot);
   pl->drop_graph();
+  free_dev_bufs(pl->device, pl->dev_bufs);
   delete pl;
   return 0;
 }

@@ -110,7 +110,7 @@ struct TabScratch : RegScratch<T, N> {
   const double* sctab;
 };
 template <class T, int N>
-struct LdsScratch {
+struct LdsScratch : ScratchBase {
   static constexpr bool kHasTab = (ABRK_SINCOS_TABLE != 0);
   using V2 = T __attribute__((ext_vector_type(2)));
   V2* slab;  // [N][3][kBlock]
@@ -139,28 +139,67 @@ struct LdsScratch {
   }
 };
 
+// Worklist of deferred rows: kWlLists sub-lists (wavefront w appends to sub-list w mod kWlLists), each with its own
+// counter on its own 64-byte line - one shared counter serialises at ~90 atomics per microsecond, which at 8 M rows
+// (125 k wavefronts with a deferred row) cost 1.4 ms, three times the arithmetic.
+constexpr int kWlLists = 256;
+constexpr long wl_capacity(long B) { return ((B + kBlock - 1) / kBlock / kWlLists + 1) * kBlock; }  // rows per sub-list
+constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(B); }
+// `mode`: 0 = every row start to finish; 1 = rows whose law needs the Jacobi eigen-decomposition (a truncating pinv that
+// neither certificate excludes) only leave their index in the worklist `wl`; 2 = work that list off, densely packed
+// (persistent grid: block b strides sub-list b mod kWlLists).  Lanes diverge, so in mode 0 one such row costs its whole wavefront
+// the sweeps - with all six task rows that is most wavefronts (9340 executed instructions per row on UR5 against
+// ~1700 without the sweeps).
 template <class A, class T, int KM, bool USE_C, int FEAT>
 __global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
-           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg) {
+           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl) {
   constexpr bool kTab = std::is_same<T, double>::value && (ABRK_SINCOS_TABLE != 0);
+  constexpr bool kLds = USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0);
   __shared__ double sctab[kTab ? 2 * kSinCosN : 1];
-  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);  // every lane takes part: before the row-index exit
-  if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
-    using V2 = typename LdsScratch<T, A::N>::V2;
-    __shared__ V2 slab[A::N * 3 * kBlock];
-    ABRK_ROW_INDEX
-    LdsScratch<T, A::N> scr{slab, (int)threadIdx.x, sctab};
-    osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
-  } else if constexpr (kTab) {
-    ABRK_ROW_INDEX
-    TabScratch<T, A::N> scr;
-    scr.sctab = sctab;
-    osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);  // every lane takes part: before any exit
+  using V2 = typename LdsScratch<T, A::N>::V2;
+  __shared__ V2 slab[kLds ? A::N * 3 * kBlock : 1];
+  auto row = [&](long b, bool allow_defer) ABRK_LAMBDA {
+    auto go = [&](auto& scr) ABRK_LAMBDA {
+      scr.allow_defer = allow_defer;
+      osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+      if (scr.deferred) {
+        const int sub = (int)(blockIdx.x % kWlLists);
+        wl[16 * kWlLists + sub * wl_capacity(B) + atomicAdd(wl + 16 * sub, 1)] = (int)b;
+      }
+    };
+    if constexpr (kLds) {
+      LdsScratch<T, A::N> scr;
+      scr.slab = slab;
+      scr.lane = (int)threadIdx.x;
+      scr.sctab = sctab;
+      go(scr);
+    } else if constexpr (kTab) {
+      TabScratch<T, A::N> scr;
+      scr.sctab = sctab;
+      go(scr);
+    } else {
+      RegScratch<T, A::N> scr;
+      go(scr);
+    }
+  };
+  if constexpr (KM == 6) {
+    // one call site for the row program (it is inlined): modes 0 / 1 launch one lane per row and leave the loop after
+    // their row, mode 2 strides a persistent grid over the worklist.  (Only the six-row kernels defer: with x,y,z
+    // alone the two certificates leave < 0.01 % of the rows to the sweeps, and the loop form costs the three-row
+    // kernels 40 registers.)
+    const bool list = mode == 2;
+    const int sub = (int)(blockIdx.x % kWlLists);
+    const int* rows = wl + 16 * kWlLists + sub * wl_capacity(B);
+    const long n = list ? (long)wl[16 * sub] : B;
+    const long first = list ? (long)(blockIdx.x / kWlLists) * kBlock + threadIdx.x : (long)blockIdx.x * kBlock + threadIdx.x;
+    const long step = list ? (long)(gridDim.x / kWlLists) * kBlock : (long)gridDim.x * kBlock;
+    for (long i = first; i < n; i += step) row(list ? (long)rows[i] : i, mode == 1);
   } else {
     ABRK_ROW_INDEX
-    osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg);
+    row(b, false);
   }
 }
 
@@ -182,7 +221,10 @@ osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __r
   if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);
   if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
     using V2 = typename LdsScratch<T, A::N>::V2;
-    LdsScratch<T, A::N> scr{reinterpret_cast<V2*>(slab), (int)threadIdx.x, sctab};
+    LdsScratch<T, A::N> scr;
+    scr.slab = reinterpret_cast<V2*>(slab);
+    scr.lane = (int)threadIdx.x;
+    scr.sctab = sctab;
     osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
   } else if constexpr (kTab) {
     TabScratch<T, A::N> scr;
@@ -357,6 +399,7 @@ struct OscArgs {
   int fast, use_C;  // fast: 0 general six-row kernel, 2 / 3: first two / three position rows of the EE
   const void *q, *dq, *target, *tv, *une;
   void *ierr, *u, *ts;
+  int* wl = nullptr;  // worklist of B + 1 ints: rows that need the Jacobi sweeps are deferred to a dense second pass
   unsigned want = 0;  // != 0: the fused Mode-F kernel also writes Tx / J / M / g (W_TX | W_J | W_M | W_G)
   void* out[4] = {nullptr, nullptr, nullptr, nullptr};
 };
@@ -405,9 +448,18 @@ struct Launch {
   }
   template <int KM, bool UC, int FEAT>
   static void osc_launch(const LaunchArgs& la, const OscArgs& a) {
-    hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
-                       *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
-                       (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts);
+    auto go = [&](dim3 grid, int mode) {
+      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
+                         *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
+                         (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl);
+    };
+    if (a.wl && KM == 6) {
+      (void)hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream);
+      go(grid_for(la.B), 1);
+      go(dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
+    } else {
+      go(grid_for(la.B), 0);
+    }
   }
   template <int KM, bool UC>
   static void osc_launch_feat(const LaunchArgs& la, const OscArgs& a) {

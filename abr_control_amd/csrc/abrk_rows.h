@@ -170,6 +170,7 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
     else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
   };
   osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr);
+  if (scr.deferred) return;  // parked for the dense second pass: nothing of this row is written yet
   store_row<N>(ug, b, u);
   if (tsg) store_row<N>(tsg, b, ts);
   if (have_ierr) store_row<6>(ierrg, b, ierr);
