@@ -752,7 +752,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   int m = N;
   // sin/cos of the joint angles: through the kernel's LDS table where it keeps one (fp64 OSC kernels on the GPU)
   auto sincos_policy = [&]() ABRK_LAMBDA {
-    if constexpr (std::remove_reference<Scr>::type::kHasTab && std::is_same<T, double>::value) return ScTab{scr.sctab};
+    if constexpr (std::remove_reference<Scr>::type::kHasTab) return ScTab{scr.sctab};
     else return ScCompute{};
   };
   auto dynamics_pass = [&](auto& cap_) ABRK_LAMBDA {
@@ -814,10 +814,11 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
 }
 
 // ---------------------------------------------------------------- Sliding.generate, one row (sliding.py:34-99)
-template <class A, class T>
+// sctab: the kernel's sin/cos table in LDS, or nullptr (host check build: polynomial / library routine)
+template <class A, class T, bool TAB = false>
 ABRK_INL void sliding_row(const A& arm, const SlidingP<T>& P, const T (&q)[A::N], const T (&dq)[A::N],
                           const T (&tgt)[A::N > 3 ? A::N : 3], const T (&tv)[A::N > 3 ? A::N : 3],
-                          const T (&ta)[A::N > 3 ? A::N : 3], T (&u)[A::N], T (&s)[A::N]) {
+                          const T (&ta)[A::N > 3 ? A::N : 3], T (&u)[A::N], T (&s)[A::N], const void* sctab = nullptr) {
   constexpr int N = A::N;
   Joints<A, T> jt;
   Dyn<A, T, CMODE_MAT> d;
@@ -826,7 +827,8 @@ ABRK_INL void sliding_row(const A& arm, const SlidingP<T>& P, const T (&q)[A::N]
   cap.frame = P.ref_frame;
   sfor<9>([&](auto e) ABRK_LAMBDA { cap.R[e()] = T(0); });
   sfor<3>([&](auto r) ABRK_LAMBDA { cap.o[r()] = T(0); });
-  kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
+  if constexpr (TAB) kin_dyn_hook(arm, q, dq, jt, d, XR, xo, cap, [](auto, const T(&)[3]) ABRK_LAMBDA {}, ScTab{sctab});
+  else kin_dyn(arm, q, dq, jt, d, XR, xo, cap);
   T dq_ref[N], ddq_ref[N];
   if (P.cartesian) {
     T p[3];

@@ -87,6 +87,7 @@ struct Rm<double> {
     sincos_fast(x, s, c);
   }
   static ABRK_INL bool sincos_in_range(double x) { return ::fabs(x) < 1.0e5; }
+  static ABRK_INL bool sincos_tab_in_range(double x) { return ::fabs(x) < 1.0e5; }
   // the branch-free main path (valid for |x| < 1e5)
   static ABRK_INL void sincos_fast(double x, double& s, double& c) {
     const double n = ::rint(x * 0.6366197723675814);
@@ -121,7 +122,7 @@ struct Rm<double> {
   //   sin x = S cos r + C sin r,  cos x = C cos r - S sin r
   // with Taylor polynomials of degree 7 / 6 in r (truncation < 1e-20): 16 fp64 + 3 integer instructions and one
   // 16-byte LDS read against 25 + 10 of the polynomial routine above.  Absolute error <= 3e-16.
-  static ABRK_INL void sincos_tab(double x, const double* tab, double& s, double& c) {
+  static ABRK_INL void sincos_tab(double x, const void* tab, double& s, double& c) {
     const double n = ::rint(x * kSinCosInvStep);
     double r = ::fma(-n, kSinCosD1, x);
     r = ::fma(-n, kSinCosD2, r);
@@ -174,9 +175,27 @@ struct Rm<double> {
 template <>
 struct Rm<float> {
   static ABRK_INL void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }  // a custom routine measured no faster
-  static ABRK_INL bool sincos_in_range(float) { return true; }
+  static ABRK_INL bool sincos_in_range(float) { return true; }  // the library routine serves every argument
+  static ABRK_INL bool sincos_tab_in_range(float x) { return ::fabsf(x) < 1.0e5f; }
   static ABRK_INL void sincos_fast(float x, float& s, float& c) { ::sincosf(x, &s, &c); }
-  static ABRK_INL void sincos_tab(float x, const double*, float& s, float& c) { ::sincosf(x, &s, &c); }
+  // fp32 form of the table-driven routine (tab: [128][2] floats in LDS): ~16 instructions against ~40 of the library's
+  // sincosf; |x| < 1e5 (n < 2^21; the three-term split of 2 pi / 128 under fma keeps the reduced argument to ~2e-9),
+  // Taylor degree 3 / 4 in r (|r| <= pi/128: truncation 7e-11).  Absolute error ~1e-7 = fp32 rounding.
+  static ABRK_INL void sincos_tab(float x, const void* tab, float& s, float& c) {
+    const float n = ::rintf(x * (float)kSinCosInvStep);
+    constexpr float d1 = (float)(kSinCosD1 + kSinCosD2);
+    constexpr float d2 = (float)((kSinCosD1 - (double)d1) + kSinCosD2);
+    float r = ::fmaf(-n, d1, x);
+    r = ::fmaf(-n, d2, r);
+    const int k = (int)n & (kSinCosN - 1);
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 sc = reinterpret_cast<const f2*>(tab)[k];
+    const float z = r * r;
+    const float ss = ::fmaf(z * r, -1.66666667e-01f, r);
+    const float cc = ::fmaf(z, ::fmaf(z, 4.16666667e-02f, -0.5f), 1.0f);
+    s = ::fmaf(sc.x, cc, sc.y * ss);
+    c = ::fmaf(sc.y, cc, -(sc.x * ss));
+  }
   static ABRK_INL float sqrt(float x) { return ::sqrtf(x); }
   static ABRK_INL float fabs(float x) { return ::fabsf(x); }
   static ABRK_INL float fma(float a, float b, float c) { return ::fmaf(a, b, c); }
@@ -496,7 +515,7 @@ struct ScUse {
 
 // sin/cos through the LDS table of the calling kernel (Rm<double>::sincos_tab); fp32 rows keep the library routine
 struct ScTab {
-  const double* tab;
+  const void* tab;  // [128][2] of the kernel's arithmetic type
 };
 // sin/cos of all joint angles ahead of the chain: one straight-line block of N independent polynomial
 // evaluations (the per-joint range check would split the forward kinematics into N basic blocks and serialise
@@ -511,10 +530,10 @@ ABRK_INL void sincos_all(const T (&q)[N], T (&sv)[N][2]) {
   if (!all_in) sfor<N>([&](auto i) ABRK_LAMBDA { Rm<T>::sincos(q[i()], sv[i()][0], sv[i()][1]); });
 }
 template <int N, class T>
-ABRK_INL void sincos_all_tab(const T (&q)[N], T (&sv)[N][2], const double* tab) {
+ABRK_INL void sincos_all_tab(const T (&q)[N], T (&sv)[N][2], const void* tab) {
   bool all_in = true;
   sfor<N>([&](auto i) ABRK_LAMBDA {
-    all_in = all_in && Rm<T>::sincos_in_range(q[i()]);
+    all_in = all_in && Rm<T>::sincos_tab_in_range(q[i()]);
     Rm<T>::sincos_tab(q[i()], tab, sv[i()][0], sv[i()][1]);
   });
   if (!all_in) sfor<N>([&](auto i) ABRK_LAMBDA { Rm<T>::sincos(q[i()], sv[i()][0], sv[i()][1]); });

@@ -93,13 +93,17 @@ constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho) {
 #ifndef ABRK_SINCOS_TABLE
 #define ABRK_SINCOS_TABLE 1
 #endif
-// The wavefront's copy of the sin/cos table (abrk_sincos_table.h, 2 KiB): two entries per lane, from L2
-__device__ __forceinline__ void load_sincos_table(double* tab, int lane) {
+// The wavefront's copy of the sin/cos table (abrk_sincos_table.h; 2 KiB in fp64, 1 KiB in fp32): two entries per
+// lane, from L2
+template <class T>
+__device__ __forceinline__ void load_sincos_table(T* tab, int lane) {
   typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef T t2 __attribute__((ext_vector_type(2)));
   const d2* src = reinterpret_cast<const d2*>(&kSinCosTab[0][0]);
-  d2* dst = reinterpret_cast<d2*>(tab);
-  dst[lane] = src[lane];
-  dst[lane + kBlock] = src[lane + kBlock];
+  t2* dst = reinterpret_cast<t2*>(tab);
+  const d2 a = src[lane], b = src[lane + kBlock];
+  dst[lane] = t2{(T)a.x, (T)a.y};
+  dst[lane + kBlock] = t2{(T)b.x, (T)b.y};
   __syncthreads();
 }
 static_assert(kBlock == 64 && kSinCosN == 128, "two table entries per lane");
@@ -107,7 +111,7 @@ static_assert(kBlock == 64 && kSinCosN == 128, "two table entries per lane");
 template <class T, int N>
 struct TabScratch : RegScratch<T, N> {
   static constexpr bool kHasTab = true;
-  const double* sctab;
+  const void* sctab;
 };
 template <class T, int N>
 struct LdsScratch : ScratchBase {
@@ -115,7 +119,7 @@ struct LdsScratch : ScratchBase {
   using V2 = T __attribute__((ext_vector_type(2)));
   V2* slab;  // [N][3][kBlock]
   int lane;
-  const double* sctab;
+  const void* sctab;
   template <int K>
   __device__ __forceinline__ void put(ic<K>, const T (&fv)[3], const T (&tv)[3]) {
     slab[(K * 3 + 0) * kBlock + lane] = V2{fv[0], fv[1]};
@@ -155,9 +159,9 @@ __global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrt
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl) {
-  constexpr bool kTab = std::is_same<T, double>::value && (ABRK_SINCOS_TABLE != 0);
+  constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
   constexpr bool kLds = USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0);
-  __shared__ double sctab[kTab ? 2 * kSinCosN : 1];
+  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
   if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);  // every lane takes part: before any exit
   using V2 = typename LdsScratch<T, A::N>::V2;
   __shared__ V2 slab[kLds ? A::N * 3 * kBlock : 1];
@@ -216,8 +220,8 @@ osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __r
   const long row0 = (long)blockIdx.x * kBlock;
   const long b = row0 + threadIdx.x;
   LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
-  constexpr bool kTab = std::is_same<T, double>::value && (ABRK_SINCOS_TABLE != 0);
-  __shared__ double sctab[kTab ? 2 * kSinCosN : 1];
+  constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
+  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
   if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);
   if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
     using V2 = typename LdsScratch<T, A::N>::V2;
@@ -241,9 +245,16 @@ __global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 sliding_kernel(A arm, SlidingP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                const T* __restrict__ tg, const T* __restrict__ tvg, const T* __restrict__ tag,
                T* __restrict__ ug, T* __restrict__ sg) {
-  ABRK_ROW_INDEX
-  sliding_body<A, T>(b, arm, P, B, qg, dqg, tg, tvg, tag, ug, sg);
+  constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
+  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
+  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);
+  // grid-stride over the row blocks (the launcher caps the grid at kSlidingMaxBlocks): a threejoint fp32 wavefront
+  // lives ~5 us, and one-wavefront workgroups are dispatched at ~1.1 per ns chip-wide - too slowly to keep the 7
+  // wavefronts per SIMD this kernel could hold resident (8 M rows: 131 k dispatches)
+  for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < B; b += (long)gridDim.x * kBlock)
+    sliding_body<A, T, kTab>(b, arm, P, B, qg, dqg, tg, tvg, tag, ug, sg, sctab);
 }
+constexpr long kSlidingMaxBlocks = 256L * 32 * 4;  // four rounds of a full chip of wavefronts
 
 template <class A, class T>
 __global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
@@ -515,7 +526,9 @@ struct Launch {
     return hipGetLastError();
   }
   static hipError_t sliding(const LaunchArgs& la, const SlidingArgs& a) {
-    hipLaunchKernelGGL((sliding_kernel<A, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
+    const long blocks = (la.B + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((sliding_kernel<A, T>), dim3((unsigned)(blocks < kSlidingMaxBlocks ? blocks : kSlidingMaxBlocks)),
+                       dim3(kBlock), 0, la.stream, arm_of(la),
                        *static_cast<const SlidingP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq,
                        (const T*)a.target, (const T*)a.tv, (const T*)a.ta, (T*)a.u, (T*)a.s);
     return hipGetLastError();

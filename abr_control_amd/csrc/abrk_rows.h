@@ -285,10 +285,10 @@ ABRK_INL void osc_law_body(long b, const OscP<T>& P, long B, const T* __restrict
 }
 
 // ---- Sliding.generate for B states (sliding.py:34-99)
-template <class A, class T>
+template <class A, class T, bool TAB = false>
 ABRK_INL void sliding_body(long b, const A& arm, const SlidingP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                const T* __restrict__ tg, const T* __restrict__ tvg, const T* __restrict__ tag,
-               T* __restrict__ ug, T* __restrict__ sg) {
+               T* __restrict__ ug, T* __restrict__ sg, const void* sctab = nullptr) {
   constexpr int N = A::N;
   constexpr int NT = N > 3 ? N : 3;
   T q[N], dq[N], tgt[NT], tv[NT], ta[NT], u[N], s[N];
@@ -301,7 +301,7 @@ ABRK_INL void sliding_body(long b, const A& arm, const SlidingP<T>& P, long B, c
     tv[i()] = (in && tvg) ? tvg[b * nt + i()] : T(0);
     ta[i()] = (in && tag) ? tag[b * nt + i()] : T(0);
   });
-  sliding_row<A, T>(arm, P, q, dq, tgt, tv, ta, u, s);
+  sliding_row<A, T, TAB>(arm, P, q, dq, tgt, tv, ta, u, s, sctab);
   store_row<N>(ug, b, u);
   if (sg) store_row<N>(sg, b, s);
 }
