@@ -63,6 +63,7 @@ def lib():
         L.abrk_plan_begin.argtypes = [C.c_int, _vp]
         L.abrk_plan_launch.argtypes = [C.c_int]
         L.abrk_plan_launch_graph.argtypes = [C.c_int, C.c_int]
+        L.abrk_plan_launch_repeat.argtypes = [C.c_int, C.c_int]
         L.abrk_plan_destroy.argtypes = [C.c_int]
         L.abrk_ik_generate_path_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.IkParams), _i64, _vp, _vp, _vp, _vp,
                                                   C.c_int, _vp]

@@ -1456,6 +1456,18 @@ extern "C" int abrk_plan_launch(int plan) {
   return 0;
 }
 
+extern "C" int abrk_plan_launch_repeat(int plan, int repeat) {
+  Plan* pl = find_plan(plan);
+  if (!pl) return fail(ABRK_EINVAL, "unknown plan %d", plan);
+  if (repeat < 1) return fail(ABRK_EINVAL, "repeat must be >= 1");
+  if (t_current_device != pl->device) {
+    HIPCHK(hipSetDevice(pl->device));
+    t_current_device = pl->device;
+  }
+  for (int i = 0; i < repeat; i++) HIPCHK(pl->enqueue());
+  return 0;
+}
+
 extern "C" int abrk_plan_launch_graph(int plan, int repeat) {
   Plan* pl = find_plan(plan);
   if (!pl) return fail(ABRK_EINVAL, "unknown plan %d", plan);

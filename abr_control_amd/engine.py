@@ -445,6 +445,10 @@ class Plan:
         """`repeat` consecutive launches as one hipGraph launch (needs a plan on an explicit stream)"""
         check(lib().abrk_plan_launch_graph(self.id, int(repeat)))
 
+    def launch_repeat(self, repeat):
+        """`repeat` consecutive plain launches enqueued by one C call (abrk_plan_launch_repeat)"""
+        check(lib().abrk_plan_launch_repeat(self.id, int(repeat)))
+
     def close(self):
         pid, self.id = self.id, None
         if pid is not None:

@@ -249,6 +249,9 @@ int abrk_plan_end(void);
 int abrk_plan_abort(void);
 int abrk_plan_count(void); /* live plans */
 int abrk_plan_launch(int plan);
+/* `repeat` consecutive plain launches of the plan enqueued by ONE call (no per-launch crossing of the language
+ * boundary): for a few tens of ticks this beats the fixed cost of a graph launch.                              */
+int abrk_plan_launch_repeat(int plan, int repeat);
 /* `repeat` consecutive launches of the plan as ONE hipGraph launch (captured on first use and cached per
  * repeat count): removes the per-launch host work and tightens the dependent-launch gaps of short kernels. */
 int abrk_plan_launch_graph(int plan, int repeat);
