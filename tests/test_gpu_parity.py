@@ -1267,7 +1267,8 @@ def test_gpu_wave_cooperative_variant_matches_reference_and_lane_per_arm(lanes):
 
 
 # ---------------------------------------------------------------------------- six-row law: Jacobi rows deferred to a dense pass
-def test_gpu_six_row_deferred_pass_equals_inline_sweeps():
+@pytest.mark.parametrize("variant", ["static", "rt"])
+def test_gpu_six_row_deferred_pass_equals_inline_sweeps(variant):
     """With all six task rows most wavefronts hold a row whose pinv truncates; those rows are parked in a worklist and
     worked off by a second, densely packed pass (abrk_kernels.h osc_kernel modes 1 / 2).  Batches below 16384 rows run
     the sweeps inline: chunked calls must reproduce the one big call bit for bit - u, training signal and the per-row
@@ -1275,7 +1276,7 @@ def test_gpu_six_row_deferred_pass_equals_inline_sweeps():
     import abr_control_amd as a
     from abr_control_amd import engine
 
-    be = cases.GpuBackend("ur5")
+    be = cases.GpuBackend("ur5", variant)
     B = 40000
     q, dq, t = draw(97, B, 6)
     for kw in (dict(kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6),
@@ -1318,3 +1319,39 @@ def test_gpu_six_row_deferred_pass_equals_inline_sweeps():
             s.sync()
             assert np.array_equal(u.numpy(), u_big)
             plan.close()
+
+
+def test_gpu_table_sincos_negative_and_large_angles():
+    """the OSC / Sliding kernels take sin/cos through the 128-entry LDS table (abrk_sincos_table.h): negative angles,
+    angles up to the routine's range (|q| < 1e5; beyond it the library path), fp64 and fp32, builtin and user arms,
+    against the oracle (libm)"""
+    from oracle.oracle import Oracle
+
+    o = Oracle(_abi.load_table("ur5"))
+    rng = np.random.RandomState(123)
+    B = 4000
+    dq, t = rng.uniform(-2, 2, (B, 6)), rng.uniform(-0.8, 0.8, (B, 6))
+    p = _abi.make_osc_params(6, kp=200, use_C=True)
+    for scale in (7.0, 1e3, 9.9e4, 3e5):
+        q = rng.uniform(-scale, scale, (B, 6))
+        q[0] = 0.0
+        q[1] = -np.pi / 128 * np.arange(1, 7)          # table nodes and half-way points
+        q[2] = np.pi / 256 * (2 * np.arange(1, 7) + 1)
+        uo = o.osc_batch(p, q, dq, t)
+        for variant in ("static", "rt"):
+            u = cases.GpuBackend("ur5", variant).osc(p, q, dq, t)[0]
+            err = cases.rel_err(u, uo)
+            # sin/cos of |q| ~ 1e5 are only defined to ~1e-11 (ulp of the argument); the law amplifies by cond(Mx)
+            tol_med, tol_max = (1e-12, 1e-7) if scale <= 1e3 else (1e-9, 1e-4)
+            assert np.median(err) <= tol_med and np.percentile(err, 99) <= tol_max, (scale, variant, np.median(err), err.max())
+    # fp32 Sliding (config 5's kernel) on negative / moderately large angles vs its fp64 twin
+    be = cases.GpuBackend("threejoint")
+    sp = _abi.make_sliding_params(3)
+    q3, dq3, t3 = rng.uniform(-300, 300, (B, 3)), rng.uniform(-2, 2, (B, 3)), rng.uniform(-1, 1, (B, 3))
+    u64 = be.sliding(sp, q3, dq3, t3)[0]
+    u32 = be.sliding(sp, q3.astype(np.float32), dq3.astype(np.float32), t3.astype(np.float32), dtype=np.float32)[0]
+    q32 = q3.astype(np.float32).astype(float)  # the fp32 kernel sees rounded angles: compare on the same inputs
+    u64r = be.sliding(sp, q32, dq3.astype(np.float32).astype(float), t3.astype(np.float32).astype(float))[0]
+    well = (np.abs(np.sin(q32[:, 1])) > 0.05) & (np.abs(np.sin(q32[:, 2])) > 0.05)
+    assert np.median(cases.rel_err(u32.astype(float), u64r)[well]) < 2e-5
+    assert np.isfinite(u64).all()
