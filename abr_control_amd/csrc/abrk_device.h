@@ -487,21 +487,11 @@ struct NoCap {};
 // ur5/config.py:301-339).  For i = 0..N-1: records joint_i (z, o, W), rotates by q_i,
 // calls on_link(ic<i+1>, p) with the COM position of link_{i+1}.  Leaves in (XR, xo) the
 // rotation of joint_{N-1} after its Rz and its origin - the EE hangs off that.
-// Where sin/cos of the joint angles come from: computed (default), computed and kept, or taken from a
-// previous pass over the same state.
+// Where sin/cos of the joint angles come from: computed in the chain (ScCompute), or handed in ready (ScUse: evaluated
+// ahead of the chain by sincos_all / sincos_all_tab).
 struct ScCompute {
   template <int I, class T>
   ABRK_INL void get(T q, T& s, T& c) const { Rm<T>::sincos(q, s, c); }
-};
-template <class T, int N>
-struct ScSave {
-  T (&sv)[N][2];
-  template <int I>
-  ABRK_INL void get(T q, T& s, T& c) const {
-    Rm<T>::sincos(q, s, c);
-    sv[I][0] = s;
-    sv[I][1] = c;
-  }
 };
 template <class T, int N>
 struct ScUse {
@@ -619,9 +609,9 @@ ABRK_INL void fk_forward(const A& arm, const T (&q)[A::N], Joints<A, T>& jt, T (
 // Lower-triangular index of a symmetric N x N matrix
 constexpr int tri(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
 
-// CMODE_CVONLY: only the Coriolis vector of an orthogonal chain (no M, no g) - the first of two passes of the
-// OSC(use_C) law, which keeps the register peak of the dynamics pass proper at the plain law's level
-enum { CMODE_NONE = 0, CMODE_VEC = 1, CMODE_MAT = 2, CMODE_CVONLY = 3 };
+// CMODE_VEC: C(q,dq) dq accumulated link by link in the same pass as M (general chains; orthogonal chains of the OSC
+// kernels take the recursion of rne_forward_step / rne_backward instead); CMODE_MAT: the full Christoffel matrix
+enum { CMODE_NONE = 0, CMODE_VEC = 1, CMODE_MAT = 2 };
 
 template <class A, class T, int CMODE>
 struct Dyn {
@@ -629,18 +619,15 @@ struct Dyn {
   T Ms[N * (N + 1) / 2];                  // M, lower triangle            (base_config.py:594-645)
   T gz[N];                                // sum_l m_l,z * dp_l,z/dq_i    (g = -9.81 gz, base_config.py:417-468)
   T Cm[CMODE == CMODE_MAT ? N * N : 1];   // Christoffel matrix           (base_config.py:678-727)
-  T cv[(CMODE == CMODE_VEC || CMODE == CMODE_CVONLY) ? N : 1];  // C(q,dq) dq
+  T cv[CMODE == CMODE_VEC ? N : 1];  // C(q,dq) dq
   T om[CMODE != CMODE_NONE ? N : 1][3];   // omega_j = sum_{k<j} dq_k z_k  (orthogonal chains, matrix mode)
   // CMODE_VEC on orthogonal chains: kinematic state of the body the current link belongs to -
   // angular velocity, bias angular acceleration, bias acceleration of the last joint origin
   T bw[3], bal[3], bao[3];
-  // CMODE_CVONLY: bias force of every link and its moment about the world origin (+ the angular term n_l);
-  // projected onto the joint axes by one backward sweep after the chain (coriolis_backward)
-  T lf[CMODE == CMODE_CVONLY ? N : 1][3], lt[CMODE == CMODE_CVONLY ? N : 1][3];
 };
 // the recursive Coriolis-vector path (below) replaces the omega prefix sums
 template <class A, int CM>
-constexpr bool kRecursiveC = (CM == CMODE_VEC || CM == CMODE_CVONLY) && A::kOrtho;
+constexpr bool kRecursiveC = (CM == CMODE_VEC) && A::kOrtho;
 
 // does link L carry linear / any mass?  (static arms: compile time; user arms: assume yes)
 template <class A, int L>
@@ -686,22 +673,17 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
     if constexpr (!(L < A::NL) || !link_has_linear_mass<A, L>()) return;
   }
   if (!live) return;
-  constexpr bool kBackward = (CM == CMODE_CVONLY) && kRecursiveC<A, CM>;
-  T e[kBackward ? 1 : NJ][3];
-  if constexpr (!kBackward) {
-    sfor<NJ>([&](auto i) ABRK_LAMBDA {
-      T dlt[3] = {p[0] - jt.o[i()][0], p[1] - jt.o[i()][1], p[2] - jt.o[i()][2]};
-      wapply<i()>(jt, dlt, e[i()]);
-    });
-  }
+  T e[NJ][3];
+  sfor<NJ>([&](auto i) ABRK_LAMBDA {
+    T dlt[3] = {p[0] - jt.o[i()][0], p[1] - jt.o[i()][1], p[2] - jt.o[i()][2]};
+    wapply<i()>(jt, dlt, e[i()]);
+  });
   T m0 = AccMD<A, T, L, 0>::get(arm), m1 = AccMD<A, T, L, 1>::get(arm), m2 = AccMD<A, T, L, 2>::get(arm);
-  if constexpr (CM != CMODE_CVONLY) {
-    sfor<NJ>([&](auto i) ABRK_LAMBDA {
-      T me[3] = {m0 * e[i()][0], m1 * e[i()][1], m2 * e[i()][2]};  // D_l e_i (transient)
-      d.gz[i()] += me[2];
-      sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = fdot3(d.Ms[tri(i(), j())], me, e[j()]); });
-    });
-  }
+  sfor<NJ>([&](auto i) ABRK_LAMBDA {
+    T me[3] = {m0 * e[i()][0], m1 * e[i()][1], m2 * e[i()][2]};  // D_l e_i (transient)
+    d.gz[i()] += me[2];
+    sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = fdot3(d.Ms[tri(i(), j())], me, e[j()]); });
+  });
   if constexpr (kRecursiveC<A, CM>) {
     // C(q,dq) dq, linear part = sum_l E_l^T D_l a_l with a_l the bias (qdd = 0) acceleration of the COM,
     // from the body recursion instead of per-link suffix sums:
@@ -712,19 +694,7 @@ ABRK_INL void link_accumulate(const A& arm, const Joints<A, T>& jt, const T (&dq
     cross3(d.bal, dl, ad);
     cross3(d.bw, t, wt);
     T ma[3] = {m0 * (d.bao[0] + ad[0] + wt[0]), m1 * (d.bao[1] + ad[1] + wt[1]), m2 * (d.bao[2] + ad[2] + wt[2])};
-    if constexpr (kBackward) {
-      // e_k . ma = z_k . ((p - o_k) x ma): keep the force and its moment about the world origin; the sum over the
-      // links beyond joint k is taken once, backwards (coriolis_backward) - 12 instead of 12 (L) instructions per link
-      static_assert(L >= 1 && L <= A::N, "links beyond the last joint carry no joint-dependent term");
-      T mo[3];
-      cross3(p, ma, mo);
-      sfor<3>([&](auto r) ABRK_LAMBDA {
-        d.lf[L - 1][r()] = ma[r()];
-        d.lt[L - 1][r()] += mo[r()];
-      });
-    } else {
-      sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], e[k()], ma); });
-    }
+    sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], e[k()], ma); });
   } else if constexpr (CM != CMODE_NONE) {
     T s[3] = {T(-0.0), T(-0.0), T(-0.0)};
     T a[3] = {T(-0.0), T(-0.0), T(-0.0)};  // COM bias acceleration  Edot dq
@@ -775,33 +745,7 @@ ABRK_INL void angular_link_coriolis(const A& arm, const Joints<A, T>& jt, Dyn<A,
     n[0] = Rm<T>::fma(I0, d.bal[0], n[0]);
     n[1] = Rm<T>::fma(I1, d.bal[1], n[1]);
     n[2] = Rm<T>::fma(I2, d.bal[2], n[2]);
-    if constexpr (CM == CMODE_CVONLY) {
-      sfor<3>([&](auto r) ABRK_LAMBDA { d.lt[L - 1][r()] += n[r()]; });
-    } else {
-      sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], jt.z[k()], n); });
-    }
-  }
-}
-
-// c_k = z_k . (sum_{l>k} (p_l x f_l + n_l) - o_k x sum_{l>k} f_l): the backward half of the recursion (what the
-// recursive Newton-Euler algorithm does with its link wrenches), after the forward pass has left f_l and the
-// moments in d.lf / d.lt
-template <class A, class T, int CM>
-ABRK_INL void coriolis_backward(const Joints<A, T>& jt, Dyn<A, T, CM>& d) {
-  if constexpr (CM == CMODE_CVONLY && kRecursiveC<A, CM>) {
-    constexpr int N = A::N;
-    T F[3] = {T(0), T(0), T(0)}, Nm[3] = {T(0), T(0), T(0)};
-    sfor<N>([&](auto kr) ABRK_LAMBDA {
-      constexpr int k = N - 1 - kr();
-      sfor<3>([&](auto r) ABRK_LAMBDA {
-        F[r()] += d.lf[k][r()];
-        Nm[r()] += d.lt[k][r()];
-      });
-      T of[3];
-      cross3(jt.o[k], F, of);
-      T w[3] = {Nm[0] - of[0], Nm[1] - of[1], Nm[2] - of[2]};
-      d.cv[k] = dot3(jt.z[k], w);
-    });
+    sfor<NJ>([&](auto k) ABRK_LAMBDA { d.cv[k()] = fdot3(d.cv[k()], jt.z[k()], n); });
   }
 }
 
@@ -836,12 +780,7 @@ ABRK_INL void dyn_init(Dyn<A, T, CM>& d) {
   sfor<N*(N + 1) / 2>([&](auto e) ABRK_LAMBDA { d.Ms[e()] = T(-0.0); });  // -0.0: exact additive identity, lets the first fma fold to a mul
   sfor<N>([&](auto i) ABRK_LAMBDA { d.gz[i()] = T(-0.0); });
   if constexpr (CM == CMODE_MAT) sfor<N * N>([&](auto e) ABRK_LAMBDA { d.Cm[e()] = T(-0.0); });
-  if constexpr (CM == CMODE_VEC || CM == CMODE_CVONLY) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(-0.0); });
-  if constexpr (CM == CMODE_CVONLY) {
-    sfor<N>([&](auto l) ABRK_LAMBDA {
-      sfor<3>([&](auto r) ABRK_LAMBDA { d.lf[l()][r()] = d.lt[l()][r()] = T(0); });
-    });
-  }
+  if constexpr (CM == CMODE_VEC) sfor<N>([&](auto e) ABRK_LAMBDA { d.cv[e()] = T(-0.0); });
 }
 
 // weighted dot  sum_r Isuf(m,r) a[r] b[r]
@@ -856,10 +795,6 @@ ABRK_INL T idot(const A& arm, const T (&a)[3], const T (&b)[3], T acc = T(-0.0))
 template <class A, class T, int CM>
 ABRK_INL void angular_finish(const A& arm, const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, T, CM>& d) {
   constexpr int N = A::N;
-  if constexpr (CM == CMODE_CVONLY) {
-    coriolis_backward(jt, d);
-    return;
-  }
   sfor<N>([&](auto i) ABRK_LAMBDA {
     sfor<i() + 1>([&](auto j) ABRK_LAMBDA { d.Ms[tri(i(), j())] = idot<i()>(arm, jt.z[i()], jt.z[j()], d.Ms[tri(i(), j())]); });
   });

@@ -773,9 +773,12 @@ extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_p
   if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
   if (B == 0) return 0;
   const void* all[] = {q, dq, target, target_velocity, integrated_error, u_null_ext, u, training_signal};
-  for (const void* p : all)
-    if (p && device_view(p) == p)
+  for (const void* p : all) {
+    hipPointerAttribute_t at;
+    if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice)
       return fail(ABRK_EINVAL, "the sharded entry point takes host arrays (a device pointer lives on one device)");
+    (void)hipGetLastError();  // plain malloc'ed memory is "invalid value" to HIP
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
     (void)hipGetLastError();
