@@ -115,6 +115,26 @@ def osc_generate(arm, params, q, dq, target, target_velocity=None, integrated_er
     return (u, ts) if training_signal else u
 
 
+def osc_generate_full(arm, params, q, dq, target, want=("Tx", "J", "M", "g"), target_velocity=None, u_null_ext=None,
+                      dtype=np.float64):
+    """the fused row program (osc_full_body): u, training_signal and the requested robot_config outputs"""
+    name, desc, n = _arm(arm)
+    dt = np.dtype(dtype)
+    q, dq, target = _in(q, dt), _in(dq, dt), _in(target, dt)
+    tv, une = _in(target_velocity, dt), _in(u_null_ext, dt)
+    B = q.shape[0]
+    u, ts = np.full((B, n), np.nan, dt), np.full((B, n), np.nan, dt)
+    do, res, bits = _abi.DynOut(), {}, 0
+    for w in want:
+        res[w] = np.full((B,) + _OUT_SHAPES[w](n), np.nan, dt)
+        setattr(do, w, res[w].ctypes.data)
+        bits |= _WANT_BITS[w]
+    rc = _lib_for(arm).hostsim_osc_full(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq),
+                                        _p(target), _p(tv), None, _p(une), _p(u), _p(ts), C.c_uint32(bits), C.byref(do))
+    assert rc == 0, rc
+    return u, ts, res
+
+
 def sliding_generate(arm, params, q, dq, target, target_velocity=None, target_acc=None, want_s=False,
                      dtype=np.float64):
     name, desc, n = _arm(arm)

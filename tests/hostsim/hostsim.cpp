@@ -79,6 +79,41 @@ int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void
   }
   return 0;
 }
+// the fused "u + Tx, J, M, g" row program (osc_full_body; FEAT 0 / 2 and KM 3 / 6 as Launch::osc_full dispatches)
+template <class A, class T>
+int run_osc_full(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void* q, const void* dq,
+                 const void* tg, const void* tv, void* ie, const void* une, void* u, void* ts, unsigned want,
+                 void* const* outs) {
+  OscP<T> p = make_oscp<T>(*P, n);
+  const int fast = osc_fast_rows(*P, n, une != nullptr);
+  if (P->ki == 0) ie = nullptr;
+  const bool plain = !(tv || ie || une) && p.n_null == 0;
+  DynOutP<T> o{};
+  o.Tx = (T*)outs[0];
+  o.J = (T*)outs[1];
+  o.M = (T*)outs[2];
+  o.g = (T*)outs[3];
+  DirectStore<T> st;
+  RegScratch<T, A::N> scr;
+  for (long b = 0; b < B; b++) {
+#define FULL(KM, UC, FT)                                                                                            \
+  osc_full_body<A, T, KM, UC, FT>(b, true, st, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, \
+                                  (T*)ie, (const T*)une, (T*)u, (T*)ts, want, o, scr)
+#define FULLF(KM, UC)        \
+  do {                       \
+    if (plain) FULL(KM, UC, 0); \
+    else FULL(KM, UC, 2);    \
+  } while (0)
+    if (fast == 3) {
+      if (P->use_C) FULLF(3, true); else FULLF(3, false);
+    } else {
+      if (P->use_C) FULLF(6, true); else FULLF(6, false);
+    }
+#undef FULLF
+#undef FULL
+  }
+  return 0;
+}
 template <class A, class T>
 int run_sliding(const A& arm, int n, const abrk_sliding_params* P, int64_t B, const void* q, const void* dq,
                 const void* tg, const void* tv, const void* ta, void* u, void* s) {
@@ -165,6 +200,16 @@ extern "C" int hostsim_osc(const char* builtin, const abrk_arm_desc* d, int dtyp
     using A = std::decay_t<decltype(a)>;
     using T = decltype(t);
     return run_osc<A, T>(a, n, P, B, q, dq, tg, tv, ie, une, u, ts);
+  });
+}
+extern "C" int hostsim_osc_full(const char* builtin, const abrk_arm_desc* d, int dtype, const abrk_osc_params* P,
+                                int64_t B, const void* q, const void* dq, const void* tg, const void* tv, void* ie,
+                                const void* une, void* u, void* ts, uint32_t want, const abrk_dyn_out* out) {
+  void* const* outs = reinterpret_cast<void* const*>(out);
+  return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int n) {
+    using A = std::decay_t<decltype(a)>;
+    using T = decltype(t);
+    return run_osc_full<A, T>(a, n, P, B, q, dq, tg, tv, ie, une, u, ts, want, outs);
   });
 }
 extern "C" int hostsim_sliding(const char* builtin, const abrk_arm_desc* d, int dtype,

@@ -370,3 +370,32 @@ def test_rows_truncated_pinv_rows_are_compared():
 def test_rows_quaternion_every_frame(arm):
     """power-iteration quaternion vs the reference's eigh on every frame, incl. Jaco2's non-orthogonal late frames"""
     cases.check_quaternions_all_frames(cases.HostsimBackend(arm, "static"), arm, golden(f"quat_{arm}"))
+
+
+@pytest.mark.parametrize("arm,kw", [
+    ("ur5", dict(kp=200)),
+    ("ur5", dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6, use_C=True, ref_frame="link5", xyz_offset=[0.05, 0.0, -0.1],
+                 null_controllers=[cases.make_damping(5)])),
+    ("jaco2", dict(kp=200, null_controllers=[cases.make_damping(10)])),
+    ("twojoint", dict(kp=10, kv=3, ctrlr_dof=cases.XY, use_C=True)),
+])
+def test_rows_fused_full_outputs(arm, kw):
+    """the Mode-F row program (osc_full_body: u + Tx, J, M, g) on the host: u / training signal equal to the plain row
+    program, the robot_config outputs equal to the dynamics row program of the same frame / offset, static and
+    runtime-table arms"""
+    from tests import hostsim
+    from abr_control_amd import _abi
+
+    tab = _abi.load_table(arm)
+    n = tab["n_joints"]
+    p = cases.P(n, **kw)
+    rng = np.random.RandomState(5)
+    q, dq, t = rng.uniform(0, 2 * np.pi, (40, n)), rng.uniform(0, 5, (40, n)), rng.uniform(-1, 1, (40, 6))
+    frame, off = kw.get("ref_frame", "EE"), kw.get("xyz_offset")
+    for a in (arm, tab):
+        u0, ts0 = hostsim.osc_generate(a, p, q, dq, t, training_signal=True)
+        u1, ts1, dyn = hostsim.osc_generate_full(a, p, q, dq, t)
+        ref = hostsim.dynamics(a, q, None, _abi.frame_id(frame, n), off, ("Tx", "J", "M", "g"), np.float64)
+        assert np.allclose(u1, u0, rtol=1e-12, atol=1e-12) and np.allclose(ts1, ts0, rtol=1e-12, atol=1e-12)
+        for k in ("Tx", "J", "M", "g"):
+            assert np.allclose(dyn[k], ref[k], rtol=1e-13, atol=1e-13), (arm, k)
