@@ -694,7 +694,10 @@ def check_fuzz_secondary(backend_factory, seed, B=64):
                                     gain=float(rng.uniform(1, 50)))
     with np.errstate(all="ignore"):
         uo, diag = o.avoid_obstacles_batch(PO, q)
-    ok = (diag[:, 0] > 1e-7) & (diag[:, 1] > 1e-20)
+    # mobility (diag[:, 1]): a closest point that barely moves with the joints it hangs on has a task-space inertia
+    # made of rounding noise, which both sides invert differently (the golden check keeps its documented 1e-20 floor;
+    # random arms reach 1e-14, e.g. seed 15600)
+    ok = (diag[:, 0] > 1e-7) & (diag[:, 1] > 1e-12)
     for b in range(B):
         if np.linalg.cond(o.M(q[b])) > 1e6:
             ok[b] = False

@@ -39,6 +39,39 @@ while time.time() - t3 < budget * 0.4:
         fails.append(("secondary", s3, repr(e)[:300]))
     n_sec += 1
     s3 += 1
+# six-row law, big batches: the deferred second pass (rows whose pinv truncates) against the inline sweeps of chunked
+# calls, bit for bit, on random user arms; and the fused u + Tx,J,M,g kernel against the separate calls
+import numpy as np  # noqa: E402
+
+from abr_control_amd import _abi  # noqa: E402
+from tests.synthetic_arms import make_arm  # noqa: E402
+
+n_def, t4, s4 = 0, time.time(), 9000 + offset
+while time.time() - t4 < min(30.0, budget * 0.15):
+    rng = np.random.RandomState(s4)
+    n = int(rng.randint(4, 8))
+    be = cases.GpuBackend(make_arm(n, s4, non_orthogonal=bool(rng.randint(2))))
+    B = 20000
+    q, dq, t = rng.uniform(-3, 3, (B, n)), rng.uniform(-2, 2, (B, n)), rng.uniform(-0.6, 0.6, (B, 6))
+    dof = [1] * 6 if n >= 6 else [1, 1, 1, 1, 0, 0]
+    p = _abi.make_osc_params(n, kp=100, ko=60, kv=12, ctrlr_dof=dof, use_C=bool(rng.randint(2)),
+                             orientation_algorithm=int(rng.randint(2)))
+    try:
+        u_big = be.osc(p, q, dq, t)[0]
+        u_c = np.concatenate([be.osc(p, q[lo:lo + 5000], dq[lo:lo + 5000], t[lo:lo + 5000])[0] for lo in range(0, B, 5000)])
+        assert np.array_equal(u_big, u_c, equal_nan=True), "deferred pass differs from inline sweeps"
+        u1, _, dyn = be.e.osc_generate(be.arm_id, n, p, q[:3000], dq[:3000], t[:3000], training_signal=True,
+                                       want=("Tx", "J", "M", "g"))
+        ref = be.e.dynamics(be.arm_id, n, q[:3000], None, _abi.frame_id("EE", n), None, ("Tx", "J", "M", "g"), np.float64, 0)
+        for k in ref:
+            assert np.max(np.abs(dyn[k] - ref[k])) <= 1e-12 * max(1.0, np.max(np.abs(ref[k]))), k
+        fin = np.isfinite(u_c[:3000]).all(axis=1) & np.isfinite(u1).all(axis=1)
+        assert np.max(np.abs(u1[fin] - u_c[:3000][fin])) <= 1e-9 * max(1.0, np.max(np.abs(u_c[:3000][fin]))), "fused u"
+    except Exception as e:  # noqa: BLE001
+        fails.append(("deferred/fused", s4, n, repr(e)[:300]))
+    n_def += 1
+    s4 += 1
+print(f"soak: {n_def} deferred-pass / fused-output cases (seeds {9000 + offset}..{s4 - 1})")
 print(f"soak: {n_sec} secondary-controller cases (seeds {5000 + offset}..{s3 - 1})")
 print(f"soak: {n_osc} OSC cases (seeds {100 + offset}..{seed - 1}), worst rel err {worst:.3e}; {n_other} other cases "
       f"(seeds {1000 + offset}..{s2 - 1}); {len(fails)} failures in {time.time() - t0:.0f} s")
