@@ -1319,6 +1319,13 @@ def test_gpu_six_row_deferred_pass_equals_inline_sweeps(variant):
             s.sync()
             assert np.array_equal(u.numpy(), u_big)
             plan.close()
+    # the fp32 instantiation takes the same two passes
+    p = _abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6)
+    q32, dq32, t32 = (x.astype(np.float32) for x in (q, dq, t))
+    big = be.e.osc_generate(be.arm_id, 6, p, q32, dq32, t32, dtype=np.float32)
+    chunks = [be.e.osc_generate(be.arm_id, 6, p, q32[lo:lo + 8000], dq32[lo:lo + 8000], t32[lo:lo + 8000], dtype=np.float32)
+              for lo in range(0, B, 8000)]
+    assert big.dtype == np.float32 and np.array_equal(big, np.concatenate(chunks), equal_nan=True)
 
 
 def test_gpu_table_sincos_negative_and_large_angles():
