@@ -246,27 +246,36 @@ class Runner:
             self.plan.launch_graph(self.graph_steps)
         self.stream.sync()
         ev0, ev1 = a.Event(self.device), a.Event(self.device)
+
+        def k_steps():
+            if graph:
+                # K steps as ceil(K/G) hipGraph launches of G kernel nodes each (+ a remainder of plain launches)
+                for _ in range(steps // self.graph_steps):
+                    self.plan.launch_graph(self.graph_steps)
+                for _ in range(steps % self.graph_steps):
+                    self.step()
+            else:
+                for _ in range(steps):
+                    self.step()
+
         if barrier:
             barrier()
         self.stream.sync()
         t0 = time.perf_counter()
-        ev0.record(self.stream)
-        if graph:
-            # K steps as ceil(K/G) hipGraph launches of G kernel nodes each (+ a remainder of plain launches)
-            for _ in range(steps // self.graph_steps):
-                self.plan.launch_graph(self.graph_steps)
-            for _ in range(steps % self.graph_steps):
-                self.step()
-        else:
-            for _ in range(steps):
-                self.step()
-        ev1.record(self.stream)
+        k_steps()
         self.stream.sync()
         # this rank's K steps, device-synchronised on both sides; the closing barrier keeps the ranks together but
         # its own (gloo, TCP) latency is not step time - main() takes the MAX of `wall` over the ranks
         wall = time.perf_counter() - t0
         if barrier:
             barrier()
+        # the HIP-event time per launch (the `roofline*` blocks) comes from one more, untimed replay of the same K
+        # steps: recording the two events inside the wall-clocked region costs ~5 us of host time, which at K = 20
+        # config-sized steps is 5 % of the run
+        ev0.record(self.stream)
+        k_steps()
+        ev1.record(self.stream)
+        self.stream.sync()
         return wall, ev1.elapsed_ms_since(ev0) / steps
 
 
