@@ -693,7 +693,15 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = T(0); });
     for (int c = 0; c < P.n_null; c++) null_command<N>(P.nul[c], q, dq, v);
     T un[N];
-    symv<N>(Ms, v, un);
+    // Damping only (BASELINE config 3): v = -kv dq, so M v = -kv (M dq) - and M dq is at hand (wave-uniform branch)
+    bool damping_only = P.n_null > 0;
+    T kvs = T(0);
+    for (int c = 0; c < P.n_null; c++) {
+      damping_only = damping_only && (P.nul[c].kind == 1);
+      kvs += P.nul[c].kv;
+    }
+    if (damping_only) sfor<N>([&](auto i) ABRK_LAMBDA { un[i()] = -kvs * Mdq[i()]; });
+    else symv<N>(Ms, v, un);
     if (FEAT >= 2 && have_ext) {
       // caller-evaluated u_null: v_ext = M^-1 u_ext
       T y[N], w[N];
