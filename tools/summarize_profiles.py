@@ -89,10 +89,25 @@ if rows:
         for (k, gsz), grp in kt2.groupby(["kernel", "Grid_Size_X"]):
             durs[(k, int(gsz))] = float(grp["dur"].mean())
     counters = {"_commit": commit}
+    # grid-stride kernels (Sliding) launch fewer lanes than rows: the rows of each leg are in the bench line of the pass
+    rows_of = {}
+    try:
+        line = [l for l in open(os.path.join(src, "pmc_sq.log")) if l.startswith("{")][-1]
+        bj = json.loads(line)
+        legs = [bj.get("roofline"), bj.get("roofline_full_outputs")] + list((bj.get("also") or {}).values())
+        for leg in legs:
+            if leg:
+                rows_of[leg["kernel"].replace(" ", "")] = int(leg["batch"])
+    except (OSError, IndexError, ValueError, KeyError):
+        pass
     for (k, gsz), r in piv.iterrows():
         if "SQ_WAVES" not in r or r["SQ_WAVES"] != r["SQ_WAVES"] or gsz < 4096:
             continue
         w = r["SQ_WAVES"]
+        rows = rows_of.get(k.replace(" ", ""), 0)
+        if rows > gsz >= (1 << 20):  # more rows than lanes: per-row figures, keyed by the rows
+            w = rows / 64.0
+            gsz = rows
         e = {"valu_per_row": float(r["SQ_INSTS_VALU"] / w), "salu_per_row": float(r["SQ_INSTS_SALU"] / w),
              "wave_cycles_per_wave": float(4 * r["SQ_WAVE_CYCLES"] / w),
              "busy_cycles": float(r["SQ_BUSY_CYCLES"]) if "SQ_BUSY_CYCLES" in r else None}
