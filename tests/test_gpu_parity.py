@@ -1362,3 +1362,36 @@ def test_gpu_table_sincos_negative_and_large_angles():
     well = (np.abs(np.sin(q32[:, 1])) > 0.05) & (np.abs(np.sin(q32[:, 2])) > 0.05)
     assert np.median(cases.rel_err(u32.astype(float), u64r)[well]) < 2e-5
     assert np.isfinite(u64).all()
+
+
+def test_gpu_closed_loop_as_recorded_plan_matches_fused_rollout():
+    """the examples' loop (examples/PyGame/force_osc_xy.py:57-78) as a recorded two-kernel tick - OSC.generate, then the
+    plant step advancing q, dq in place - replayed 300 times as hipGraph launches, against the fused rollout kernel and
+    the reference's own loop (tests/golden/twojoint.npz rollout_*)"""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+    from abr_control_amd.arms import twojoint
+    from abr_control_amd.arms.twojoint import ArmSim
+    from abr_control_amd.controllers import OSC, Damping, RestingConfig
+
+    g = golden("twojoint")
+    rc = twojoint.Config()
+    q0, dq0, tgt = g["rollout_q0"], g["rollout_dq0"], g["rollout_target"]
+    T = int(g["rollout_T"])
+    ctrlr = OSC(rc, kp=20, use_C=True, ctrlr_dof=cases.XY, null_controllers=[
+        Damping(rc, kv=10), RestingConfig(rc, kp=50, kv=np.sqrt(50), rest_angles=[np.pi / 4, np.pi])])
+    sim = ArmSim(rc, dt=0.001, q_init=q0.copy())
+    sim.dq = dq0.copy()
+    sim.rollout(ctrlr, tgt, T)
+    s = a.Stream(0)
+    qd, dqd, td = _dev(q0, dq0, tgt)
+    u = a.DeviceArray((len(q0), 2))
+    with engine.Plan(0, s) as tick:
+        engine.osc_generate(rc.arm_id, 2, ctrlr._params("EE", None), qd, dqd, td, u=u, stream=s)
+        engine.twolink_step(sim._plant, qd, dqd, u, stream=s)
+    for _ in range(T // 100):
+        tick.launch_graph(100)
+    s.sync()
+    # same arithmetic, different fusion: equal to rounding accumulated over 300 steps
+    assert np.max(np.abs(qd.numpy() - sim.q)) < 1e-9 and np.max(np.abs(dqd.numpy() - sim.dq)) < 1e-8
+    assert np.max(np.abs(qd.numpy() - g["rollout_qD"][:, -1])) < 1e-9  # the reference's loop (fp64 formulas), last checkpoint
