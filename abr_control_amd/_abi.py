@@ -224,6 +224,36 @@ def desc_from_table(tab):
     return d
 
 
+def render_tab_struct(t, struct_name, name=None):
+    """C++ source of the constexpr arm table `struct <struct_name>` the StaticArm kernels are instantiated on
+    (abrk_arms_builtin.h for the built-in arms, the plugin source of a compiled user arm).  Literals are `repr`
+    of the doubles, i.e. they read back to exactly the values of the table."""
+    def lit(v):
+        return repr(float(v))
+
+    def mat(m):
+        return "{" + ", ".join(lit(v) for row in m for v in row) + "}"
+
+    ident = [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]]
+    n = int(t["n_joints"])
+    md = [list(r) for r in t["mdiag"]] + [[0.0] * 6] * (n + 1 - len(t["mdiag"]))
+    out = [
+        f"struct {struct_name} {{",
+        f"  static constexpr int N = {n};",
+        f"  static constexpr int NL = {int(t['n_links_dyn'])};",
+        f"  static constexpr bool kHasEE = {'true' if t['has_ee'] else 'false'};",
+        f"  static constexpr double A0[12] = {mat(t['A0'])};",
+        f"  static constexpr double AJ[{n}][12] = {{" + ",\n      ".join(mat(m) for m in t["AJ"][:n]) + "};",
+        f"  static constexpr double B[{n}][12] = {{" + ",\n      ".join(mat(m) for m in t["B"][:n]) + "};",
+        f"  static constexpr double E[12] = {mat(t['E'] if t['has_ee'] else ident)};",
+        f"  static constexpr double MD[{n + 1}][6] = {{" + ",\n      ".join(
+            "{" + ", ".join(lit(v) for v in row) + "}" for row in md[: n + 1]) + "};",
+        f'  static constexpr const char* kName = "{name if name is not None else t.get("name", "robot")}";',
+        "};",
+    ]
+    return "\n".join(out)
+
+
 def table_from_desc(d):
     n = d.n_joints
     m = lambda a: np.array(list(a), dtype=np.float64).reshape(3, 4).tolist()

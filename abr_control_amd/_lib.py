@@ -36,6 +36,8 @@ def lib():
         L.abrk_last_error.restype = C.c_char_p
         L.abrk_arm_builtin.argtypes = [C.c_char_p]
         L.abrk_arm_create.argtypes = [C.POINTER(_abi.ArmDesc)]
+        L.abrk_arm_create_compiled.argtypes = [C.POINTER(_abi.ArmDesc), C.c_char_p]
+        L.abrk_plugin_abi.restype = C.c_char_p
         L.abrk_arm_get_desc.argtypes = [C.c_int, C.POINTER(_abi.ArmDesc)]
         L.abrk_arm_destroy.argtypes = [C.c_int]
         L.abrk_dynamics_batch.argtypes = [

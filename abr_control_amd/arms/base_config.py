@@ -38,10 +38,14 @@ class BatchedConfig:
     reference_dtypes : bool
         True (default): NumPy results carry the reference's dtypes (float32 for
         J/M/g/C/dJ/R).  False: keep the kernel dtype.
+    compiled : None, True or False (user arms only)
+        kernels specialised for this table (abr_control_amd/specialize.py - the counterpart of the reference's cached
+        generated functions, base_config.py:173-191).  None (default): use the cached plugin when there is one, else
+        the runtime-table kernels.  True: build it now if it is not cached (one hipcc run, 1-3 min).  False: never.
     """
 
     def __init__(self, table, builtin=None, use_cython=True, dtype=np.float64, device=0,
-                 reference_dtypes=True, **kwargs):
+                 reference_dtypes=True, compiled=None, **kwargs):
         if kwargs:
             raise TypeError(f"unexpected keyword arguments {sorted(kwargs)}")  # as base_config.py:78 would
         self.table = table
@@ -68,6 +72,8 @@ class BatchedConfig:
         if "START_ANGLES" in table:
             self.START_ANGLES = np.array(table["START_ANGLES"])
         self._builtin = builtin
+        self._compiled = compiled
+        self._plugin_path = None
         self._arm_id = None
 
     # ---- library handle (lazy: constructing a config needs no GPU)
@@ -78,13 +84,39 @@ class BatchedConfig:
                 self._arm_id = check(lib().abrk_arm_builtin(self._builtin.encode()))
             else:
                 desc = _abi.desc_from_table(self.table)
-                self._arm_id = check(lib().abrk_arm_create(C.byref(desc)))
+                path = None
+                if self._compiled is not False:
+                    from .. import specialize
+
+                    path = specialize.compile_arm(self.table) if self._compiled else specialize.find_compiled(self.table)
+                if path:
+                    self._arm_id = check(lib().abrk_arm_create_compiled(C.byref(desc), path.encode()))
+                    self._plugin_path = path
+                else:
+                    self._arm_id = check(lib().abrk_arm_create(C.byref(desc)))
         return self._arm_id
+
+    @property
+    def plugin_path(self):
+        """the shared object of this arm's compiled kernels, or None (built-in arms; user arms on the runtime table)"""
+        self.arm_id  # noqa: B018 - registers the arm, which is when the choice is made
+        return self._plugin_path
+
+    def compile(self, **kw):
+        """build (or find) the kernels specialised for this arm's table and switch to them; returns the plugin path"""
+        if self._builtin is not None:
+            return None
+        from .. import specialize
+
+        path = specialize.compile_arm(self.table, **kw)
+        self.close()
+        self._compiled = True
+        return path
 
     def close(self):
         """hand a user arm's registry slot back to the library (built-in arms hold none).  Called on garbage
         collection too, so loops that build configs repeatedly do not run out of the 4091 user slots."""
-        arm_id, self._arm_id = self._arm_id, None
+        arm_id, self._arm_id, self._plugin_path = self._arm_id, None, None
         if arm_id is not None and self._builtin is None:
             try:
                 lib().abrk_arm_destroy(arm_id)

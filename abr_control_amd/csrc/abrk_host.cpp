@@ -2,6 +2,7 @@
 // conversion, host<->device staging and kernel dispatch.  No arithmetic of the hot path
 // happens here and there is no CPU fallback: without a HIP device every compute entry
 // point fails with ABRK_ENODEV.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -16,6 +17,7 @@
 
 #include "../../include/abrk.h"
 #include "abrk_coop.h"
+#include "abrk_plugin.h"
 #include "abrk_kernels.h"
 #include "abrk_params.h"
 
@@ -63,27 +65,18 @@ struct ArmEntry {
   bool builtin = false;
   abrk_arm_desc desc;
   const ArmOps* ops = nullptr;
-  std::vector<unsigned char> rt64, rt32;  // RtArm<N,double> / RtArm<N,float> images (user arms)
+  std::vector<unsigned char> rt64, rt32;  // RtArm<N,double> / RtArm<N,float> images (user arms on the runtime-table
+                                          // kernels; empty for built-in and compiled arms)
 };
+// plugins stay loaded for the life of the process (their code objects are registered with the HIP runtime)
+struct PluginLib {
+  std::string path;
+  const ArmOps* ops;
+  abrk_arm_desc desc;
+};
+std::vector<PluginLib> g_plugins;
 std::mutex g_mu;
 std::vector<ArmEntry> g_arms;
-
-template <class Tab>
-void desc_from_tab(abrk_arm_desc* d) {
-  memset(d, 0, sizeof *d);
-  d->n_joints = Tab::N;
-  d->n_links_dyn = Tab::NL;
-  d->has_ee = Tab::kHasEE ? 1 : 0;
-  const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-  memcpy(d->A0, Tab::A0, sizeof d->A0);
-  for (int i = 0; i < ABRK_MAX_JOINTS; i++) {
-    memcpy(d->AJ[i], i < Tab::N ? Tab::AJ[i] : ident, sizeof ident);
-    memcpy(d->B[i], i < Tab::N ? Tab::B[i] : ident, sizeof ident);
-  }
-  memcpy(d->E, Tab::E, sizeof d->E);
-  for (int l = 0; l <= Tab::N; l++) memcpy(d->mdiag[l], Tab::MD[l], 6 * sizeof(double));
-  snprintf(d->name, sizeof d->name, "%s", Tab::kName);
-}
 
 void init_builtins() {
   if (!g_arms.empty()) return;
@@ -144,6 +137,75 @@ extern "C" int abrk_arm_create(const abrk_arm_desc* d) {
   e.rt32.resize(rt_table_size(d->n_joints, ABRK_F32));
   rt_table_fill(d->n_joints, ABRK_F64, d, e.rt64.data());
   rt_table_fill(d->n_joints, ABRK_F32, d, e.rt32.data());
+  if (slot >= 0) {
+    g_arms[slot] = std::move(e);
+    return slot;
+  }
+  g_arms.push_back(std::move(e));
+  return (int)g_arms.size() - 1;
+}
+
+namespace {
+bool same_table(const abrk_arm_desc& a, const abrk_arm_desc& b) {
+  if (a.n_joints != b.n_joints || a.n_links_dyn != b.n_links_dyn || (a.has_ee != 0) != (b.has_ee != 0)) return false;
+  const int n = a.n_joints;
+  if (memcmp(a.A0, b.A0, sizeof a.A0)) return false;
+  for (int i = 0; i < n; i++)
+    if (memcmp(a.AJ[i], b.AJ[i], sizeof a.AJ[i]) || memcmp(a.B[i], b.B[i], sizeof a.B[i])) return false;
+  if (a.has_ee && memcmp(a.E, b.E, sizeof a.E)) return false;
+  for (int l = 0; l <= n; l++)
+    if (memcmp(a.mdiag[l], b.mdiag[l], sizeof a.mdiag[l])) return false;
+  return true;
+}
+}  // namespace
+
+extern "C" const char* abrk_plugin_abi(void) { return ABRK_PLUGIN_ABI; }
+
+extern "C" int abrk_arm_create_compiled(const abrk_arm_desc* d, const char* plugin_path) {
+  if (!d || !plugin_path) return fail(ABRK_EINVAL, "abrk_arm_create_compiled: NULL argument");
+  if (d->n_joints < 1 || d->n_joints > ABRK_MAX_JOINTS)
+    return fail(ABRK_EINVAL, "n_joints=%d outside 1..%d", d->n_joints, ABRK_MAX_JOINTS);
+  if (d->n_links_dyn < 0 || d->n_links_dyn > d->n_joints + 1)
+    return fail(ABRK_EINVAL, "n_links_dyn=%d outside 0..n_joints+1", d->n_links_dyn);
+  std::lock_guard<std::mutex> lk(g_mu);
+  init_builtins();
+  const PluginLib* pl = nullptr;
+  for (const auto& p : g_plugins)
+    if (p.path == plugin_path) pl = &p;
+  if (!pl) {
+    void* h = dlopen(plugin_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(ABRK_EINVAL, "cannot load arm plugin: %s", dlerror());
+    auto f_abi = reinterpret_cast<abrk_plugin_abi_fn>(dlsym(h, "abrk_plugin_abi_tag"));
+    auto f_ops = reinterpret_cast<abrk_plugin_ops_fn>(dlsym(h, "abrk_plugin_ops"));
+    auto f_desc = reinterpret_cast<abrk_plugin_desc_fn>(dlsym(h, "abrk_plugin_desc"));
+    if (!f_abi || !f_ops || !f_desc) {
+      dlclose(h);
+      return fail(ABRK_EINVAL, "%s is not an arm plugin (entry points missing)", plugin_path);
+    }
+    if (strcmp(f_abi(), ABRK_PLUGIN_ABI) != 0) {
+      int rc = fail(ABRK_EINVAL, "arm plugin %s was built for kernel headers %s, this library is %s: rebuild it",
+                    plugin_path, f_abi(), ABRK_PLUGIN_ABI);
+      dlclose(h);
+      return rc;
+    }
+    PluginLib p;
+    p.path = plugin_path;
+    p.ops = static_cast<const ArmOps*>(f_ops());
+    f_desc(&p.desc);
+    g_plugins.push_back(std::move(p));
+    pl = &g_plugins.back();
+  }
+  if (!same_table(pl->desc, *d))
+    return fail(ABRK_EINVAL, "arm plugin %s was compiled for a different arm table than the one given", plugin_path);
+  int slot = -1;
+  for (int i = 5; i < (int)g_arms.size() && slot < 0; i++)
+    if (!g_arms[i].live) slot = i;
+  if (slot < 0 && g_arms.size() >= 4096) return fail(ABRK_ENOMEM, "too many arms (4096 live at once)");
+  ArmEntry e;
+  e.live = true;
+  e.desc = *d;
+  e.desc.name[sizeof e.desc.name - 1] = 0;
+  e.ops = pl->ops;
   if (slot >= 0) {
     g_arms[slot] = std::move(e);
     return slot;
@@ -457,7 +519,7 @@ thread_local Recorder* t_rec = nullptr;
 bool recording() { return t_rec != nullptr; }
 
 const void* arm_table(const ArmEntry* a, int dtype) {
-  if (!a || a->builtin) return nullptr;
+  if (!a || a->rt64.empty()) return nullptr;  // built-in and compiled arms carry their table in the kernels
   return dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data();
 }
 
@@ -470,7 +532,7 @@ int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn) {
     if (st.device != r->device || st.stream != r->stream)
       return fail(ABRK_EINVAL, "a recorded call must use the device and stream given to abrk_plan_begin");
     const void* rt = nullptr;
-    if (a && !a->builtin) {
+    if (a && !a->rt64.empty()) {
       r->tables.emplace_back(new std::vector<unsigned char>(dtype == ABRK_F64 ? a->rt64 : a->rt32));
       rt = r->tables.back()->data();
     }

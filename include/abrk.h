@@ -48,6 +48,16 @@ int abrk_arm_builtin(const char* name);
  * Replaces writing a BaseConfig subclass + first-use SymPy/Cython code generation
  * (base_config.py:125-146).                                                            */
 int abrk_arm_create(const abrk_arm_desc* desc);
+/* Register a user arm together with kernels compiled for its own table - the counterpart of the reference's cached
+ * generated functions (base_config.py:173-191: `_load_from_file` imports the Cython module generated for this arm;
+ * _generate_and_save_function :125-146 writes it).  `plugin_path` is a shared object built by
+ * `make -C abr_control_amd/csrc plugin` from the same description (abr_control_amd/specialize.py generates the source,
+ * runs the build and caches the result); it is checked against `desc` value by value and against abrk_plugin_abi(), and
+ * refused with ABRK_EINVAL on any mismatch.  The arm then runs the same compile-time specialised kernels as a built-in
+ * arm (about 2.2x the rate of the runtime-table kernels abrk_arm_create gives).  Returns arm id >= 0.                */
+int abrk_arm_create_compiled(const abrk_arm_desc* desc, const char* plugin_path);
+/* tag of the kernel headers and compile flags this library was built from; a plugin must carry the same one */
+const char* abrk_plugin_abi(void);
 int abrk_arm_get_desc(int arm_id, abrk_arm_desc* out);
 int abrk_arm_destroy(int arm_id);
 

@@ -230,14 +230,21 @@ class GpuBackend:
         from abr_control_amd._lib import check, lib
 
         self.e = engine
-        if isinstance(arm, dict):  # a user arm table -> runtime-table kernels
-            self.tab, variant = arm, "rt"
+        if isinstance(arm, dict):  # a user arm table -> runtime-table kernels ("compiled": its plugin, specialize.py)
+            self.tab, variant = arm, ("compiled" if variant == "compiled" else "rt")
         else:
             self.tab = _abi.load_table(arm)
         self.n = self.tab["n_joints"]
         self.device = device
         if variant == "static":
             self.arm_id = check(lib().abrk_arm_builtin(arm.encode()))
+        elif variant == "compiled":
+            from abr_control_amd import specialize
+
+            path = specialize.find_compiled(self.tab)
+            assert path, "no compiled plugin for this arm and the current kernel headers: run __graft_entry__.build()"
+            d = _abi.desc_from_table(self.tab)
+            self.arm_id = check(lib().abrk_arm_create_compiled(C.byref(d), path.encode()))
         else:
             d = _abi.desc_from_table(self.tab)
             self.arm_id = check(lib().abrk_arm_create(C.byref(d)))

@@ -1395,3 +1395,83 @@ def test_gpu_closed_loop_as_recorded_plan_matches_fused_rollout():
     # same arithmetic, different fusion: equal to rounding accumulated over 300 steps
     assert np.max(np.abs(qd.numpy() - sim.q)) < 1e-9 and np.max(np.abs(dqd.numpy() - sim.dq)) < 1e-8
     assert np.max(np.abs(qd.numpy() - g["rollout_qD"][:, -1])) < 1e-9  # the reference's loop (fp64 formulas), last checkpoint
+
+
+def test_gpu_compiled_user_arm_equals_the_builtin_bit_for_bit():
+    """a user arm's compiled kernels (specialize.py, abrk_arm_create_compiled) are the StaticArm instantiations a
+    built-in arm gets: the built-in threejoint's table, registered as a user arm with its plugin, returns the built-in's
+    bits - dynamics, the OSC law and BASELINE config 5's Sliding law in both arithmetic types"""
+    from tests import compiled_arms
+
+    tab = compiled_arms.test_arms()["threejoint_user"]
+    cu, bi = cases.GpuBackend(tab, "compiled"), cases.GpuBackend("threejoint")
+    q, dq, t = draw(31, 5000, 3)
+    for dtype in (np.float64, np.float32):
+        a = cu.dynamics(q, dq, "EE", [0.1, -0.2, 0.05], ("Tx", "J", "dJ", "M", "g", "C", "R", "quat"), dtype=dtype)
+        b = bi.dynamics(q, dq, "EE", [0.1, -0.2, 0.05], ("Tx", "J", "dJ", "M", "g", "C", "R", "quat"), dtype=dtype)
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+        for p in (_abi.make_osc_params(3, kp=50), _abi.make_osc_params(3, kp=50, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 1],
+                                                                       null_controllers=[_abi.make_damping(5)])):
+            assert np.array_equal(cu.osc(p, q, dq, t, dtype=dtype)[0], bi.osc(p, q, dq, t, dtype=dtype)[0])
+        sp = _abi.make_sliding_params(3)
+        ua, ub = cu.sliding(sp, q, dq, t[:, :3], dtype=dtype), bi.sliding(sp, q, dq, t[:, :3], dtype=dtype)
+        assert np.array_equal(ua[0], ub[0]) and np.array_equal(ua[1], ub[1])
+
+
+def test_gpu_compiled_user_arm_against_the_oracle_and_the_runtime_table_kernels():
+    """an arm no built-in resembles (4 joints, non-orthogonal fixed rotations): its compiled kernels against the oracle
+    at the north_star bound and against the runtime-table kernels of the same table (both fp64: 1e-11), through the
+    engine and through the robot_config / controller classes, recorded plans included"""
+    import abr_control_amd as a
+    from abr_control_amd import arms, engine
+    from abr_control_amd.controllers import OSC, Damping
+    from oracle.oracle import Oracle
+    from tests import compiled_arms
+
+    tab = compiled_arms.test_arms()["synthetic4"]
+    cu, rt, o = cases.GpuBackend(tab, "compiled"), cases.GpuBackend(tab), Oracle(tab)
+    rng = np.random.RandomState(5)
+    B = 400
+    q, dq, t = rng.uniform(-3, 3, (B, 4)), rng.uniform(-2, 2, (B, 4)), rng.uniform(-0.5, 0.5, (B, 6))
+    want = ("Tx", "J", "dJ", "M", "g", "C", "R", "quat", "T", "Tinv")
+    for frame, off in (("EE", [0.05, -0.02, 0.03]), ("link2", None), ("joint3", [0.0, 0.1, 0.0])):
+        r, r2 = cu.dynamics(q, dq, frame, off, want), rt.dynamics(q, dq, frame, off, want)
+        for k in want:
+            assert np.allclose(r[k], r2[k], atol=1e-11), (frame, k)
+        for b in range(0, B, 13):
+            assert np.allclose(r["Tx"][b], o.Tx(frame, q[b], off), atol=1e-12)
+            assert np.allclose(r["J"][b], o.J(frame, q[b], off), atol=1e-12)
+            assert np.allclose(r["dJ"][b], o.dJ(frame, q[b], dq[b], off), atol=1e-11)
+            assert np.allclose(r["M"][b], o.M(q[b]), atol=1e-12) and np.allclose(r["g"][b], o.g(q[b]), atol=1e-12)
+            assert np.allclose(r["C"][b], o.C(q[b], dq[b]), atol=1e-11)
+            assert np.allclose(r["quat"][b], o.quaternion(frame, q[b]), atol=1e-10)
+    ok = np.array([np.linalg.cond(o.M(q[b])) < 1e8 for b in range(B)])
+    P = _abi.make_osc_params
+    for p in (P(4, kp=30), P(4, kp=30, use_C=True, null_controllers=[_abi.make_damping(3)]),
+              P(4, kp=30, ko=20, ctrlr_dof=[1, 1, 1, 1, 0, 0], vmax=[0.5, 1.0])):
+        u, ts = cu.osc(p, q, dq, t)
+        uo = o.osc_batch(p, q, dq, t)
+        assert cases.rel_err(u, uo)[ok].max() < 1e-6
+        assert cases.rel_err(u, rt.osc(p, q, dq, t)[0])[ok].max() < 1e-9
+    us = cu.sliding(_abi.make_sliding_params(4), q, dq, t[:, :3])[0]
+    assert cases.rel_err(us, rt.sliding(_abi.make_sliding_params(4), q, dq, t[:, :3])[0]).max() < 1e-8
+    # the classes: the cached plugin is picked up without being asked for; compiled=False keeps the runtime table
+    rc, rc_rt = arms.from_table(tab), arms.from_table(tab, compiled=False)
+    assert rc.plugin_path and rc_rt.plugin_path is None
+    ctrl = OSC(rc, kp=30, null_controllers=[Damping(rc, kv=3)], use_C=True)
+    ctrl_rt = OSC(rc_rt, kp=30, null_controllers=[Damping(rc_rt, kv=3)], use_C=True)
+    uc = ctrl.generate(q, dq, t)
+    assert cases.rel_err(uc, ctrl_rt.generate(q, dq, t))[ok].max() < 1e-9
+    assert cases.rel_err(uc, o.osc_batch(P(4, kp=30, use_C=True, null_controllers=[_abi.make_damping(3)]), q, dq, t))[ok].max() < 1e-6
+    assert np.allclose(rc.M(q[3]), o.M(q[3]).astype(np.float32)) and rc.M(q[3]).dtype == np.float32
+    # a recorded plan on a compiled arm carries no table copy and replays as a graph
+    s = a.Stream(0)
+    qd, dd, td = (a.DeviceArray.from_numpy(x) for x in (q, dq, t))
+    ud = a.DeviceArray((B, 4))
+    with engine.Plan(0, s) as plan:
+        engine.osc_generate(rc.arm_id, 4, P(4, kp=30), qd, dd, td, u=ud, stream=s)
+    plan.launch_graph(3)
+    s.sync()
+    assert np.array_equal(ud.numpy(), cu.osc(P(4, kp=30), q, dq, t)[0])
+    plan.close()
