@@ -220,6 +220,78 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
   sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = S[tri(i(), i())]; });
 }
 
+// Direct eigen-decomposition of a symmetric 3 x 3 matrix (packed lower in) - no sweeps, no data-dependent trip
+// count, so the lanes of a wavefront stay together (AvoidObstacles runs one truncated pinv per near segment-obstacle
+// pair; with the Jacobi sweeps that was ~12.7 k vector instructions per row).  The hybrid of the closed form and one
+// rotation: (1) the eigenvalue that is ISOLATED from the other two - the largest when det(A - mI) >= 0, else the
+// smallest - from the trigonometric solution of the characteristic cubic, where it is well conditioned (the two
+// others may coincide; their closed form loses half the digits there and is not used); (2) its eigenvector as the
+// largest cross product of two rows of (A - lam I), a rank-2 matrix whose non-zero eigenvalues are at least sqrt(3)
+// normalised units away from 0; (3) an orthonormal basis of the complement, the 2 x 2 block of A in it, and ONE
+// Jacobi rotation, exact for two dimensions.  V is orthonormal by construction; eigenvalues carry errors of a few
+// eps |A| (prototype against numpy.linalg.eigvalsh / pinv over 2e5 rank-1, rank-2, clustered and graded matrices:
+// 1.6e-15 |A|, pinv(rcond=0.01) within 1.2e-13).  The order of the pairs is (isolated, pair, pair), NOT by row:
+// callers that rely on Jacobi leaving a decoupled row's eigenpair in place (osc_law's masked rows) keep jacobi_eig.
+template <class T>
+ABRK_INL void sym3_eig(const T (&S)[6], T (&V)[3][3], T (&lam)[3]) {
+  const T a00 = S[tri(0, 0)], a01 = S[tri(1, 0)], a11 = S[tri(1, 1)], a02 = S[tri(2, 0)], a12 = S[tri(2, 1)],
+          a22 = S[tri(2, 2)];
+  const T m = (a00 + a11 + a22) * T(1.0 / 3.0);
+  const T b00 = a00 - m, b11 = a11 - m, b22 = a22 - m;
+  const T p2 = (b00 * b00 + b11 * b11 + b22 * b22 + T(2) * (a01 * a01 + a02 * a02 + a12 * a12)) * T(1.0 / 6.0);
+  const T lim = T(4) * Rm<T>::eps() * Rm<T>::fabs(m);
+  if (!(p2 > lim * lim)) {  // a multiple of the identity to working precision: any basis serves
+    sfor<3>([&](auto i) ABRK_LAMBDA { sfor<3>([&](auto j) ABRK_LAMBDA { V[i()][j()] = (i() == j()) ? T(1) : T(0); }); });
+    lam[0] = a00;
+    lam[1] = a11;
+    lam[2] = a22;
+    return;
+  }
+  const T ip = Rm<T>::rsqrt(p2);
+  const T c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = a01 * ip, c02 = a02 * ip, c12 = a12 * ip;
+  T hd = T(0.5) * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+  hd = Rm<T>::fmin(T(1), Rm<T>::fmax(T(-1), hd));
+  const T phi = Rm<T>::acos(hd) * T(1.0 / 3.0);  // in [0, pi/3]
+  T sn, cs;
+  Rm<T>::sincos_fast(phi, sn, cs);
+  // roots of the normalised cubic: 2 cos(phi) >= 2 cos(phi - 2pi/3) >= 2 cos(phi + 2pi/3)
+  const T s = hd >= T(0) ? T(2) * cs : -cs - T(1.7320508075688772935) * sn;
+  const T r0[3] = {c00 - s, c01, c02}, r1[3] = {c01, c11 - s, c12}, r2[3] = {c02, c12, c22 - s};
+  T x0[3], x1[3], x2[3];
+  cross3(r0, r1, x0);
+  cross3(r0, r2, x1);
+  cross3(r1, r2, x2);
+  const T n0 = dot3(x0, x0), n1 = dot3(x1, x1), n2 = dot3(x2, x2);
+  const bool u1 = n1 > n0;
+  T nb = u1 ? n1 : n0, xb[3];
+  sfor<3>([&](auto r) ABRK_LAMBDA { xb[r()] = u1 ? x1[r()] : x0[r()]; });
+  const bool u2 = n2 > nb;
+  nb = u2 ? n2 : nb;
+  const T inb = Rm<T>::rsqrt(nb);
+  T vs[3];
+  sfor<3>([&](auto r) ABRK_LAMBDA { vs[r()] = (u2 ? x2[r()] : xb[r()]) * inb; });
+  // u perpendicular to vs from its two larger components (their squares sum to at least 1/2), w = vs x u
+  const bool xbig = Rm<T>::fabs(vs[0]) > Rm<T>::fabs(vs[1]);
+  const T ih = Rm<T>::rsqrt(xbig ? vs[0] * vs[0] + vs[2] * vs[2] : vs[1] * vs[1] + vs[2] * vs[2]);
+  const T u[3] = {xbig ? -vs[2] * ih : T(0), xbig ? T(0) : vs[2] * ih, xbig ? vs[0] * ih : -vs[1] * ih};
+  T w[3], Au[3], Aw[3], Av[3];
+  cross3(vs, u, w);
+  symv<3>(S, u, Au);
+  symv<3>(S, w, Aw);
+  symv<3>(S, vs, Av);
+  const T k00 = dot3(u, Au), k01 = dot3(u, Aw), k11 = dot3(w, Aw);
+  const T t = jacobi_tan(k11 - k00, T(2) * k01);  // 0 when k01 = 0
+  const T c = Rm<T>::rsqrt(t * t + T(1)), sr = t * c;
+  lam[0] = dot3(vs, Av);
+  lam[1] = k00 - t * k01;
+  lam[2] = k11 + t * k01;
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    V[r()][0] = vs[r()];
+    V[r()][1] = c * u[r()] - sr * w[r()];
+    V[r()][2] = sr * u[r()] + c * w[r()];
+  });
+}
+
 // One-sided (Hestenes) Jacobi SVD: orthogonalise the K columns G[:,0..K-1] (length N each, G = J^T),
 // accumulating the rotations in V (K x K).  Afterwards G = U diag(sig), so for J = G^T (K x N):
 //   pinv(J)[i][r] = sum_{sig_j > rcond * sig_max} G[i][j] V[r][j] / sig_j^2
@@ -1051,9 +1123,8 @@ ABRK_INL void point_inertia(const T (&L)[N * (N + 1) / 2], const T (&il)[N], con
   if (!direct && okA)  // lam_min/lam_max >= 1 / (trace(A) trace(A^-1)): nothing is truncated (see osc_law)
     direct = trace * (Mx[tri(0, 0)] + Mx[tri(1, 1)] + Mx[tri(2, 2)]) * rcond < T(1);
   if (!direct) {
-    T S[6], V[3][3], lam[3];
-    sfor<6>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
-    jacobi_eig<3>(S, V, lam);
+    T V[3][3], lam[3];
+    sym3_eig(Am, V, lam);
     T smax = T(0);
     sfor<3>([&](auto r) ABRK_LAMBDA { smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()])); });
     T cut = rcond * smax, wv[3];

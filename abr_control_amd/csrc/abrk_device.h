@@ -86,6 +86,7 @@ struct Rm<double> {
     }
     sincos_fast(x, s, c);
   }
+  static ABRK_INL double acos(double x) { return ::acos(x); }
   static ABRK_INL bool sincos_in_range(double x) { return ::fabs(x) < 1.0e5; }
   static ABRK_INL bool sincos_tab_in_range(double x) { return ::fabs(x) < 1.0e5; }
   // the branch-free main path (valid for |x| < 1e5)
@@ -175,6 +176,7 @@ struct Rm<double> {
 template <>
 struct Rm<float> {
   static ABRK_INL void sincos(float x, float& s, float& c) { ::sincosf(x, &s, &c); }  // a custom routine measured no faster
+  static ABRK_INL float acos(float x) { return ::acosf(x); }
   static ABRK_INL bool sincos_in_range(float) { return true; }  // the library routine serves every argument
   static ABRK_INL bool sincos_tab_in_range(float x) { return ::fabsf(x) < 1.0e5f; }
   static ABRK_INL void sincos_fast(float x, float& s, float& c) { ::sincosf(x, &s, &c); }

@@ -225,6 +225,17 @@ def osc_mx(n, M, J, threshold=1e-3, dtype=np.float64):
     return Mx, Minv
 
 
+def sym3_eig(A, dtype=np.float64):
+    """the device code's direct symmetric 3x3 eigen-solver (abrk_ctrl.h `sym3_eig`): -> (lam [B,3], V [B,3,3])"""
+    dt = np.dtype(dtype)
+    A = _in(A, dt)
+    B = A.shape[0]
+    lam, V = np.full((B, 3), np.nan, dt), np.full((B, 3, 3), np.nan, dt)
+    rc = _lib_for(law=True).hostsim_sym3_eig(_dtype_code(dt), C.c_int64(B), _p(A), _p(lam), _p(V))
+    assert rc == 0, rc
+    return lam, V
+
+
 def osc_velocity_limiting(params, u_task, dtype=np.float64):
     dt = np.dtype(dtype)
     u_task = _in(u_task, dt)

@@ -286,6 +286,26 @@ extern "C" int hostsim_osc_mx(int n, int k, int dtype, int64_t B, const void* M,
 #undef MX_CASE
   return -1;
 }
+// the direct symmetric 3x3 eigen-solver on its own (A: [B,3,3] symmetric; lam [B,3], V [B,3,3] columns = eigenvectors)
+extern "C" int hostsim_sym3_eig(int dtype, int64_t B, const void* A, void* lam, void* V) {
+  auto run = [&](auto tag) {
+    using T = decltype(tag);
+    const T* a = (const T*)A;
+    for (long b = 0; b < B; b++) {
+      T S[6], Vv[3][3], l[3];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c <= r; c++) S[tri(r, c)] = a[b * 9 + r * 3 + c];
+      sym3_eig<T>(S, Vv, l);
+      for (int r = 0; r < 3; r++) {
+        ((T*)lam)[b * 3 + r] = l[r];
+        for (int c = 0; c < 3; c++) ((T*)V)[b * 9 + r * 3 + c] = Vv[r][c];
+      }
+    }
+  };
+  if (dtype == 0) run(double{});
+  else run(float{});
+  return 0;
+}
 extern "C" int hostsim_velocity_limiting(int dtype, const abrk_osc_params* P, int64_t B, const void* in, void* out) {
   for (long b = 0; b < B; b++) {
     if (dtype == 0)

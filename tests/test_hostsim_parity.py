@@ -399,3 +399,57 @@ def test_rows_fused_full_outputs(arm, kw):
         assert np.allclose(u1, u0, rtol=1e-12, atol=1e-12) and np.allclose(ts1, ts0, rtol=1e-12, atol=1e-12)
         for k in ("Tx", "J", "M", "g"):
             assert np.allclose(dyn[k], ref[k], rtol=1e-13, atol=1e-13), (arm, k)
+
+
+def test_rows_direct_sym3_eigensolver():
+    """abrk_ctrl.h `sym3_eig` (the sweep-free eigen-decomposition behind AvoidObstacles' truncated pinv) against
+    numpy.linalg.eigvalsh / pinv on the matrices that break closed forms: rank 1 and rank 2 (what the first two
+    segments of every arm produce), clustered pairs at either end, spectra graded over 12 decades, multiples of the
+    identity, diagonal input - eigenvalues to a few eps |A|, V orthonormal, pinv(rcond=0.01) as numpy's"""
+    from tests import hostsim
+
+    rng = np.random.RandomState(7)
+    mats, kinds = [], []
+    for trial in range(6000):
+        kind = trial % 8
+        Q, _ = np.linalg.qr(rng.randn(3, 3))
+        if kind == 0:
+            lam = np.array([1.0, 0, 0]) * rng.uniform(0.1, 10)
+        elif kind == 1:
+            lam = np.array([1.0, rng.uniform(1e-3, 1), 0])
+        elif kind == 2:
+            lam = 10 ** rng.uniform(-12, 0, 3)
+        elif kind == 3:
+            lam = np.array([1.0, 1 + rng.uniform(-1e-9, 1e-9), rng.uniform(0, 1e-3)])
+        elif kind == 4:
+            l1 = rng.uniform(0, 1e-3)
+            lam = np.array([1.0, l1, l1 * (1 + rng.uniform(-1e-9, 1e-9))])
+        elif kind == 5:
+            lam = rng.uniform(0, 1, 3)
+        elif kind == 6:
+            lam = np.full(3, rng.uniform(0.1, 5)) * (1 + rng.uniform(-1e-15, 1e-15, 3))
+        else:
+            lam, Q = rng.uniform(0, 1, 3), np.eye(3)[rng.permutation(3)]
+        A = (Q * lam) @ Q.T
+        mats.append((A + A.T) / 2)
+        kinds.append(kind)
+    A = np.array(mats)
+    lam, V = hostsim.sym3_eig(A)
+    ref = np.linalg.eigvalsh(A)
+    scale = np.abs(ref).max(axis=1)
+    assert (np.abs(np.sort(lam, axis=1) - ref).max(axis=1) / scale).max() < 2e-14
+    assert np.abs(np.einsum("bij,bik->bjk", V, V) - np.eye(3)).max() < 1e-14
+    # A V = V diag(lam)
+    assert (np.abs(np.einsum("bij,bjk->bik", A, V) - V * lam[:, None, :]).max(axis=(1, 2)) / scale).max() < 1e-13
+    sv = np.abs(ref) / scale[:, None]
+    clear = np.all(np.abs(sv - 0.01) > 1e-6, axis=1)  # away from the cut, where either answer is legitimate
+    cut = 0.01 * np.abs(lam).max(axis=1, keepdims=True)
+    w = np.where(np.abs(lam) > cut, 1.0 / np.where(lam == 0, 1, lam), 0.0)
+    P = np.einsum("bij,bj,bkj->bik", V, w, V)
+    Pr = np.array([np.linalg.pinv(a, rcond=0.01, hermitian=True) for a in A])
+    err = np.abs(P - Pr).max(axis=(1, 2)) / np.abs(Pr).max(axis=(1, 2))
+    assert err[clear].max() < 1e-11, (err[clear].max(), kinds[int(np.argmax(np.where(clear, err, 0)))])
+    # fp32 instantiation: the same to single precision
+    lam32, V32 = hostsim.sym3_eig(A, dtype=np.float32)
+    assert (np.abs(np.sort(lam32, axis=1) - ref).max(axis=1) / scale).max() < 2e-5
+    assert np.abs(np.einsum("bij,bik->bjk", V32, V32) - np.eye(3)).max() < 1e-5

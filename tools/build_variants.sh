@@ -9,7 +9,7 @@ TU=${TU:-ur5}   # which arm translation unit to rebuild (TU=jaco2 tools/build_va
 OTHERS=$(ls build/*.o | grep -v abrk_arm_$TU.o)
 for spec in "$@"; do
   tag="${spec%%:*}"; flags="${spec#*:}"
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only -mllvm -amdgpu-sched-strategy=max-ilp $flags -c abrk_arm_$TU.hip -o variants/${TU}_$tag.o \
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-signed-zeros -ffinite-math-only -mllvm -amdgpu-sched-strategy=max-ilp -fno-slp-vectorize $flags -c abrk_arm_$TU.hip -o variants/${TU}_$tag.o \
     && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/libabrk_$tag.so variants/${TU}_$tag.o $OTHERS \
     && echo "built $tag" ) &
 done
