@@ -1255,6 +1255,26 @@ ABRK_INL void obstacles_row(const A& arm, const ObsP<T>& P, const T (&q)[A::N], 
   T noise = T(0);
   sfor<N>([&](auto i) ABRK_LAMBDA { noise += il[i()] * il[i()]; });
   noise *= sizeof(T) == 8 ? T(1e-24) : T(1e-10);
+  // The first two segments hang on one and two joints: their Mx_inv = J_b W J_b^T has rank 1 / 2 BY STRUCTURE (W = the
+  // leading 1x1 / 2x2 block of M^-1), the reference's pinv(rcond=0.01) always truncates there, and the general 3x3
+  // eigen path (~760 fp64 instructions per near pair) reduces to a division / a 2x2 problem in the plane of the two
+  // Jacobian columns.  W from the first two columns of L^-1, once per row:
+  T w00 = T(0), w01 = T(0), w11 = T(0);
+  {
+    T e[N], y0[N], y1[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { e[i()] = i() == 0 ? T(1) : T(0); });
+    chol_fwd<N>(L, il, e, y0);
+    w00 = T(0);
+    sfor<N>([&](auto i) ABRK_LAMBDA { w00 += y0[i()] * y0[i()]; });
+    if constexpr (N >= 2) {
+      sfor<N>([&](auto i) ABRK_LAMBDA { e[i()] = i() == 1 ? T(1) : T(0); });
+      chol_fwd<N>(L, il, e, y1);
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        w01 += y0[i()] * y1[i()];
+        w11 += y1[i()] * y1[i()];
+      });
+    }
+  }
   for (int ob = 0; ob < P.n; ob++) {
     const T v[3] = {P.obs[ob][0], P.obs[ob][1], P.obs[ob][2]};
     const T radius = P.obs[ob][3];
@@ -1300,12 +1320,55 @@ ABRK_INL void obstacles_row(const A& arm, const ObsP<T>& P, const T (&q)[A::N], 
               Jp[i()][0] = Jp[i()][1] = Jp[i()][2] = T(0);
             }
           });
-          T Mx[6], f[3];
-          point_inertia<N, T, false>(L, il, Jp, T(0), T(0.01), noise * len2, Mx);  // :114-117
-          symv<3>(Mx, F, f);
-          sfor<N>([&](auto i) ABRK_LAMBDA {
-            if constexpr (i() <= ii) u[i()] -= Jp[i()][0] * f[0] + Jp[i()][1] * f[1] + Jp[i()][2] * f[2];  // :119
-          });
+          const T floor = noise * len2;
+          bool done = false;
+          if constexpr (ii == 0) {
+            // rank 1: Mx_inv = w00 j j^T, pinv = j j^T / (w00 |j|^4), J^T Mx F = (j . F) / (w00 |j|^2)
+            const T tr = w00 * dot3(Jp[0], Jp[0]);
+            if (tr > floor) u[0] -= dot3(Jp[0], F) * rcp(tr);
+            done = true;
+          } else if constexpr (ii == 1) {
+            // rank 2: J_b = Q R (Q: orthonormal pair spanning the two columns), Mx_inv = Q (R W R^T) Q^T; the 2x2 block
+            // S = R W R^T has the non-zero eigenvalues of Mx_inv - closed form, one rotation; keep lam_- iff
+            // lam_- > 0.01 lam_+;  J_b^T Mx F = R^T S^+ (Q^T F).  Degenerate pairs (a zero first column, parallel
+            // columns to working precision) take the general path.
+            const T g00 = dot3(Jp[0], Jp[0]);
+            const T ig0 = Rm<T>::rsqrt(Rm<T>::fmax(g00, Rm<T>::tiny()));
+            const T q0[3] = {Jp[0][0] * ig0, Jp[0][1] * ig0, Jp[0][2] * ig0};
+            const T r01 = dot3(q0, Jp[1]);
+            const T p1[3] = {Jp[1][0] - r01 * q0[0], Jp[1][1] - r01 * q0[1], Jp[1][2] - r01 * q0[2]};
+            const T h11 = dot3(p1, p1), g11 = dot3(Jp[1], Jp[1]);
+            if (g00 > T(0) && h11 > (sizeof(T) == 8 ? T(1e-20) : T(1e-8)) * g11) {
+              const T ih = Rm<T>::rsqrt(h11);
+              const T q1[3] = {p1[0] * ih, p1[1] * ih, p1[2] * ih};
+              const T r00 = g00 * ig0, r11 = h11 * ih;
+              // S = R W R^T, R = [[r00, r01], [0, r11]]
+              const T a0 = r00 * w00 + r01 * w01, a1 = r00 * w01 + r01 * w11;  // first row of R W
+              const T s00 = a0 * r00 + a1 * r01, s01 = a1 * r11, s11 = r11 * w11 * r11;
+              const T tr = s00 + s11;
+              if (tr > floor) {
+                const T t = jacobi_tan(s11 - s00, T(2) * s01);
+                const T c = Rm<T>::rsqrt(t * t + T(1)), sn = t * c;
+                const T l0 = s00 - t * s01, l1 = s11 + t * s01;  // eigenpairs (c, -sn) and (sn, c)
+                const T lmax = Rm<T>::fmax(l0, l1), cut = T(0.01) * lmax;
+                const T i0 = l0 > cut ? rcp(l0 > cut ? l0 : T(1)) : T(0), i1 = l1 > cut ? rcp(l1 > cut ? l1 : T(1)) : T(0);
+                const T b0 = dot3(q0, F), b1 = dot3(q1, F);
+                const T z0 = (c * b0 - sn * b1) * i0, z1 = (sn * b0 + c * b1) * i1;  // S^+ b in the eigenbasis
+                const T x0 = c * z0 + sn * z1, x1 = -sn * z0 + c * z1;
+                u[0] -= r00 * x0;
+                u[1] -= r01 * x0 + r11 * x1;
+              }
+              done = true;
+            }
+          }
+          if (!done) {
+            T Mx[6], f[3];
+            point_inertia<N, T, false>(L, il, Jp, T(0), T(0.01), floor, Mx);  // :114-117
+            symv<3>(Mx, F, f);
+            sfor<N>([&](auto i) ABRK_LAMBDA {
+              if constexpr (i() <= ii) u[i()] -= Jp[i()][0] * f[0] + Jp[i()][1] * f[1] + Jp[i()][2] * f[2];  // :119
+            });
+          }
         }
       }
     });

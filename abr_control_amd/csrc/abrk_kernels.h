@@ -321,8 +321,13 @@ floating_kernel(A arm, int dynamic, int task_space, long B, const T* __restrict_
   floating_body<A, T>(b, arm, dynamic, task_space, qg, dqg, ug, acc);
 }
 
+// measurement switch: 2 = cap at 256 VGPRs for two waves per SIMD (UR5 fp64: 320 -> 256 + 172 B of scratch).  Measured
+// no faster at 8 M rows (2830 vs 2822 us: the kernel is issue-bound) and slower at 4096 (38.5 vs 30.2 us), so 1 stays.
+#ifndef ABRK_OBS_WAVES
+#define ABRK_OBS_WAVES ABRK_MIN_WAVES
+#endif
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, ABRK_OBS_WAVES)
 obstacles_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
   ABRK_ROW_INDEX
   obstacles_body<A, T>(b, arm, P, qg, ug, acc);
