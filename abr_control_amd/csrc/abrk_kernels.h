@@ -146,6 +146,9 @@ struct LdsScratch : ScratchBase {
 // Worklist of deferred rows: kWlLists sub-lists (wavefront w appends to sub-list w mod kWlLists), each with its own
 // counter on its own 64-byte line - one shared counter serialises at ~90 atomics per microsecond, which at 8 M rows
 // (125 k wavefronts with a deferred row) cost 1.4 ms, three times the arithmetic.
+#ifndef ABRK_KM6_GRID_CAP
+#define ABRK_KM6_GRID_CAP 4096  // first pass of the six-row law: a persistent grid of at most this many blocks (a multiple of kWlLists)
+#endif
 constexpr int kWlLists = 256;
 constexpr long wl_capacity(long B) { return ((B + kBlock - 1) / kBlock / kWlLists + 1) * kBlock; }  // rows per sub-list
 constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(B); }
@@ -194,6 +197,11 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
     // their row, mode 2 strides a persistent grid over the worklist.  (Only the six-row kernels defer: with x,y,z
     // alone the two certificates leave < 0.01 % of the rows to the sweeps, and the loop form costs the three-row
     // kernels 40 registers.)
+    // Large batches run as a persistent grid (Launch::osc_launch caps it at ABRK_KM6_GRID_CAP blocks): the kernel holds
+    // one wavefront per SIMD (390-490 registers), so nothing hides a row's memory round trips but its neighbours in
+    // time - in the loop a row's stores drain under the next row's arithmetic (UR5, 8 M rows: 1133 -> 985 us).
+    // Requesting row i + step's inputs before working on row i was measured too: 36 more live registers cost more
+    // accumulator-register traffic than the hidden latency returns (1049 us against 1004 us on one box).
     const bool list = mode == 2;
     const int sub = (int)(blockIdx.x % kWlLists);
     const int* rows = wl + 16 * kWlLists + sub * wl_capacity(B);
@@ -329,9 +337,12 @@ floating_kernel(A arm, int dynamic, int task_space, long B, const T* __restrict_
 template <class A, class T>
 __global__ void __launch_bounds__(kBlock, ABRK_OBS_WAVES)
 obstacles_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
-  ABRK_ROW_INDEX
-  obstacles_body<A, T>(b, arm, P, qg, ug, acc);
+  // grid-stride (the launcher caps the grid at kObstaclesMaxBlocks): one wavefront per SIMD in fp64, so in the loop a
+  // row's stores drain under the next row's arithmetic, as in the six-row OSC kernels
+  for (long b = (long)blockIdx.x * kBlock + threadIdx.x; b < B; b += (long)gridDim.x * kBlock)
+    obstacles_body<A, T>(b, arm, P, qg, ug, acc);
 }
+constexpr long kObstaclesMaxBlocks = 4096;
 
 template <int N, class T>
 __global__ void __launch_bounds__(kBlock)
@@ -471,7 +482,9 @@ struct Launch {
     };
     if (a.wl && KM == 6) {
       (void)hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream);
-      go(grid_for(la.B), 1);
+      dim3 g1 = grid_for(la.B);
+      if (ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;  // a multiple of kWlLists
+      go(g1, 1);
       go(dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
     } else {
       go(grid_for(la.B), 0);
@@ -606,7 +619,9 @@ struct OpsFor {
   }
   template <class A, class T>
   static hipError_t obstacles_t(const LaunchArgs& la, const ObstaclesArgs& a) {
-    hipLaunchKernelGGL((obstacles_kernel<A, T>), grid_for(la.B), dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la),
+    const long blocks = (la.B + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL((obstacles_kernel<A, T>), dim3((unsigned)(blocks < kObstaclesMaxBlocks ? blocks : kObstaclesMaxBlocks)),
+                       dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la),
                        *static_cast<const ObsP<T>*>(a.P), la.B, (const T*)a.q, (T*)a.u, a.acc);
     return hipGetLastError();
   }
