@@ -21,6 +21,7 @@ def build_all(verbose=False):
     import threading
 
     abi = specialize.plugin_abi(from_sources=True)
+    specialize.prune(specialize.IN_TREE, abi)  # plugins of older kernel headers would only travel to the GPU box for nothing
     out, err = {}, []
 
     def one(name, tab):

@@ -124,3 +124,17 @@ def test_compile_arm_fails_loudly_without_a_compiler(monkeypatch, tmp_path):
     with pytest.raises(RuntimeError, match="hipcc not found"):
         specialize.compile_arm(tab, cache_dir=str(tmp_path))
     assert not any(f.endswith(".so") for _, _, fs in os.walk(tmp_path) for f in fs)
+
+
+def test_prune_drops_only_plugins_of_other_headers(tmp_path):
+    cur, old, other = tmp_path / "aaaa", tmp_path / "bbbb", tmp_path / "not_a_plugin"
+    for d, tag in ((cur, specialize.plugin_abi()), (old, "0123456789abcdef-00000000")):
+        d.mkdir()
+        (d / "arm.hip").write_text("// x\n")
+        (d / "arm.so").write_bytes(b"")
+        (d / "abi.txt").write_text(tag + "\n")
+    other.mkdir()
+    (other / "keep.txt").write_text("x")
+    gone = specialize.prune(str(tmp_path))
+    assert gone == [str(old)] and cur.exists() and other.exists() and not old.exists()
+    assert specialize.prune(str(tmp_path / "missing")) == []
