@@ -46,6 +46,9 @@ WORKLOADS = {
     # not a BASELINE config: the batched robot_config surface (Tx, J, M, g in one launch) - the
     # HBM-bound "full outputs" mode of SURVEY.md 8d
     "dynF": ("ur5", 4096, "f64", "dyn", dict(want=("Tx", "J", "M", "g")), 2500),
+    # the two velocity-dependent robot_config functions, the reference's most expensive ones (SURVEY 8a rows a6, a7:
+    # C 6338 + dJ 820 operations after CSE, 4.9 us per call): Christoffel matrix C [n,n] and dJ [6,n] from (q, dq)
+    "dynC": ("ur5", 4096, "f64", "dyn", dict(want=("C", "dJ")), 7200),
     # SURVEY 8d "Mode F": the control signal AND the robot_config outputs it consumed (Tx, J, M, g of the EE) from ONE
     # launch of the fused kernel (abrk_osc_generate_full_batch) - 192 + 648 = 840 B per row, HBM-bound
     "oscF": ("ur5", 4096, "f64", "osc_full", dict(kp=200), 3500),
@@ -68,11 +71,15 @@ ROLLOUT_STEPS = 1000
 ROOFLINE_WARMUP = 12
 
 
-def algorithmic_bytes(n, esz, kind):
+DYN_OUT = lambda n: {"Tx": 3, "J": 6 * n, "M": n * n, "g": n, "C": n * n, "dJ": 6 * n}  # values per row
+
+
+def algorithmic_bytes(n, esz, kind, want=None):
     """SURVEY.md 8d.  Mode U (controllers): read q, dq [n] + target, write u [n].
-    Full-output dynamics: read q [n], write Tx[3] + J[6,n] + M[n,n] + g[n]."""
+    Full-output dynamics: read q [n] (+ dq [n] for C, dJ), write the requested outputs (Tx[3], J[6,n], M[n,n], g[n], ...)."""
     if kind == "dyn":
-        return esz * n + esz * (3 + 6 * n + n * n + n)
+        want = want or ("Tx", "J", "M", "g")
+        return esz * n * (2 if ("C" in want or "dJ" in want) else 1) + esz * sum(DYN_OUT(n)[w] for w in want)
     if kind == "osc_full":  # Mode U (q, dq, target in; u out) + Tx, J, M, g out
         return esz * (2 * n + 6) + esz * n + esz * (3 + 6 * n + n * n + n)
     if kind == "ik":  # per launch and row: q, target in; position + velocity paths out
@@ -137,7 +144,7 @@ class Runner:
             self.t = a.DeviceArray.from_numpy(t6, device)
         elif kind in ("dyn", "osc_full"):
             n = self.n
-            shapes = {"Tx": (3,), "J": (6, n), "M": (n, n), "g": (n,)}
+            shapes = {"Tx": (3,), "J": (6, n), "M": (n, n), "g": (n,), "C": (n, n), "dJ": (6, n)}
             self.want = kw.get("want", ("Tx", "J", "M", "g"))
             self.dyn_out = {w: a.DeviceArray((B,) + shapes[w], self.dt, device) for w in self.want}
             if kind == "osc_full":
@@ -172,7 +179,8 @@ class Runner:
             # initialisation, not a step, whatever --warmup says (the rollout advances its state in place: left alone)
             self.step()
             stream.sync()
-        self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind)
+        self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind,
+                                                getattr(self, "want", None) if kind == "dyn" else None)
         self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else kw["n_timesteps"] if kind == "ik" else 1)
 
     def kernel_name(self):
@@ -187,7 +195,7 @@ class Runner:
             b = lambda v: "true" if v else "false"
             return f"osc_kernel<{arm}, {t}, {3 if fast else 6}, {b(p.use_C)}, {1 if p.n_null else 0}>"
         if k == "dyn":
-            return f"dyn_kernel<{arm}, {t}, false>"
+            return f"dyn_kernel<{arm}, {t}, {'true' if ('C' in self.want or 'dJ' in self.want) else 'false'}>"
         if k == "osc_full":
             return f"osc_full_kernel<{arm}, {t}, 3, {'true' if self.params.use_C else 'false'}, 0>"
         if k == "limits":
@@ -215,7 +223,8 @@ class Runner:
             self.engine.osc_rollout_twolink(self.arm_id, self.params, self.plant, self.q, self.dq, self.t,
                                             ROLLOUT_STEPS, dtype=self.dt, device=self.device, stream=self.stream)
         elif self.kind == "dyn":
-            self.engine.dynamics(self.arm_id, self.n, self.q, None, None, None, self.want, self.dt, self.device,
+            vel = self.dq if ("C" in self.want or "dJ" in self.want) else None
+            self.engine.dynamics(self.arm_id, self.n, self.q, vel, None, None, self.want, self.dt, self.device,
                                  self.stream, out=self.dyn_out)
         elif self.kind == "sliding":
             self.engine.sliding_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
@@ -440,7 +449,10 @@ def cpu_baseline(workload, budget_s=12.0):
     Bs, scale = 2048, 1
     q, dq, t = make_inputs(1, Bs, o.n, nt, np.float64)
     if kind == "dyn":
-        fn = lambda: [(o.Tx("EE", q[i]), o.J("EE", q[i]), o.M(q[i]), o.g(q[i])) for i in range(Bs)]
+        want = kw.get("want", ("Tx", "J", "M", "g"))
+        f1 = {"Tx": lambda i: o.Tx("EE", q[i]), "J": lambda i: o.J("EE", q[i]), "M": lambda i: o.M(q[i]),
+              "g": lambda i: o.g(q[i]), "C": lambda i: o.C(q[i], dq[i]), "dJ": lambda i: o.dJ("EE", q[i], dq[i])}
+        fn = lambda: [[f1[w](i) for w in want] for i in range(Bs)]
     elif kind == "sliding":
         p = _abi.make_sliding_params(o.n)
         fn = lambda: o.sliding_batch(p, q, dq, t)
