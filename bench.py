@@ -62,6 +62,8 @@ WORKLOADS = {
     # Sliding on the six-joint Jaco2 (general affine chain, full Christoffel matrix + dJ): the heaviest kernel of the set
     "sliding_j2": ("jaco2", 65536, "f64", "sliding", dict(), 12000),
     # the remaining secondary controllers as their own kernels (u [B,n] each)
+    # the Joint controller (joint.py:104-131, gravity-compensated PD in joint space), its own kernel
+    "joint": ("ur5", 4096, "f64", "joint", dict(kp=50, kv=7), 2700),
     "limits": ("ur5", 4096, "f64", "limits", dict(), 60),
     "floating": ("ur5", 4096, "f64", "floating", dict(dynamic=True, task_space=True), 3300),
     "obstacles": ("ur5", 4096, "f64", "obstacles", dict(threshold=0.3, gain=30, obstacles=[
@@ -90,6 +92,8 @@ def algorithmic_bytes(n, esz, kind, want=None):
         return esz * 2 * n
     if kind == "floating":  # q, dq in, u out
         return esz * 3 * n
+    if kind == "joint":  # q, dq, target [n] in, u out
+        return esz * 4 * n
     nt = 3 if kind == "sliding" else 6
     return esz * (2 * n + nt) + esz * n
 
@@ -158,6 +162,9 @@ class Runner:
                 [False, True, False, False, False, True])
         elif kind == "floating":
             self.params = kw
+        elif kind == "joint":
+            self.params = _abi.make_joint(**kw)
+            self.tj = a.DeviceArray.from_numpy(np.random.RandomState(3).uniform(0, 2 * np.pi, (B, self.n)).astype(self.dt), device)
         elif kind == "obstacles":
             self.params = _abi.make_obstacles_params(**kw)
         else:
@@ -236,6 +243,9 @@ class Runner:
             self.engine.floating_generate(self.arm_id, self.n, self.params["dynamic"], self.params["task_space"],
                                           self.q, self.dq, u=self.u, dtype=self.dt, device=self.device,
                                           stream=self.stream)
+        elif self.kind == "joint":
+            self.engine.joint_generate(self.arm_id, self.n, self.params, True, self.q, self.dq, self.tj, None, u=self.u,
+                                       dtype=self.dt, device=self.device, stream=self.stream)
         elif self.kind == "obstacles":
             self.engine.avoid_obstacles_generate(self.arm_id, self.n, self.params, self.q, u=self.u, dtype=self.dt,
                                                  device=self.device, stream=self.stream)
@@ -484,6 +494,9 @@ def cpu_baseline(workload, budget_s=12.0):
         fn = lambda: avoid_joint_limits_batch(o.n, p, q)
     elif kind == "floating":
         fn = lambda: o.floating_batch(kw["dynamic"], kw["task_space"], q, dq)
+    elif kind == "joint":
+        tj = np.random.RandomState(3).uniform(0, 2 * np.pi, q.shape)
+        fn = lambda: o.joint_batch(_abi.make_joint(**kw), True, q, dq, tj)
     elif kind == "obstacles":
         p = _abi.make_obstacles_params(**kw)
         fn = lambda: o.avoid_obstacles_batch(p, q)

@@ -13,7 +13,7 @@ python tools/coop_ab.py $O/coop_ab.md > $O/coop_ab.log 2>&1; tail -3 $O/coop_ab.
 python tools/rt_ab.py $O/rt_ab.md > $O/rt_ab.log 2>&1; tail -3 $O/rt_ab.log   # needs the ur5 / jaco2 / threejoint plugins in the in-tree cache
 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err; tail -3 $O/bench_cfg2.err
 for w in cfg3 cfg4 cfg5 osc6 sliding_j2 oscF; do python bench.py --workload $w --steps 500 --warmup 50 --no-cpu-baseline --no-strong-leg > $O/bench_$w.json 2> $O/bench_$w.err; done
-for w in limits floating obstacles rollout ik dynF dynC; do python bench.py --workload $w --steps 200 --warmup 20 --roofline-batch 4194304 --roofline-steps 10 --no-strong-leg > $O/bench_$w.json 2> $O/bench_$w.err; done
+for w in limits floating joint obstacles rollout ik dynF dynC; do python bench.py --workload $w --steps 200 --warmup 20 --roofline-batch 4194304 --roofline-steps 10 --no-strong-leg > $O/bench_$w.json 2> $O/bench_$w.err; done
 ALSO="--no-streams-leg --no-strong-leg --also cfg3,cfg4,cfg5,osc6,sliding_j2,limits,floating,obstacles"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $ALSO > $O/stats.log 2>&1
