@@ -557,7 +557,8 @@ std::vector<WorklistSlot> g_wl_cache;
 int* worklist_for(int device, hipStream_t stream, int64_t B) {
   static const bool off = getenv("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
   // below ~16 k rows the second launch costs more than the divergence it removes (B = 4096: 32 -> 38 us per step)
-  if (off || B < 16384) return nullptr;
+  // (row indices are parked as 32-bit ints: batches beyond 2^31 rows - they fit the 288 GB for fp32 arms - run inline)
+  if (off || B < 16384 || B > 0x7fffffffLL) return nullptr;
   const size_t need = (size_t)wl_ints(B) * sizeof(int);
   if (Recorder* r = t_rec) {
     void* p = nullptr;
