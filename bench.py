@@ -43,6 +43,8 @@ WORKLOADS = {
     "cfg3": ("jaco2", 16384, "f64", "osc_damp", dict(kp=200), 4500),
     "cfg4": ("ur5", (1 << 20) // 8, "f64", "osc", dict(kp=200, use_g=True, use_C=True), 10000),
     "cfg5": ("threejoint", 65536, "f32", "sliding", dict(), 1200),
+    # config 2's law in single precision (every kernel exists in both arithmetic types; tolerance 1e-4 as for config 5)
+    "cfg2_f32": ("ur5", 4096, "f32", "osc", dict(kp=200), 3500),
     # not a BASELINE config: the batched robot_config surface (Tx, J, M, g in one launch) - the
     # HBM-bound "full outputs" mode of SURVEY.md 8d
     "dynF": ("ur5", 4096, "f64", "dyn", dict(want=("Tx", "J", "M", "g")), 2500),
