@@ -1475,3 +1475,61 @@ def test_gpu_compiled_user_arm_against_the_oracle_and_the_runtime_table_kernels(
     s.sync()
     assert np.array_equal(ud.numpy(), cu.osc(P(4, kp=30), q, dq, t)[0])
     plan.close()
+
+
+def test_gpu_concurrent_threads_own_streams():
+    """include/abrk.h: entry points are re-entrant per (device, stream).  Eight host threads, each with its own stream,
+    mix host-staged calls, device-resident calls, the six-row law with its deferred pass (worklists cached per stream),
+    recording + replay of launch plans (the recorder is per thread) and user-arm registration / release (one registry) -
+    every result must equal the single-threaded one bit for bit"""
+    import ctypes as C
+    import threading
+
+    import abr_control_amd as a
+    from abr_control_amd import engine
+    from abr_control_amd._lib import check, lib
+
+    arm = check(lib().abrk_arm_builtin(b"ur5"))
+    P3, P6 = _abi.make_osc_params(6, kp=200, use_C=True), _abi.make_osc_params(6, kp=100, ko=80, ctrlr_dof=[1] * 6)
+    desc = _abi.desc_from_table(_abi.load_table("jaco2"))
+    n_threads, rounds = 8, 12
+    inputs = [draw(100 + k, 20000 + 64 * k, 6) for k in range(n_threads)]
+    expect = [(engine.osc_generate(arm, 6, P3, *inputs[k]), engine.osc_generate(arm, 6, P6, *inputs[k]))
+              for k in range(n_threads)]
+    errors = []
+
+    def work(k):
+        try:
+            q, dq, t = inputs[k]
+            s = a.Stream(0)
+            qd, dd, td = (a.DeviceArray.from_numpy(x) for x in (q, dq, t))
+            u3, u6 = a.DeviceArray(q.shape), a.DeviceArray(q.shape)
+            for r in range(rounds):
+                # host arrays in and out (per-thread staging), on this thread's stream
+                assert np.array_equal(engine.osc_generate(arm, 6, P3, q, dq, t, stream=s), expect[k][0])
+                # device-resident, six rows: deferred second pass with this stream's worklist
+                engine.osc_generate(arm, 6, P6, qd, dd, td, u=u6, stream=s)
+                # a plan recorded and replayed by this thread while the others record theirs
+                with engine.Plan(0, s) as plan:
+                    engine.osc_generate(arm, 6, P3, qd, dd, td, u=u3, stream=s)
+                    engine.osc_generate(arm, 6, P6, qd, dd, td, u=u6, stream=s)
+                plan.launch()
+                plan.launch_graph(2)
+                s.sync()
+                assert np.array_equal(u3.numpy(), expect[k][0]) and np.array_equal(u6.numpy(), expect[k][1])
+                plan.close()
+                # the arm registry under contention
+                uid = check(lib().abrk_arm_create(C.byref(desc)))
+                assert uid >= 5
+                um = engine.dynamics(uid, 6, q[:64], None, _abi.frame_id("EE", 6), None, ("M",), np.float64, 0, s)["M"]
+                assert np.isfinite(um).all()
+                assert lib().abrk_arm_destroy(uid) == 0
+        except BaseException as e:  # noqa: BLE001 - reported on the main thread
+            errors.append((k, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
