@@ -129,6 +129,32 @@ class BatchedConfig:
         except Exception:  # noqa: BLE001
             pass
 
+    # A copy (copy.copy / deepcopy / pickle) must not share the registry handle: the first of the two to be collected
+    # would hand the slot back under the other.  Copies start unregistered and take a handle of their own at first use.
+    # (The library also tags user-arm ids with a generation, so a stale id fails with ENOARM instead of reaching
+    # whatever arm took the slot next.)
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_arm_id"] = None
+        st["_plugin_path"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+
+    def __copy__(self):
+        new = self.__class__.__new__(self.__class__)
+        new.__setstate__(self.__getstate__())
+        return new
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        new.__setstate__(copy.deepcopy(self.__getstate__(), memo))
+        return new
+
     def frame_id(self, name):
         return _abi.frame_id(name, self.N_JOINTS)
 

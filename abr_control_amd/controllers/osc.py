@@ -175,12 +175,7 @@ class OSC(Controller):
                 if not isinstance(ie, DeviceArray) or ie.shape != (B, 6):
                     ie = self.integrated_error = DeviceArray((B, 6), rc.dtype, rc.device).zero_()
             else:
-                ie = np.asarray(ie, dtype=rc.dtype)
-                if ie.shape == (6,) and B == 1:
-                    ie = ie.reshape(1, 6)
-                if ie.shape != (B, 6):
-                    ie = np.zeros((B, 6), rc.dtype)
-                ie = np.ascontiguousarray(ie)
+                ie = self._host_integrated_error(B, rc.dtype)
         une = None
         if self._foreign:
             if on_device:
@@ -216,6 +211,16 @@ class OSC(Controller):
             return (u[0] if single else u), dyn
         return u[0] if single else u
 
+    def _host_integrated_error(self, B, dtype):
+        """the per-row integral state (osc.py:81-82, 262-264) as the [B, 6] array a call updates in place: a single
+        state keeps it as (6,) between calls (what the reference stores); a batch of another size starts from zero"""
+        ie = np.asarray(self.integrated_error, dtype=dtype)
+        if ie.shape == (6,) and B == 1:
+            ie = ie.reshape(1, 6)
+        if ie.shape != (B, 6):
+            ie = np.zeros((B, 6), dtype)
+        return np.ascontiguousarray(ie)
+
     def _generate_foreign(self, q, dq, target, target_velocity, ref_frame, xyz_offset):
         """robot_config is not an abr_control_amd config: gather its J/M/Tx/g/C/R per state (its own code,
         as osc.py:242-301 calls them) and run the law on the GPU."""
@@ -245,11 +250,7 @@ class OSC(Controller):
                     une[b] += nc.generate(q2[b], dq2[b])
         ie = None
         if self.ki != 0:
-            ie = np.asarray(self.integrated_error, dtype=float)
-            ie = ie.reshape(1, 6) if ie.shape == (6,) and B == 1 else ie
-            if ie.shape != (B, 6):
-                ie = np.zeros((B, 6))
-            ie = np.ascontiguousarray(ie)
+            ie = self._host_integrated_error(B, float)
         device = getattr(rc, "device", 0)
         u, ts = engine.osc_law(n, self._params(ref_frame, xyz_offset), J, M, dq2, t2, g=g, Cdq=Cdq, xyz=xyz, R=R,
                                q=q2, target_velocity=tv2, integrated_error=ie, u_null_ext=une,

@@ -799,6 +799,233 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   }
 }
 
+// ---- the same law for all six task rows (any ctrlr_dof, ref_frame, orientation control), restructured around its
+// register peak.  osc_law above keeps Jr (6 N values), Y = L^-1 J^T (6 N), M, its factor and two 6 x 6 factors alive
+// together: 390-490 registers, ONE wave per SIMD.  Here
+//   * the six (masked) rows of the task Jacobian sit in `js` - the wavefront's LDS slab on the GPU (LdsScratch), plain
+//     arrays in the host check build and the law-only kernel - and are read back a row at a time: for Y, for J^T f,
+//     for J v and J dq;
+//   * everything that only needs the kinematic outputs (the task-space forces incl. the orientation error, M dq, the
+//     secondary controllers' M v) is reduced to its N- or 6-vector BEFORE the factorisations, so p, RF, the target and M
+//     are dead by then;
+//   * Y is held three rows at a time: Mx_inv = Y Y^T in two row blocks of three (+3 forward solves, -18 live values).
+// Same arithmetic per entry as osc_law (Gram form of Mx_inv, Cholesky, the two certificates, Jacobi behind them);
+// only the order of independent steps differs.  Two waves per SIMD on the six-joint arms.
+template <int N, class T, bool USE_C, int FEAT, class Rows>
+ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
+                       const T (&cvec)[N], const Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
+                       const T (&dq)[N], const T (&tgt)[6], bool tv_given, const T (&tvin)[6], bool have_ierr,
+                       T (&ierr)[6], bool have_ext, const T (&une)[N], T (&u)[N], T (&ts)[N], bool* defer = nullptr) {
+  constexpr int KM = 6;
+  bool sel[KM];
+  sfor<KM>([&](auto r) ABRK_LAMBDA { sel[r()] = P.dof[r()] != 0; });
+
+  // desired task-space forces (osc.py:250-259)
+  T ut[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+  if (P.pos_on) sfor<3>([&](auto r) ABRK_LAMBDA { ut[r()] = p[r()] - tgt[r()]; });
+  if (P.ori_on) {
+    T abg[3] = {tgt[3], tgt[4], tgt[5]}, uo[3];
+    orientation_forces(P.alg, RF, abg, uo);
+    sfor<3>([&](auto r) ABRK_LAMBDA { ut[3 + r()] = uo[r()]; });
+  }
+  // integral term (osc.py:262-264).  (A deferred row returns below without its state being stored.)
+  if (FEAT >= 2 && have_ierr) {
+    sfor<6>([&](auto r) ABRK_LAMBDA {
+      ierr[r()] += ut[r()];
+      ut[r()] += P.ki * ierr[r()];
+    });
+  }
+  // gains / velocity limiting (osc.py:266-272, 198-215; constants osc.py:89-115)
+  if (P.use_vmax) {
+    T sat_xyz = P.vmax0 / P.kp * P.kv, sat_abg = P.vmax1 / P.ko * P.kv;
+    T nx = Rm<T>::sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
+    T na = Rm<T>::sqrt(ut[3] * ut[3] + ut[4] * ut[4] + ut[5] * ut[5]);
+    T sx = (nx > sat_xyz) ? sat_xyz / nx : T(1);
+    T sa = (na > sat_abg) ? sat_abg / na : T(1);
+    T lx = P.kp / P.kv, la = P.ko / P.kv;
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      ut[r()] = P.kv * sx * lx * ut[r()];
+      ut[3 + r()] = P.kv * sa * la * ut[3 + r()];
+    });
+  } else {
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      ut[r()] *= P.kp;
+      ut[3 + r()] *= P.ko;
+    });
+  }
+  // velocity compensation (osc.py:274-282)
+  bool tv_zero = true;
+  if (FEAT >= 2 && tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
+  T Mdq[N], u0[N];
+  symv<N>(Ms, dq, Mdq);
+  if (tv_zero) {
+    sfor<N>([&](auto i) ABRK_LAMBDA { u0[i()] = T(-1) * P.kv * Mdq[i()]; });
+  } else {
+    sfor<6>([&](auto r) ABRK_LAMBDA {
+      T row[N];
+      js.get_row(r, row);
+      T dx = T(-0.0);
+      sfor<N>([&](auto i) ABRK_LAMBDA { dx += row[i()] * dq[i()]; });
+      ut[r()] += P.kv * (dx - tvin[r()]);
+    });
+    sfor<N>([&](auto i) ABRK_LAMBDA { u0[i()] = T(0); });
+  }
+  T uts[KM];
+  sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
+
+  // secondary controllers (osc.py:310-318): v with u_null = M v, and un = M v while M is at hand
+  const bool nulls = FEAT >= 1 && (P.n_null > 0 || (FEAT >= 2 && have_ext));
+  T v[FEAT >= 1 ? N : 1], un[FEAT >= 1 ? N : 1];
+  if constexpr (FEAT >= 1) {
+    if (nulls) {
+      sfor<N>([&](auto i) ABRK_LAMBDA { v[i()] = T(0); });
+      for (int c = 0; c < P.n_null; c++) null_command<N>(P.nul[c], q, dq, v);
+      bool damping_only = P.n_null > 0;
+      T kvs = T(0);
+      for (int c = 0; c < P.n_null; c++) {
+        damping_only = damping_only && (P.nul[c].kind == 1);
+        kvs += P.nul[c].kv;
+      }
+      if (damping_only) sfor<N>([&](auto i) ABRK_LAMBDA { un[i()] = -kvs * Mdq[i()]; });
+      else symv<N>(Ms, v, un);
+    }
+  }
+
+  // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T = Y Y^T, Y = J L^-T (rows y_r = L^-1 j_r)
+  T L[N * (N + 1) / 2], il[N];
+  chol<N>(Ms, L, il);
+  if constexpr (FEAT >= 2) {
+    if (have_ext) {  // caller-evaluated u_null: v_ext = M^-1 u_ext
+      T y[N], w[N];
+      chol_fwd<N>(L, il, une, y);
+      chol_bwd<N>(L, il, y, w);
+      sfor<N>([&](auto i) ABRK_LAMBDA {
+        v[i()] += w[i()];
+        un[i()] += une[i()];
+      });
+    }
+  }
+  T Am[KM * (KM + 1) / 2];
+  auto yrow = [&](auto r, T(&y)[N]) ABRK_LAMBDA {
+    T b[N];
+    js.get_row(r, b);
+    chol_fwd<N>(L, il, b, y);
+  };
+  auto ydot = [&](const T(&a)[N], const T(&b)[N]) ABRK_LAMBDA -> T {
+    T acc = T(-0.0);
+    sfor<N>([&](auto i) ABRK_LAMBDA { acc += a[i()] * b[i()]; });
+    return acc;
+  };
+  {
+    T Ya[3][N];
+    sfor<3>([&](auto r) ABRK_LAMBDA { yrow(r, Ya[r()]); });
+    sfor<3>([&](auto r) ABRK_LAMBDA { sfor<r() + 1>([&](auto c) ABRK_LAMBDA { Am[tri(r(), c())] = ydot(Ya[r()], Ya[c()]); }); });
+    T Yb[3][N];
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      yrow(ic<3 + r()>{}, Yb[r()]);
+      sfor<3>([&](auto c) ABRK_LAMBDA { Am[tri(3 + r(), c())] = ydot(Yb[r()], Ya[c()]); });
+    });
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      sfor<r() + 1>([&](auto c) ABRK_LAMBDA { Am[tri(3 + r(), 3 + c())] = ydot(Yb[r()], Yb[c()]); });
+    });
+  }
+  T trace = T(0);
+  sfor<KM>([&](auto r) ABRK_LAMBDA {
+    trace += sel[r()] ? Am[tri(r(), r())] : T(0);
+    if (!sel[r()]) Am[tri(r(), r())] = T(1);
+  });
+  T LA[KM * (KM + 1) / 2], ila[KM], Mx[KM * (KM + 1) / 2];
+  bool okA = chol<KM>(Am, LA, ila);
+  T det = T(1);
+  sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
+  bool mx_explicit = FEAT != 0;
+  if constexpr (FEAT != 0) chol_inverse<KM>(LA, ila, Mx);
+  const T thr = T(1e-3), rcond = T(1e-3) * T(0.1);
+  if (!(okA && det >= thr)) {
+    // pinv branch (osc.py:142-145); the two certificates of osc_law
+    T bound = rcond;
+    sfor<KM>([&](auto r) ABRK_LAMBDA { bound *= sel[r()] ? trace : T(1); });
+    bool truncates = !(okA && det > bound);
+    if (truncates && okA) {
+      if constexpr (FEAT == 0) chol_inverse<KM>(LA, ila, Mx);
+      T tinv = T(0);
+      sfor<KM>([&](auto r) ABRK_LAMBDA { tinv += sel[r()] ? Mx[tri(r(), r())] : T(0); });
+      if (trace * tinv * rcond < T(1)) {
+        truncates = false;
+        mx_explicit = true;
+      }
+    }
+    if (truncates && (Rows::kDeferOnly || defer)) {
+      if (defer) *defer = true;  // worked off in the dense second pass; nothing of this row is written
+      return;
+    }
+    if constexpr (!Rows::kDeferOnly) if (truncates) {
+      T S[KM * (KM + 1) / 2], V[KM][KM], lam[KM];
+      sfor<KM*(KM + 1) / 2>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
+      jacobi_eig<KM>(S, V, lam);
+      T smax = T(0);
+      sfor<KM>([&](auto r) ABRK_LAMBDA {
+        bool mine = sel[r()];  // a masked row is an isolated unit diagonal: Jacobi never rotates it (see osc_law)
+        lam[r()] = mine ? lam[r()] : T(0);
+        smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()]));
+      });
+      T cut = rcond * smax;
+      T wv[KM];
+      sfor<KM>([&](auto r) ABRK_LAMBDA { wv[r()] = (Rm<T>::fabs(lam[r()]) > cut) ? rcp(lam[r()]) : T(0); });
+      sfor<KM>([&](auto a) ABRK_LAMBDA {
+        sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
+          T acc = T(-0.0);
+          sfor<KM>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
+          Mx[tri(a(), b())] = acc;
+        });
+      });
+      mx_explicit = true;
+    }
+  }
+
+  // f = Mx u_task[ctrlr_dof] (osc.py:285-288); f2 = Mx (J v) for the null-space filter
+  T f[KM], f2[FEAT >= 1 ? KM : 1];
+  if (mx_explicit) {
+    symv<KM>(Mx, uts, f);
+  } else {
+    T y[KM];
+    chol_fwd<KM>(LA, ila, uts, y);
+    chol_bwd<KM>(LA, ila, y, f);
+  }
+  if constexpr (FEAT >= 1) {
+    if (nulls) {
+      T jv[KM];
+      sfor<KM>([&](auto r) ABRK_LAMBDA {
+        T row[N];
+        js.get_row(r, row);
+        T acc = T(-0.0);
+        sfor<N>([&](auto i) ABRK_LAMBDA { acc += row[i()] * v[i()]; });
+        jv[r()] = acc;
+      });
+      symv<KM>(Mx, jv, f2);
+    }
+  }
+  // u = u0 - J^T f [- C dq]; training signal; + g; + (I - J^T Jbar^T) u_null = M v - J^T Mx (J v)
+  T a1[N], a2[FEAT >= 1 ? N : 1];
+  sfor<N>([&](auto i) ABRK_LAMBDA { a1[i()] = T(-0.0); });
+  if constexpr (FEAT >= 1) sfor<N>([&](auto i) ABRK_LAMBDA { a2[i()] = T(-0.0); });
+  sfor<KM>([&](auto r) ABRK_LAMBDA {
+    T row[N];
+    js.get_row(r, row);
+    sfor<N>([&](auto i) ABRK_LAMBDA { a1[i()] += row[i()] * f[r()]; });
+    if constexpr (FEAT >= 1) {
+      if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { a2[i()] += row[i()] * f2[r()]; });
+    }
+  });
+  sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = u0[i()] - a1[i()]; });
+  if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= cvec[i()]; });  // osc.py:291-292
+  sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297
+  if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gscale, gz[i()], u[i()]); });  // osc.py:300-301
+  if constexpr (FEAT >= 1) {
+    if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += un[i()] - a2[i()]; });
+  }
+}
+
 // `late()` loads the inputs that are not needed by the kinematics (target, velocities, state; dq
 // too unless the Coriolis term is on) - it is invoked after the register-pressure peak.
 // FEAT selects which optional inputs are compiled in: 0 = none (the plain law: ~70 registers fewer,
@@ -877,20 +1104,50 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     m = P.m_joints;
   }
   // task Jacobian, rows masked (osc.py:242-244)
-  T Jv[N][3], Jw[N][3];
-  jacobian(jt, p, m, Jv, Jw);
-  emit(p, Jv, Jw, d.Ms, d.gz);
-  ABRK_SCHED_FENCE();
-  late();
-  if constexpr (TWO_PASS)
-    osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
-                                  ierr, have_ext, une, u, ts, scr.defer_ptr());
-  else if constexpr (USE_C)
-    osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
-                                  ierr, have_ext, une, u, ts, scr.defer_ptr());
-  else  // no Coriolis vector: the slot is not read (d.gz stands in for the array type)
-    osc_law<N, T, KM, false, FEAT>(P, d.Ms, d.gz, T(9.81), d.gz, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin,
-                                   have_ierr, ierr, have_ext, une, u, ts, scr.defer_ptr());
+  if constexpr (FAST) {
+    T Jv[N][3], Jw[N][3];
+    jacobian(jt, p, m, Jv, Jw);
+    emit(p, Jv, Jw, d.Ms, d.gz);
+    ABRK_SCHED_FENCE();
+    late();
+    if constexpr (TWO_PASS)
+      osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
+                                    ierr, have_ext, une, u, ts, scr.defer_ptr());
+    else if constexpr (USE_C)
+      osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
+                                    ierr, have_ext, une, u, ts, scr.defer_ptr());
+    else  // no Coriolis vector: the slot is not read (d.gz stands in for the array type)
+      osc_law<N, T, KM, false, FEAT>(P, d.Ms, d.gz, T(9.81), d.gz, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin,
+                                     have_ierr, ierr, have_ext, une, u, ts, scr.defer_ptr());
+  } else {
+    {
+      // the six rows go to the row store (the LDS slab on the GPU - free again: rne_backward has read the wrenches)
+      T Jv[N][3], Jw[N][3];
+      jacobian(jt, p, m, Jv, Jw);
+      emit(p, Jv, Jw, d.Ms, d.gz);
+      sfor<6>([&](auto r) ABRK_LAMBDA {
+        const bool on = P.dof[r()] != 0;
+        T row[N];
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          const T val = (r() < 3) ? Jv[i()][r() % 3] : Jw[i()][r() % 3];
+          row[i()] = on ? val : T(0);
+        });
+        scr.put_row(r, row);
+      });
+      scr.seal();
+    }
+    ABRK_SCHED_FENCE();
+    late();
+    if constexpr (TWO_PASS)
+      osc_law6<N, T, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+                                 have_ext, une, u, ts, scr.defer_ptr());
+    else if constexpr (USE_C)
+      osc_law6<N, T, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+                                 have_ext, une, u, ts, scr.defer_ptr());
+    else
+      osc_law6<N, T, false, FEAT>(P, d.Ms, d.gz, T(9.81), d.gz, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+                                  have_ext, une, u, ts, scr.defer_ptr());
+  }
 }
 
 // ---------------------------------------------------------------- Sliding.generate, one row (sliding.py:34-99)

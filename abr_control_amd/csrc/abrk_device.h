@@ -882,6 +882,9 @@ ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, 
 // index in a worklist that a second, densely packed pass works off (abrk_kernels.h osc_kernel, modes 1 / 2).  Lanes
 // diverge otherwise: one such row makes its whole wavefront run the sweeps.
 struct ScratchBase {
+  // true in the first pass of the six-row kernels (DeferOnly below): the row program is compiled WITHOUT the eigen-
+  // decomposition - a row that needs it is always deferred - so its registers do not weigh on the two-wave budget
+  static constexpr bool kDeferOnly = false;
   bool allow_defer = false, deferred = false;
   ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
 };
@@ -889,6 +892,16 @@ template <class T, int N>
 struct RegScratch : ScratchBase {
   static constexpr bool kHasTab = false;  // no sin/cos table: the polynomial routine
   T f[N][3], t[N][3];
+  // rows of the task Jacobian for the six-row OSC law (osc_law6): plain arrays here, the wavefront's LDS slab on the GPU
+  T jrow[6][N];
+  template <int R>
+  ABRK_INL void put_row(ic<R>, const T (&row)[N]) {
+    sfor<N>([&](auto i) ABRK_LAMBDA { jrow[R][i()] = row[i()]; });
+  }
+  template <int R>
+  ABRK_INL void get_row(ic<R>, T (&row)[N]) const {
+    sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = jrow[R][i()]; });
+  }
   template <int K>
   ABRK_INL void put(ic<K>, const T (&fv)[3], const T (&tv)[3]) {
     sfor<3>([&](auto r) ABRK_LAMBDA {
@@ -904,6 +917,11 @@ struct RegScratch : ScratchBase {
       tv[r()] = t[K][r()];
     });
   }
+};
+
+template <class Scr>
+struct DeferOnly : Scr {
+  static constexpr bool kDeferOnly = true;
 };
 
 // a + al x d + w (w . d) - w2 d : acceleration of a point at offset d from a point of the same body whose

@@ -63,6 +63,8 @@ namespace {
 struct ArmEntry {
   bool live = false;
   bool builtin = false;
+  int gen = 0;  // user arms: bumped when the slot is freed - an id is slot | gen << kArmSlotBits, so a stale id (a copy of a
+                // closed config, a handle cached past abrk_arm_destroy) never matches the slot's next tenant
   abrk_arm_desc desc;
   const ArmOps* ops = nullptr;
   std::vector<unsigned char> rt64, rt32;  // RtArm<N,double> / RtArm<N,float> images (user arms on the runtime-table
@@ -77,10 +79,19 @@ struct PluginLib {
 std::vector<PluginLib> g_plugins;
 std::mutex g_mu;
 std::vector<ArmEntry> g_arms;
+constexpr int kArmSlotBits = 12, kArmSlots = 1 << kArmSlotBits, kArmGenMask = (1 << (31 - kArmSlotBits)) - 1;
+int arm_id_of(int slot) { return slot | (g_arms[slot].gen << kArmSlotBits); }
+// slot of a live arm id, or -1 (caller holds g_mu)
+int arm_slot(int id) {
+  if (id < 0) return -1;
+  const int slot = id & (kArmSlots - 1);
+  if (slot >= (int)g_arms.size() || !g_arms[slot].live || g_arms[slot].gen != (id >> kArmSlotBits)) return -1;
+  return slot;
+}
 
 void init_builtins() {
   if (!g_arms.empty()) return;
-  g_arms.reserve(4096);  // entries are handed out by address: never reallocate
+  g_arms.reserve(kArmSlots);  // entries are handed out by address: never reallocate
   g_arms.resize(5);
   desc_from_tab<Tab_ur5>(&g_arms[0].desc);
   g_arms[0].ops = ops_ur5();
@@ -100,8 +111,8 @@ void init_builtins() {
 ArmEntry* get_arm(int id) {
   std::lock_guard<std::mutex> lk(g_mu);
   init_builtins();
-  if (id < 0 || id >= (int)g_arms.size() || !g_arms[id].live) return nullptr;
-  return &g_arms[id];
+  const int slot = arm_slot(id);
+  return slot < 0 ? nullptr : &g_arms[slot];
 }
 }  // namespace
 
@@ -127,7 +138,7 @@ extern "C" int abrk_arm_create(const abrk_arm_desc* d) {
   int slot = -1;
   for (int i = 5; i < (int)g_arms.size() && slot < 0; i++)
     if (!g_arms[i].live) slot = i;
-  if (slot < 0 && g_arms.size() >= 4096) return fail(ABRK_ENOMEM, "too many arms (4096 live at once)");
+  if (slot < 0 && g_arms.size() >= (size_t)kArmSlots) return fail(ABRK_ENOMEM, "too many arms (%d live at once)", kArmSlots);
   ArmEntry e;
   e.live = true;
   e.desc = *d;
@@ -138,11 +149,12 @@ extern "C" int abrk_arm_create(const abrk_arm_desc* d) {
   rt_table_fill(d->n_joints, ABRK_F64, d, e.rt64.data());
   rt_table_fill(d->n_joints, ABRK_F32, d, e.rt32.data());
   if (slot >= 0) {
+    e.gen = g_arms[slot].gen;
     g_arms[slot] = std::move(e);
-    return slot;
+    return arm_id_of(slot);
   }
   g_arms.push_back(std::move(e));
-  return (int)g_arms.size() - 1;
+  return arm_id_of((int)g_arms.size() - 1);
 }
 
 namespace {
@@ -200,18 +212,19 @@ extern "C" int abrk_arm_create_compiled(const abrk_arm_desc* d, const char* plug
   int slot = -1;
   for (int i = 5; i < (int)g_arms.size() && slot < 0; i++)
     if (!g_arms[i].live) slot = i;
-  if (slot < 0 && g_arms.size() >= 4096) return fail(ABRK_ENOMEM, "too many arms (4096 live at once)");
+  if (slot < 0 && g_arms.size() >= (size_t)kArmSlots) return fail(ABRK_ENOMEM, "too many arms (%d live at once)", kArmSlots);
   ArmEntry e;
   e.live = true;
   e.desc = *d;
   e.desc.name[sizeof e.desc.name - 1] = 0;
   e.ops = pl->ops;
   if (slot >= 0) {
+    e.gen = g_arms[slot].gen;
     g_arms[slot] = std::move(e);
-    return slot;
+    return arm_id_of(slot);
   }
   g_arms.push_back(std::move(e));
-  return (int)g_arms.size() - 1;
+  return arm_id_of((int)g_arms.size() - 1);
 }
 
 extern "C" int abrk_arm_get_desc(int arm_id, abrk_arm_desc* out) {
@@ -224,11 +237,12 @@ extern "C" int abrk_arm_get_desc(int arm_id, abrk_arm_desc* out) {
 extern "C" int abrk_arm_destroy(int arm_id) {
   std::lock_guard<std::mutex> lk(g_mu);
   init_builtins();
-  if (arm_id < 5 || arm_id >= (int)g_arms.size() || !g_arms[arm_id].live)
-    return fail(ABRK_ENOARM, "arm id %d is not a user arm", arm_id);
-  g_arms[arm_id].live = false;
-  g_arms[arm_id].rt64 = {};
-  g_arms[arm_id].rt32 = {};
+  const int slot = arm_slot(arm_id);
+  if (slot < 5) return fail(ABRK_ENOARM, "arm id %d is not a (live) user arm", arm_id);
+  g_arms[slot].live = false;
+  g_arms[slot].gen = (g_arms[slot].gen + 1) & kArmGenMask;
+  g_arms[slot].rt64 = {};
+  g_arms[slot].rt32 = {};
   return 0;
 }
 
@@ -526,7 +540,7 @@ const void* arm_table(const ArmEntry* a, int dtype) {
 // enqueue now (and finish the staging), or keep the launch for the plan being recorded.  fn(arm_rt) launches the
 // kernel; it captures its arguments by value.
 template <class F>
-int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn) {
+int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn, std::unique_lock<std::mutex>* held = nullptr) {
   if (Recorder* r = t_rec) {
     if (st.staged) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
     if (st.device != r->device || st.stream != r->stream)
@@ -539,13 +553,21 @@ int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn) {
     r->steps.emplace_back([fn, rt]() { return fn(rt); });
     return 0;
   }
-  HIPCHK(fn(arm_table(a, dtype)));
+  const hipError_t le = fn(arm_table(a, dtype));
+  if (held && held->owns_lock()) held->unlock();  // everything that uses the shared scratch is enqueued
+  HIPCHK(le);
   return st.finish();
 }
 
 // Worklist of the six-row OSC kernels (rows whose law needs the Jacobi sweeps are deferred to a dense second pass,
 // abrk_kernels.h): wl_ints(B) ~ B + 20 k ints of device scratch.  Immediate calls take it from a cache keyed by (device, stream) -
-// calls on one stream are ordered, so the buffer can be reused; a recorded plan owns its own.
+// calls on one stream are ordered, so the buffer can be reused - PROVIDED the three launches that use it (memset of the
+// counters, pass 1, pass 2) enter the stream as a unit: several host threads may share a stream (every Python call
+// without an explicit stream is on the NULL stream, and ctypes releases the GIL), and memset A, pass-1 A, memset B,
+// pass-2 A would lose A's deferred rows (or overrun a list sized for one call).  So the caller keeps `hold` (g_wl_mu)
+// from here until its launches are enqueued (dispatch() releases it before any stream sync).  A grow frees the old
+// buffer only after draining the stream, which - every earlier user having enqueued under the same lock - covers all of
+// them.  A recorded plan owns its worklist.
 struct WorklistSlot {
   int device;
   hipStream_t stream;
@@ -554,33 +576,40 @@ struct WorklistSlot {
 };
 std::mutex g_wl_mu;
 std::vector<WorklistSlot> g_wl_cache;
-int* worklist_for(int device, hipStream_t stream, int64_t B) {
+// -> 0 and *out = the worklist (nullptr: run the sweeps inline), or an error code
+int worklist_for(int device, hipStream_t stream, int64_t B, int** out, std::unique_lock<std::mutex>& hold) {
+  *out = nullptr;
   static const bool off = getenv("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
   // below ~16 k rows the second launch costs more than the divergence it removes (B = 4096: 32 -> 38 us per step)
   // (row indices are parked as 32-bit ints: batches beyond 2^31 rows - they fit the 288 GB for fp32 arms - run inline)
-  if (off || B < 16384 || B > 0x7fffffffLL) return nullptr;
+  if (off || B < 16384 || B > 0x7fffffffLL) return 0;
   const size_t need = (size_t)wl_ints(B) * sizeof(int);
   if (Recorder* r = t_rec) {
     void* p = nullptr;
-    if (hipMalloc(&p, need) != hipSuccess) {
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
       (void)hipGetLastError();
-      return nullptr;  // no scratch: the kernel runs the sweeps inline
+      return fail(ABRK_ENOMEM, "worklist of the recorded six-row OSC call, hipMalloc(%zu): %s", need, hipGetErrorString(e));
     }
     r->dev_bufs.push_back(p);
-    return (int*)p;
+    *out = (int*)p;
+    return 0;
   }
-  std::lock_guard<std::mutex> lk(g_wl_mu);
+  hold = std::unique_lock<std::mutex>(g_wl_mu);
   WorklistSlot* s = nullptr;
   for (auto& e : g_wl_cache)
     if (e.device == device && e.stream == stream) s = &e;
   if (!s) {
-    if (g_wl_cache.size() >= 64) return nullptr;  // many short-lived streams: do not hoard scratch
+    if (g_wl_cache.size() >= 64) {  // many short-lived streams: do not hoard scratch, run the sweeps inline
+      hold.unlock();
+      return 0;
+    }
     g_wl_cache.push_back({device, stream, nullptr, 0});
     s = &g_wl_cache.back();
   }
   if (s->cap < need) {
     if (s->buf) {
-      (void)hipStreamSynchronize(stream);  // a launch in flight may still use the old buffer
+      (void)hipStreamSynchronize(stream);  // launches in flight may still use the old buffer (all enqueued: see above)
       (void)hipFree(s->buf);
     }
     s->buf = nullptr;
@@ -588,12 +617,14 @@ int* worklist_for(int device, hipStream_t stream, int64_t B) {
     void* p = nullptr;
     if (hipMalloc(&p, need + need / 4) != hipSuccess) {
       (void)hipGetLastError();
-      return nullptr;
+      hold.unlock();
+      return 0;  // no scratch on an immediate call: inline sweeps (same results)
     }
     s->buf = (int*)p;
     s->cap = need + need / 4;
   }
-  return s->buf;
+  *out = s->buf;
+  return 0;
 }
 
 int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
@@ -725,7 +756,9 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   oa.ts = st.fix(ts_, training_signal);
   oa.use_C = P->use_C ? 1 : 0;
   oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
-  if (oa.fast == 0 && !want) oa.wl = worklist_for(device, (hipStream_t)stream, B);
+  std::unique_lock<std::mutex> wl_hold;  // the (device, stream) worklist stays ours until the launches are enqueued
+  if (oa.fast == 0 && !want)
+    if (int rc = worklist_for(device, (hipStream_t)stream, B, &oa.wl, wl_hold)) return rc;
   const OscP<double> p64 = make_oscp<double>(*P, n);
   const OscP<float> p32 = make_oscp<float>(*P, n);
   const ArmOps* ops = a->ops;
@@ -734,7 +767,7 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
     OscArgs o = oa;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
     return ops->osc(dtype, LaunchArgs{rt, (long)B, hs}, o);
-  });
+  }, &wl_hold);
 }
 
 // ------------------------------------------------------------------------------- OSC, wave-cooperative mapping
@@ -1552,6 +1585,9 @@ extern "C" int abrk_plan_launch_graph(int plan, int repeat) {
     if (le != hipSuccess || ce != hipSuccess)
       return fail(ABRK_ENODEV, "graph capture failed: %s", hipGetErrorString(le != hipSuccess ? le : ce));
     HIPCHK(hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0));
+    // stage the executable graph's launch state on the device now, not inside the first launch (a short replay - the
+    // driver's 20 steps - is otherwise charged for it)
+    if (hipGraphUpload(pl->graph_exec, pl->stream) != hipSuccess) (void)hipGetLastError();  // optional: the launch uploads
     pl->graph_repeat = repeat;
   }
   HIPCHK(hipGraphLaunch(pl->graph_exec, pl->stream));

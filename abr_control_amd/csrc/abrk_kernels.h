@@ -77,8 +77,15 @@ dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, con
 #define ABRK_FEAT1_TWO_WAVES 1
 #endif
 // (use_C: only the two-pass form of orthogonal chains, abrk_ctrl.h osc_row, fits the two-wave budget)
-constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho) {
-  return (km <= 3 && (!use_c || (ABRK_C_TWO_WAVES && ortho)) && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES)))
+#ifndef ABRK_KM6_LDS
+#define ABRK_KM6_LDS 1  // six-row law: task Jacobian rows in the wavefront's LDS slab (0: registers, as in round 2)
+#endif
+#ifndef ABRK_KM6_TWO_WAVES
+#define ABRK_KM6_TWO_WAVES 1  // six-row law with its Jacobian rows in LDS (osc_law6)
+#endif
+constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho, int pass = 0) {
+  if (km == 6) return (pass == 1 && ABRK_KM6_TWO_WAVES && ABRK_KM6_LDS && (!use_c || ortho) && feat <= 1) ? 2 : ABRK_MIN_WAVES;
+  return ((!use_c || (ABRK_C_TWO_WAVES && ortho)) && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES)))
              ? 2
              : ABRK_MIN_WAVES;
 }
@@ -93,6 +100,7 @@ constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho) {
 #ifndef ABRK_SINCOS_TABLE
 #define ABRK_SINCOS_TABLE 1
 #endif
+
 // The wavefront's copy of the sin/cos table (abrk_sincos_table.h; 2 KiB in fp64, 1 KiB in fp32): two entries per
 // lane, from L2
 template <class T>
@@ -113,13 +121,42 @@ struct TabScratch : RegScratch<T, N> {
   static constexpr bool kHasTab = true;
   const void* sctab;
 };
+// The six-row OSC law (osc_law6) parks the six rows of the task Jacobian in the same slab once the Coriolis recursion is
+// through with it: [6][(N + 1) / 2][kBlock] pairs, the same 18 KiB for a six-joint arm.  That takes the 36 values out
+// of the register file for the whole law - what lets the six-row kernels hold two waves per SIMD.
+template <int N>
+constexpr int slab_pairs() { return 3 * N > 6 * ((N + 1) / 2) ? 3 * N : 6 * ((N + 1) / 2); }
 template <class T, int N>
 struct LdsScratch : ScratchBase {
   static constexpr bool kHasTab = (ABRK_SINCOS_TABLE != 0);
   using V2 = T __attribute__((ext_vector_type(2)));
-  V2* slab;  // [N][3][kBlock]
+  V2* slab;  // [N][3][kBlock] wrenches, then [6][(N + 1) / 2][kBlock] Jacobian rows
   int lane;
   const void* sctab;
+  static constexpr int NP = (N + 1) / 2;
+  template <int R>
+  __device__ __forceinline__ void put_row(ic<R>, const T (&row)[N]) {
+    sfor<NP>([&](auto k) ABRK_LAMBDA {
+      constexpr int i0 = 2 * k(), i1 = 2 * k() + 1;
+      slab[(R * NP + k()) * kBlock + lane] = V2{row[i0], i1 < N ? row[i1 < N ? i1 : i0] : T(0)};
+    });
+  }
+  // A row is read where it is used, every time: each read goes through a pointer the optimiser cannot see through
+  // (repeated reads of a row are not merged into one long-lived copy; the constant part of the address still folds
+  // into the instruction's offset field) and is fenced (the scheduler does not gather the reads at the top of the law)
+  // - left alone the compiler fetches all 6 N values up front and carries them through the law, i.e. spills them.
+  template <int R>
+  __device__ __forceinline__ void get_row(ic<R>, T (&row)[N]) const {
+    __builtin_amdgcn_sched_barrier(0);
+    const V2* vs = slab + lane;
+    asm volatile("" : "+v"(vs));
+    sfor<NP>([&](auto k) ABRK_LAMBDA {
+      constexpr int i0 = 2 * k(), i1 = 2 * k() + 1;
+      const V2 a = vs[(R * NP + k()) * kBlock];
+      row[i0] = a.x;
+      if constexpr (i1 < N) row[i1] = a.y;
+    });
+  }
   template <int K>
   __device__ __forceinline__ void put(ic<K>, const T (&fv)[3], const T (&tv)[3]) {
     slab[(K * 3 + 0) * kBlock + lane] = V2{fv[0], fv[1]};
@@ -157,17 +194,20 @@ constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(
 // (persistent grid: block b strides sub-list b mod kWlLists).  Lanes diverge, so in mode 0 one such row costs its whole wavefront
 // the sweeps - with all six task rows that is most wavefronts (9340 executed instructions per row on UR5 against
 // ~1700 without the sweeps).
-template <class A, class T, int KM, bool USE_C, int FEAT>
-__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
+// PASS (six-row kernels): 0 = the complete row program (modes 0 and 2: the sweeps are compiled in; one wave per SIMD),
+// 1 = the first pass (mode 1) - no eigen-decomposition in the code at all, two waves per SIMD.
+template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0>
+__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl) {
   constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
-  constexpr bool kLds = USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0);
+  // the slab: scratch of the Coriolis recursion (orthogonal chains) and / or the row store of the six-row law
+  constexpr bool kLds = (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) || (KM == 6 && (ABRK_KM6_LDS != 0));
   __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
   if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);  // every lane takes part: before any exit
   using V2 = typename LdsScratch<T, A::N>::V2;
-  __shared__ V2 slab[kLds ? A::N * 3 * kBlock : 1];
+  __shared__ V2 slab[kLds ? slab_pairs<A::N>() * kBlock : 1];
   auto row = [&](long b, bool allow_defer) ABRK_LAMBDA {
     auto go = [&](auto& scr) ABRK_LAMBDA {
       scr.allow_defer = allow_defer;
@@ -178,17 +218,17 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       }
     };
     if constexpr (kLds) {
-      LdsScratch<T, A::N> scr;
+      std::conditional_t<PASS == 1, DeferOnly<LdsScratch<T, A::N>>, LdsScratch<T, A::N>> scr;
       scr.slab = slab;
       scr.lane = (int)threadIdx.x;
       scr.sctab = sctab;
       go(scr);
     } else if constexpr (kTab) {
-      TabScratch<T, A::N> scr;
+      std::conditional_t<PASS == 1, DeferOnly<TabScratch<T, A::N>>, TabScratch<T, A::N>> scr;
       scr.sctab = sctab;
       go(scr);
     } else {
-      RegScratch<T, A::N> scr;
+      std::conditional_t<PASS == 1, DeferOnly<RegScratch<T, A::N>>, RegScratch<T, A::N>> scr;
       go(scr);
     }
   };
@@ -474,30 +514,34 @@ struct Launch {
     return hipGetLastError();
   }
   template <int KM, bool UC, int FEAT>
-  static void osc_launch(const LaunchArgs& la, const OscArgs& a) {
-    auto go = [&](dim3 grid, int mode) {
-      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
+  static hipError_t osc_launch(const LaunchArgs& la, const OscArgs& a) {
+    auto go = [&](auto pass, dim3 grid, int mode) {
+      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass()>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
                          *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
                          (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl);
     };
-    if (a.wl && KM == 6) {
-      (void)hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream);
-      dim3 g1 = grid_for(la.B);
-      if (ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;  // a multiple of kWlLists
-      go(g1, 1);
-      go(dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
-    } else {
-      go(grid_for(la.B), 0);
+    if constexpr (KM == 6) {
+      if (a.wl) {
+        // stale counters would let pass 1 append past its sub-lists: no launch without the memset
+        if (hipError_t e = hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream); e != hipSuccess) return e;
+        dim3 g1 = grid_for(la.B);
+        if (ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;  // a multiple of kWlLists
+        go(ic<1>{}, g1, 1);
+        go(ic<0>{}, dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
+        return hipSuccess;
+      }
     }
+    go(ic<0>{}, grid_for(la.B), 0);
+    return hipSuccess;
   }
   template <int KM, bool UC>
-  static void osc_launch_feat(const LaunchArgs& la, const OscArgs& a) {
+  static hipError_t osc_launch_feat(const LaunchArgs& la, const OscArgs& a) {
     // which optional inputs are present?  0: none, 1: fused null controllers only, 2: anything else
     const bool other = a.tv || a.ierr || a.une;
     const bool nulls = static_cast<const OscP<T>*>(a.P)->n_null > 0;
-    if (other) osc_launch<KM, UC, 2>(la, a);
-    else if (nulls) osc_launch<KM, UC, 1>(la, a);
-    else osc_launch<KM, UC, 0>(la, a);
+    if (other) return osc_launch<KM, UC, 2>(la, a);
+    if (nulls) return osc_launch<KM, UC, 1>(la, a);
+    return osc_launch<KM, UC, 0>(la, a);
   }
   template <int KM, bool UC, int FEAT>
   static void osc_full_launch(const LaunchArgs& la, const OscArgs& a) {
@@ -529,19 +573,15 @@ struct Launch {
   }
   static hipError_t osc(const LaunchArgs& la, const OscArgs& a) {
     if (a.want) return osc_full(la, a);
+    hipError_t e = hipSuccess;
     if (a.fast == 3) {
-      if (a.use_C) osc_launch_feat<3, true>(la, a);
-      else osc_launch_feat<3, false>(la, a);
+      e = a.use_C ? osc_launch_feat<3, true>(la, a) : osc_launch_feat<3, false>(la, a);
     } else if (a.fast == 2 && A::N <= 3) {
-      if constexpr (A::N <= 3) {
-        if (a.use_C) osc_launch_feat<2, true>(la, a);
-        else osc_launch_feat<2, false>(la, a);
-      }
+      if constexpr (A::N <= 3) e = a.use_C ? osc_launch_feat<2, true>(la, a) : osc_launch_feat<2, false>(la, a);
     } else {
-      if (a.use_C) osc_launch_feat<6, true>(la, a);
-      else osc_launch_feat<6, false>(la, a);
+      e = a.use_C ? osc_launch_feat<6, true>(la, a) : osc_launch_feat<6, false>(la, a);
     }
-    return hipGetLastError();
+    return e != hipSuccess ? e : hipGetLastError();
   }
   static hipError_t sliding(const LaunchArgs& la, const SlidingArgs& a) {
     const long blocks = (la.B + kBlock - 1) / kBlock;

@@ -153,7 +153,8 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // FEAT=false: every input is requested up front (one HBM round trip; 36 extra registers still
   // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
   // kinematics to keep that kernel's register peak down.
-  constexpr bool EARLY = FEAT < 2;
+  // (the six-row kernels ask late as well: their law, not the kinematics, is the register peak)
+  constexpr bool EARLY = FEAT < 2 && KM <= 3;
   // (ABRK_LATE_TARGET = 1 requests the target after the kinematics in the use_C kernels; measured unnecessary once
   //  the link wrenches of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
   constexpr bool EARLY_T = EARLY && !(USE_C && ABRK_LATE_TARGET);
@@ -277,8 +278,15 @@ ABRK_INL void osc_law_body(long b, const OscP<T>& P, long B, const T* __restrict
   opt(tvg, tv, ic<6>{}, T(0));
   opt(ierrg, ierr, ic<6>{}, T(0));
   opt(uneg, une, ic<N>{}, T(0));
-  osc_law<N, T, 6, true, 2>(P, Ms, gv, T(-1), cv, Jv, Jw, p, RF, q, dq, tgt, tvg != nullptr, tv, ierrg != nullptr,
-                               ierr, uneg != nullptr, une, u, ts);
+  RegScratch<T, N> rows;  // caller-supplied J: its six rows, masked (osc.py:244), in the law's row store
+  sfor<6>([&](auto r) ABRK_LAMBDA {
+    const bool on = P.dof[r()] != 0;
+    T row[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = on ? ((r() < 3) ? Jv[i()][r() % 3] : Jw[i()][r() % 3]) : T(0); });
+    rows.put_row(r, row);
+  });
+  osc_law6<N, T, true, 2>(P, Ms, gv, T(-1), cv, rows, p, RF, q, dq, tgt, tvg != nullptr, tv, ierrg != nullptr, ierr,
+                          uneg != nullptr, une, u, ts);
   store_row<N>(ug, b, u);
   if (tsg) store_row<N>(tsg, b, ts);
   if (ierrg) store_row<6>(ierrg, b, ierr);

@@ -60,8 +60,7 @@ class MultiDevice:
         B = q2.shape[0]
         ie = None
         if ctrlr.ki != 0:
-            ie = np.asarray(ctrlr.integrated_error, dtype=rc.dtype)
-            ie = np.ascontiguousarray(ie if ie.shape == (B, 6) else np.zeros((B, 6), rc.dtype))
+            ie = ctrlr._host_integrated_error(B, rc.dtype)  # a single state's (6,) is kept, as in OSC.generate
         u, ts = engine.osc_generate_sharded(rc.arm_id, rc.N_JOINTS, ctrlr._params(ref_frame, xyz_offset), q2, dq2, t2,
                                             self.devices, tv2, ie, training_signal=True, dtype=rc.dtype)
         if ctrlr.ki != 0:

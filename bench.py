@@ -13,7 +13,10 @@ shard (weak scaling, no collective on the data path); rank 0 prints ONE JSON lin
 Besides the contract fields the line carries
   roofline        - dominant kernel on an HBM-sized batch (>> 256 MiB Infinity Cache),
                     HIP-event timed on the launch stream: algorithmic bytes / launch time vs 8 TB/s,
-                    plus the FP64-VALU view (this kernel is above the FP64 ridge);
+                    plus the FP64-VALU view (this kernel is above the FP64 ridge).  `frac` is the SUSTAINED figure:
+                    the kernel launched back to back for --sustain-seconds (default 2 s), mean of the last second
+                    (the chip is power-limited on these kernels: the first launches after idle run at boost clocks,
+                    the limiter overshoots, then the rate settles); the short run is kept beside it as `short_run`;
   roofline_config - the same accounting for the config-sized (cache-resident, launch-bound) batch;
   cpu_baseline    - the CPU oracle (plain C port of the reference path) on this box's host cores.
 """
@@ -34,7 +37,7 @@ FP64_VALU_PEAK_TF = 78.6   # = 1/2 of the 157.3 TF fp32 vector peak
 # fp64 (a wave64 v_fma_f64 issues in 4 cycles), x 32 lanes/clk for fp32 (2 cycles; v_pk_* take 4 - no packed gain).
 # Measured by tools/microbench/valu_rates.hip on a short boost-clock run: 36.7 T (fp64), 65.1 T (fp32).
 ISSUE_PEAK_NOMINAL = {"f64": 1024 * 16 * 2.4e9, "f32": 1024 * 32 * 2.4e9}
-PROFILE_DIRS = ("round2", "round1")  # committed rocprofv3 evidence, newest first
+PROFILE_DIRS = ("round3", "round2", "round1")  # committed rocprofv3 evidence, newest first
 
 WORKLOADS = {
     # name: (arm, batch per GPU, dtype, kind, params kwargs, algorithmic flops per eval)
@@ -112,7 +115,9 @@ def make_inputs(seed, B, n, nt, dt):
 class Runner:
     """device-resident inputs + one launch per step()"""
 
-    def __init__(self, workload, B, device, stream):
+    def __init__(self, workload, B, device, stream, global_rows=None):
+        """global_rows = (lo, G): this runner holds rows [lo, lo + B) of ONE global batch of G seeded rows (the strong-
+        scaling leg: every rank draws the same G rows and keeps its contiguous shard)"""
         import abr_control_amd as a
         from abr_control_amd import _abi, engine
         from abr_control_amd._lib import check, lib
@@ -125,7 +130,11 @@ class Runner:
         self.nt = 3 if kind == "sliding" else 6
         self.arm_id = check(lib().abrk_arm_builtin(arm.encode()))
         self.B, self.device, self.stream = B, device, stream
-        q, dq, t = make_inputs(1, B, self.n, self.nt, self.dt)
+        if global_rows is None:
+            q, dq, t = make_inputs(1, B, self.n, self.nt, self.dt)
+        else:
+            lo, G = global_rows
+            q, dq, t = (np.ascontiguousarray(x[lo:lo + B]) for x in make_inputs(1, G, self.n, self.nt, self.dt))
         self.host = (q, dq, t)
         self.q = a.DeviceArray.from_numpy(q, device)
         self.dq = a.DeviceArray.from_numpy(dq, device)
@@ -202,7 +211,10 @@ class Runner:
             dof = list(p.ctrlr_dof)
             fast = dof == [1, 1, 1, 0, 0, 0] and p.ref_frame == 2 * self.n + 1
             b = lambda v: "true" if v else "false"
-            return f"osc_kernel<{arm}, {t}, {3 if fast else 6}, {b(p.use_C)}, {1 if p.n_null else 0}>"
+            # six task rows from 16 k rows on: first pass (PASS = 1, the dominant kernel) + a dense second pass (PASS = 0)
+            six_two_pass = (not fast) and self.B >= 16384
+            km = 3 if fast else (2 if dof == [1, 1, 0, 0, 0, 0] and self.n <= 3 and p.ref_frame == 2 * self.n + 1 else 6)
+            return f"osc_kernel<{arm}, {t}, {km}, {b(p.use_C)}, {1 if p.n_null else 0}, {1 if six_two_pass else 0}>"
         if k == "dyn":
             return f"dyn_kernel<{arm}, {t}, {'true' if ('C' in self.want or 'dJ' in self.want) else 'false'}>"
         if k == "osc_full":
@@ -213,11 +225,47 @@ class Runner:
             return f"rollout_kernel<{arm}, {t}, {'true' if self.params.use_C else 'false'}>"
         return f"{k}_kernel<{arm}, {t}>"
 
+    def grid_threads(self):
+        """threads of the dominant kernel's launch (grid x 64), as rocprofv3's Grid_Size prints it: the grid-stride
+        kernels cap their grid, so rows != threads for them (abrk_kernels.h: kSlidingMaxBlocks, kObstaclesMaxBlocks,
+        ABRK_KM6_GRID_CAP) - tools/summarize_profiles.py maps (kernel, Grid_Size) back to rows through this"""
+        blocks = (self.B + 63) // 64
+        if self.kind == "sliding":
+            blocks = min(blocks, 256 * 32 * 4)
+        elif self.kind == "obstacles":
+            blocks = min(blocks, 4096)
+        elif self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name() and self.B >= 16384:
+            blocks = min(blocks, 4096)
+        return blocks * 64
+
     def step(self):
         if self.plan is not None:
             self.plan.launch()
         else:
             self._enqueue()
+
+    def sustained(self, seconds, est_ms):
+        """the kernel launched back to back for >= `seconds`: HIP events every `chunk` launches, no host sync in
+        between (the stream never runs dry) -> per-launch ms of every chunk, in time order.  est_ms: the short run's
+        per-launch time (sizes the run)."""
+        a = self.a
+        chunk = max(1, min(64, int(20.0 / max(est_ms, 1e-3))))          # ~20 ms of GPU time per chunk
+        n_chunks = max(4, int(np.ceil(seconds * 1e3 / (chunk * est_ms) * 1.15)))  # the limiter slows the run down
+        graph = self.plan is not None and chunk > 1
+        if graph:
+            self.plan.launch_graph(chunk)  # builds the graph (untimed)
+            self.stream.sync()
+        evs = [a.Event(self.device) for _ in range(n_chunks + 1)]
+        evs[0].record(self.stream)
+        for i in range(n_chunks):
+            if graph:
+                self.plan.launch_graph(chunk)
+            else:
+                for _ in range(chunk):
+                    self.step()
+            evs[i + 1].record(self.stream)
+        self.stream.sync()
+        return [evs[i + 1].elapsed_ms_since(evs[i]) / chunk for i in range(n_chunks)], chunk
 
     def _enqueue(self):
         if self.kind == "ik":
@@ -355,6 +403,38 @@ def profiled_traffic(kernel, batch):
     return round((t["read_bytes"] + t["write_bytes"]) * batch / t["rows"], 1), src, commit
 
 
+def sustained_stats(per_launch_ms, chunk):
+    """mean per-launch time over the LAST SECOND of a back-to-back run (+ the run's course)"""
+    t = np.cumsum(np.asarray(per_launch_ms) * chunk)  # ms at the end of each chunk
+    total = float(t[-1])
+    tail = [x for x, end in zip(per_launch_ms, t) if end > total - 1000.0]
+    first = [x for x, end in zip(per_launch_ms, t) if end <= 1000.0] or per_launch_ms[:1]
+    return {"seconds": round(total / 1e3, 3), "launches": int(len(per_launch_ms) * chunk), "launches_per_event": chunk,
+            "us_per_launch_last_second": round(float(np.mean(tail)) * 1e3, 3),
+            "us_per_launch_first_second": round(float(np.mean(first)) * 1e3, 3),
+            "us_per_launch_min_chunk": round(float(np.min(per_launch_ms)) * 1e3, 3),
+            "us_per_launch_max_chunk": round(float(np.max(per_launch_ms)) * 1e3, 3)}
+
+
+def roofline_leg(runner, label, steps, sustain_s, barrier=None):
+    """one HBM-sized leg: ROOFLINE_WARMUP launches, `steps` timed launches (HIP events), then - unless sustain_s is
+    0 - the back-to-back run whose last second gives `frac`"""
+    _, ms_short = runner.timed(steps, ROOFLINE_WARMUP, barrier)
+    if sustain_s <= 0:
+        return roofline(runner, ms_short, label)
+    per, chunk = runner.sustained(sustain_s, ms_short)
+    st = sustained_stats(per, chunk)
+    out = roofline(runner, st["us_per_launch_last_second"] * 1e-3, label)
+    out["protocol"] = (f"back-to-back launches for {st['seconds']} s after {ROOFLINE_WARMUP} warm-up + {steps} short-run "
+                       f"launches; achieved / frac / us_per_launch = mean of the last second (HIP events every "
+                       f"{chunk} launches on the launch stream)")
+    out["sustained"] = st
+    short = roofline(runner, ms_short, label)
+    out["short_run"] = {"launches": steps, "us_per_launch": short["us_per_launch"], "achieved": short["achieved"],
+                        "frac": short["frac"]}
+    return out
+
+
 def roofline(runner, ms_per_launch, label):
     evals_s = runner.evals_per_launch / (ms_per_launch * 1e-3)
     gbs = runner.B / (ms_per_launch * 1e-3) * runner.bytes_per_eval / 1e9
@@ -362,7 +442,7 @@ def roofline(runner, ms_per_launch, label):
     traffic, tsrc, tcommit = profiled_traffic(kname, runner.B)
     dts = "f64" if runner.dt == np.float64 else "f32"
     out = {
-        "kernel": kname,
+        "kernel": kname, "grid_threads": runner.grid_threads(),
         "workload": label, "batch": runner.B, "bound": "hbm", "achieved": round(gbs, 3), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
         "traffic_source": None if traffic is None else f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
@@ -534,19 +614,44 @@ def cpu_baseline(workload, budget_s=12.0):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(worker, range(cores)))
     dtc = time.perf_counter() - t0
+    # THE REFERENCE'S OWN Cython path on this box's host cores (north_star: "timed on the host cores of the same box, core
+    # count stated"): the reference travels as oracle/_ref/abr_control_ref.tar.gz (oracle/stage_reference.py, packed in
+    # the build container; /root/reference does not exist here).  ~4 s on one core + ~4 s on all granted cores.  Without
+    # the archive (or sympy / Cython): the figures measured in the build container, labelled as such.
     ref = None
-    try:
-        rj = json.load(open(os.path.join(REPO, "profiles", "round2", "reference_cython_baseline.json")))
-        if workload in rj["workloads"]:
+    if workload in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
+        try:
+            from oracle import time_reference
+
+            rj = time_reference.measure_staged([workload], cores, budget=4.0)
+        except Exception as e:  # noqa: BLE001 - a reported baseline must not take the bench line down
+            rj = None
+            print(f"cpu_baseline: the staged reference did not run here: {e}", file=sys.stderr)
+        if rj is None:
+            for rnd in PROFILE_DIRS:
+                try:
+                    rj = json.load(open(os.path.join(REPO, "profiles", rnd, "reference_cython_baseline.json")))
+                    rj["measured_on"] += " [committed figures: no staged reference on this machine]"
+                    break
+                except (OSError, ValueError, KeyError):
+                    rj = None
+        if rj and workload in rj["workloads"]:
             ref = dict(rj["workloads"][workload], cores=rj["cores"], measured_on=rj["measured_on"], what=rj["what"],
                        script=rj["script"])
-    except (OSError, ValueError, KeyError):
-        pass
-    return {"value": round(total * Bs * scale / dtc, 1), "unit": "evals/s", "cores": cores, "kind": "port",
-            "value_1core": round(one, 1), "reference_cython": ref,
+    port = {"value": round(total * Bs * scale / dtc, 1), "unit": "evals/s", "cores": cores, "kind": "port",
+            "value_1core": round(one, 1),
             "sample": f"oracle/abrk_oracle.c (plain-C port of the reference path) on seeded rows of the same "
                       f"workload: {reps} x {Bs} rows{f' x {scale} steps' if scale > 1 else ''} on 1 thread in {dt1:.1f} s; "
                       f"{total} x {Bs} rows on {cores} threads in {dtc:.1f} s"}
+    if ref is not None and "committed figures" not in ref["measured_on"]:
+        # the reference itself ran here: it is the baseline; the compiled port is quoted beside it
+        return {"value": ref["evals_per_s_allcores"], "unit": "evals/s", "cores": ref["cores"], "kind": "reference",
+                "value_1core": ref["evals_per_s_1core"], "us_per_eval_1core": ref["us_per_eval_1core"],
+                "function_type": ref["function_type"], "measured_on": ref["measured_on"],
+                "sample": f"{ref['what']}: 256-row samples of the same seeded workload, ~4 s on one core, then ~4 s with "
+                          f"one reference process on each of the {ref['cores']} cores", "port": port}
+    port["reference_cython"] = ref
+    return port
 
 
 def main():
@@ -558,6 +663,11 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="rows per GPU (default: the workload's)")
     ap.add_argument("--roofline-batch", type=int, default=8 << 20, help="rows of the HBM-sized roofline leg")
     ap.add_argument("--roofline-steps", type=int, default=30)
+    ap.add_argument("--sustain-seconds", type=float, default=2.0,
+                    help="every HBM-sized leg then runs back to back for this long; `roofline.frac` = mean of the last "
+                         "second (0: quote the short run of --roofline-steps launches, as the PMC passes do)")
+    ap.add_argument("--dump-shard-u", default="", help="directory: every rank writes the sha256 of its cfg4 shard's u")
+    ap.add_argument("--no-extras", action="store_true", help="skip the osc6 and shard_sweep legs of the default line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-leg", action="store_true")
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the strong-scaling leg (cfg4, global batch 2^20)")
@@ -606,6 +716,13 @@ def main():
 
     barrier = (lambda: dist.barrier()) if dist else None
     wall, ms = run.timed(args.steps, args.warmup, barrier)
+    # the same step when the fixed cost of a (graph) launch is amortised: 2000 steps, HIP events (not `value`)
+    ms_long = None
+    if rank == 0 and args.steps < 1000 and kind not in ("rollout", "ik"):
+        gs = run.graph_steps
+        run.graph_steps = int(os.environ.get("ABRK_BENCH_GRAPH", "100"))
+        _, ms_long = run.timed(2000, 0)
+        run.graph_steps = gs
     if dist:
         tt = torch.tensor([wall], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -619,6 +736,7 @@ def main():
             else f"control steps/sec ({args.workload})",
             "value": round(value, 1), "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
+            "us_per_step_long_run": None if ms_long is None else round(ms_long * 1e3, 3),
             "vs_baseline": None, "dtype": dts, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {arm} {kind} batch={B} per GPU, inputs resident in HBM, "
                                    f"q~U(0,2pi) dq~U(0,5) target~U(-1,1) seed 1", "arm": arm, "batch_per_gpu": B,
@@ -636,13 +754,22 @@ def main():
 
         G = 1 << 20
         lo, hi = shard_range(G, rank, world)
-        r4 = Runner("cfg4", hi - lo, device, stream)
+        r4 = Runner("cfg4", hi - lo, device, stream, global_rows=(lo, G))
         k4 = max(min(args.steps, 400), 8)
         wall4, ms4 = r4.timed(k4, min(args.warmup, 50), barrier)
         if dist:
             tt = torch.tensor([wall4], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             wall4 = float(tt[0])
+        if args.dump_shard_u:  # test hook: this rank's shard of u (tests compare with the unsharded call, bit for bit)
+            import hashlib
+
+            r4.stream.sync()
+            uh = r4.u.numpy()
+            os.makedirs(args.dump_shard_u, exist_ok=True)
+            json.dump({"rank": rank, "lo": lo, "hi": hi, "sha256": hashlib.sha256(uh.tobytes()).hexdigest(),
+                       "first": uh[0].tolist(), "last": uh[-1].tolist()},
+                      open(os.path.join(args.dump_shard_u, f"shard_u_rank{rank}.json"), "w"))
         if rank == 0:
             out["strong_scaling_cfg4"] = {
                 "workload": "cfg4: ur5 OSC + g + C, global batch 2^20 sharded by contiguous rows, no collective",
@@ -654,8 +781,10 @@ def main():
     if world > 1 and not args.no_roofline_leg:
         rb = args.roofline_batch
         bigr = Runner(args.workload, rb, device, stream)
-        _, ms_r = bigr.timed(args.roofline_steps, ROOFLINE_WARMUP)
-        mine = roofline(bigr, ms_r, f"{args.workload} batch={rb} on every GPU at once")
+        # the ranks enter the timed launches together (barrier inside timed()), and each then runs for the same
+        # --sustain-seconds: the legs overlap in time, so the GPUs of the node draw power and host attention at once
+        mine = roofline_leg(bigr, f"{args.workload} batch={rb} on every GPU at once (barrier-aligned)",
+                            args.roofline_steps, args.sustain_seconds, barrier)
         del bigr
         gathered = [None] * world
         dist.all_gather_object(gathered, {"rank": rank, "device": device, "us_per_launch": mine["us_per_launch"],
@@ -671,28 +800,54 @@ def main():
         # warm-up long enough to leave the boost transient behind: after idle the first ~5 launches of this kernel run
         # at boost clocks (349 us at 8 M rows), the power limiter then overshoots (540 us) and settles (~430 us) within
         # ~12 launches (rocprofv3 kernel trace, profiles/round1); the timed launches are the sustained rate
-        _, ms_big = big.timed(args.roofline_steps, ROOFLINE_WARMUP)
-        out["roofline"] = roofline(big, ms_big, f"{args.workload} batch={rb} "
-                                                f"({rb * big.bytes_per_eval / 2**20:.0f} MiB algorithmic, "
-                                                f">> 256 MiB Infinity Cache)")
+        out["roofline"] = roofline_leg(big, f"{args.workload} batch={rb} ({rb * big.bytes_per_eval / 2**20:.0f} MiB "
+                                            f"algorithmic, >> 256 MiB Infinity Cache)", args.roofline_steps,
+                                       args.sustain_seconds)
         del big
     elif rank == 0:
         out["roofline"] = out["roofline_config"]
     if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg:
         # the HBM-bound mode of the same path: every robot_config output of a row (Tx, J, M, g) in one launch
         full = Runner("oscF", args.roofline_batch // 2, device, stream)
-        _, ms_full = full.timed(args.roofline_steps, ROOFLINE_WARMUP)
-        out["roofline_full_outputs"] = roofline(full, ms_full, f"oscF batch={full.B}: u + Tx,J,M,g per row from one "
-                                                               f"launch of the fused kernel, 840 B/row")
+        out["roofline_full_outputs"] = roofline_leg(full, f"oscF batch={full.B}: u + Tx,J,M,g per row from one launch of "
+                                                          f"the fused kernel, 840 B/row", args.roofline_steps,
+                                                    args.sustain_seconds)
         del full
+    if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg and not args.no_extras:
+        # the reference benchmark's own UR5 setting (examples/timing_plots.py:36: ctrlr_dof = [True] * 6): the six-row
+        # law, config-sized step and HBM-sized leg, on the default line
+        r6 = Runner("osc6", B, device, stream)
+        _, ms6 = r6.timed(max(min(args.steps, 400), 8), min(args.warmup, 50))
+        step6 = roofline(r6, ms6, f"osc6 batch={B} (cache-resident, launch-bound)")
+        del r6
+        b6 = Runner("osc6", args.roofline_batch, device, stream)
+        out["osc6"] = roofline_leg(b6, f"osc6 batch={b6.B}: xyz + orientation (six task rows), the reference "
+                                       f"benchmark's UR5 setting", args.roofline_steps, args.sustain_seconds)
+        out["osc6"]["config_sized_step"] = {"batch": B, "us_per_step": step6["us_per_launch"],
+                                            "evals_per_s": step6["evals_per_s"], "kernel": step6["kernel"]}
+        del b6
+        # BASELINE config 4 at the shard sizes of a 1/2/4/8-GPU node, each on THIS ONE GPU (labelled so: no scaling is
+        # extrapolated): the 8-way shard of 2^20 rows is 131 072 rows = 25 MB, a launch- and cache-bound regime the
+        # HBM-sized legs do not show
+        sweep = []
+        for parts in (1, 2, 4, 8):
+            rs = Runner("cfg4", (1 << 20) // parts, device, stream)
+            _, ms_s = rs.timed(200, 20)
+            sweep.append({"rows": rs.B, "would_be_n_gpus": parts, "us_per_step": round(ms_s * 1e3, 3),
+                          "evals_per_s": round(rs.B / (ms_s * 1e-3), 1),
+                          "frac_of_hbm_peak": round(rs.B * rs.bytes_per_eval / (ms_s * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+            del rs
+        out["shard_sweep_cfg4_single_gpu"] = {
+            "what": "cfg4 (UR5 OSC + g + C) at 2^20 / {1,2,4,8} rows on ONE GPU, hipGraph replay of 200 steps, HIP-event "
+                    "time per step: the per-GPU step a 1/2/4/8-GPU strong-scaling run would execute - measured "
+                    "single-GPU, not a scaling result", "legs": sweep}
     if rank == 0 and args.also:
         out["also"] = {}
         for w in args.also.split(","):
-            # keep each leg in the ms range, and the (kernel name, rows) pairs of one session distinct
-            per_row = {"rollout": 32, "ik": 64, "obstacles": 4, "osc_damp": 3}.get(WORKLOADS[w][3], 2)
-            extra = Runner(w, max(args.roofline_batch // per_row, 4096), device, stream)
-            _, ms_x = extra.timed(max(args.roofline_steps // 3, 3), 2)
-            out["also"][w] = roofline(extra, ms_x, f"{w} batch={extra.B}")
+            # same batch and protocol as the main leg (the iterative workloads write [B, T, n] trajectories: 256 k rows)
+            rbx = min(args.roofline_batch, 1 << 18) if WORKLOADS[w][3] in ("ik", "rollout") else args.roofline_batch
+            extra = Runner(w, rbx, device, stream)
+            out["also"][w] = roofline_leg(extra, f"{w} batch={extra.B}", args.roofline_steps, args.sustain_seconds)
             del extra
     if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg and not args.no_streams_leg:
         out["concurrent_streams"] = [concurrent_streams_rate("cfg2", B, device, s, args.steps) for s in (2, 4, 8, 16)]

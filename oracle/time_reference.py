@@ -2,24 +2,28 @@
 """Times the REFERENCE's own path (abr_control's Cython-loaded generated functions + its NumPy control law, exactly
 what its users run) on the host cores of the machine this script is run on, for the BASELINE workloads.
 
-TEST / MEASUREMENT INFRASTRUCTURE - build container only (needs /root/reference; the GPU box has no reference
-checkout, so bench.py quotes the committed result of this script, labelled with where it was measured).
+TEST / MEASUREMENT INFRASTRUCTURE.  Two ways to find the reference:
+  * build container: /root/reference (scratch copy) + its function cache in ~/.cache/abr_control;
+  * anywhere else (the GPU box has no reference checkout): the archive oracle/_ref/abr_control_ref.tar.gz that
+    oracle/stage_reference.py packed in the build container - the reference's package and the shared objects its own
+    code generator produced.  bench.py's `cpu_baseline` leg calls measure_staged() for that.
 
 The reference has no batch API and no multi-core path: "1 core" is its loop over the batch,
-`ctrlr.generate(q[b], dq[b], target[b])` per row; "all cores" is a multiprocessing pool, one reference instance per
-process (one arm per process - its function cache collides across arms, base_config.py:178-191), the sample split
-evenly.  Inputs: the reference benchmark's distribution (examples/timing_plots.py:18-20), seed 1 - the same rows
-bench.py's synthetic inputs start with.
+`ctrlr.generate(q[b], dq[b], target[b])` per row; "all cores" is one reference process per core (one arm per
+process - its function cache collides across arms, base_config.py:178-191), the sample split evenly.  Inputs: the
+reference benchmark's distribution (examples/timing_plots.py:18-20), seed 1 - the same rows bench.py's synthetic
+inputs start with.
 
-Usage: python oracle/time_reference.py [out.json]     (default profiles/round2/reference_cython_baseline.json)
+Usage: python oracle/time_reference.py [out.json] [--staged]    (default out: profiles/round3/reference_cython_baseline.json)
 """
 import json
-import multiprocessing as mp
 import os
 import platform
 import shutil
 import subprocess
 import sys
+import tarfile
+import tempfile
 import time
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -57,6 +61,16 @@ print(done, time.perf_counter() - t0, kind)
 '''
 
 
+def ref_env(pkg_root, home=None):
+    """environment of a reference process: its package on the path, one BLAS thread, HOME = where its function cache
+    lives (utils/paths.py:9 expands ~/.cache/abr_control)"""
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=pkg_root, OMP_NUM_THREADS="1",
+               OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    if home:
+        env["HOME"] = home
+    return env
+
+
 def run_workers(name, procs, budget, env):
     arm, factory, nt = WORKLOADS[name]
     cmd = [sys.executable, "-c", WORKER, arm, factory, str(nt), "256", str(budget)]
@@ -72,31 +86,73 @@ def run_workers(name, procs, budget, env):
     return rate, rows[0][2], wall
 
 
-def main():
-    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "profiles", "round2", "reference_cython_baseline.json")
-    if not os.path.isdir(REF):
-        sys.exit("time_reference.py needs /root/reference (build container only)")
-    if os.path.isdir(SCRATCH):
-        shutil.rmtree(SCRATCH)
-    shutil.copytree(REF, SCRATCH)
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", PYTHONPATH=SCRATCH, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1",
-               MKL_NUM_THREADS="1")
-    cores = len(os.sched_getaffinity(0))
+def host_description():
     cpu = next((l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")), platform.processor())
-    res = {"measured_on": f"build container ({cpu}, {cores} cores) - NOT the GPU box's host",
-           "what": "abr_control's own Cython path: ctrlr.generate(q[b], dq[b], target[b]) per row (no batch API), "
-                   "generated functions loaded from its cache (base_config.py:173-191)",
-           "script": "oracle/time_reference.py", "cores": cores, "workloads": {}}
-    for name in WORKLOADS:
-        r1, kind, _ = run_workers(name, 1, 4.0, env)
-        rall, _, _ = run_workers(name, cores, 4.0, env)
-        res["workloads"][name] = {"evals_per_s_1core": round(r1, 1), "us_per_eval_1core": round(1e6 / r1, 2),
-                                  "evals_per_s_allcores": round(rall, 1), "function_type": kind}
-        print(name, res["workloads"][name], flush=True)
+    return cpu, len(os.sched_getaffinity(0))
+
+
+def measure(names, env, cores, budget=4.0):
+    res = {}
+    for name in names:
+        r1, kind, _ = run_workers(name, 1, budget, env)
+        rall, _, _ = run_workers(name, cores, budget, env)
+        res[name] = {"evals_per_s_1core": round(r1, 1), "us_per_eval_1core": round(1e6 / r1, 2),
+                     "evals_per_s_allcores": round(rall, 1), "function_type": kind}
+    return res
+
+
+def measure_staged(names, cores, budget=4.0, archive=None):
+    """the staged reference (oracle/_ref/abr_control_ref.tar.gz) timed HERE.  -> dict like the committed JSON, or None
+    when there is no archive / the reference's dependencies do not import on this machine"""
+    archive = archive or os.path.join(REPO, "oracle", "_ref", "abr_control_ref.tar.gz")
+    if not os.path.exists(archive):
+        return None
+    try:
+        import cloudpickle  # noqa: F401 - what abr_control.arms.base_config imports
+        import Cython  # noqa: F401
+        import sympy  # noqa: F401
+    except ImportError:
+        return None
+    root = tempfile.mkdtemp(prefix="abrk_ref_run_")
+    try:
+        with tarfile.open(archive) as tf:
+            tf.extractall(root)
+        env = ref_env(os.path.join(root, "pkg"), os.path.join(root, "home"))
+        cpu, affinity = host_description()
+        res = {"measured_on": f"this machine's host ({cpu}; {cores} cores granted to the process, affinity {affinity})",
+               "what": "abr_control's own Cython path: ctrlr.generate(q[b], dq[b], target[b]) per row (no batch API), "
+                       "generated functions loaded from its cache (base_config.py:173-191); the reference travelled as "
+                       "oracle/_ref/abr_control_ref.tar.gz (oracle/stage_reference.py)",
+               "script": "oracle/time_reference.py", "cores": cores, "workloads": measure(names, env, cores, budget)}
+        return res
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    out = args[0] if args else os.path.join(REPO, "profiles", "round3", "reference_cython_baseline.json")
+    cores = len(os.sched_getaffinity(0))
+    if "--staged" in sys.argv or not os.path.isdir(REF):
+        res = measure_staged(list(WORKLOADS), cores)
+        if res is None:
+            sys.exit("time_reference.py: neither /root/reference nor a staged oracle/_ref archive (or sympy/Cython missing)")
+    else:
+        if os.path.isdir(SCRATCH):
+            shutil.rmtree(SCRATCH)
+        shutil.copytree(REF, SCRATCH)
+        cpu, _ = host_description()
+        res = {"measured_on": f"build container ({cpu}, {cores} cores) - NOT the GPU box's host",
+               "what": "abr_control's own Cython path: ctrlr.generate(q[b], dq[b], target[b]) per row (no batch API), "
+                       "generated functions loaded from its cache (base_config.py:173-191)",
+               "script": "oracle/time_reference.py", "cores": cores,
+               "workloads": measure(list(WORKLOADS), ref_env(SCRATCH), cores)}
+        shutil.rmtree(SCRATCH, ignore_errors=True)
+    for name, v in res["workloads"].items():
+        print(name, v, flush=True)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(res, open(out, "w"), indent=1)
     print("wrote", out)
-    shutil.rmtree(SCRATCH, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -90,13 +90,20 @@ def test_user_arm_slots_are_reused(L):
     """a long-running process may register and drop any number of arms: destroyed slots are handed out again;
     only the number of arms alive at once is bounded"""
     d = _abi.desc_from_table(_abi.load_table("twojoint"))
-    seen = set()
+    seen, ids = set(), set()
     for _ in range(6000):
         aid = L.abrk_arm_create(C.byref(d))
         assert aid >= 5
-        seen.add(aid)
+        seen.add(aid & 4095)  # an id is slot | generation << 12
+        ids.add(aid)
         assert L.abrk_arm_destroy(aid) == 0
     assert len(seen) <= 4  # the same slot(s) over and over (other tests may hold a few)
+    assert len(ids) == 6000  # ... but never the same id twice: a stale handle cannot reach the slot's next tenant
+    back = _abi.ArmDesc()
+    assert L.abrk_arm_get_desc(aid, C.byref(back)) == -4 and L.abrk_arm_destroy(aid) == -4
+    live = L.abrk_arm_create(C.byref(d))
+    assert live != aid and L.abrk_arm_get_desc(aid, C.byref(back)) == -4  # same slot, other generation
+    assert L.abrk_arm_get_desc(live, C.byref(back)) == 0 and L.abrk_arm_destroy(live) == 0
     held = [L.abrk_arm_create(C.byref(d)) for _ in range(50)]
     assert len(set(held)) == 50 and min(held) >= 5
     for aid in held:
@@ -207,3 +214,26 @@ def test_argument_validation_before_device(L):
     # empty batch is a no-op even without a device
     u = engine.osc_generate(0, 6, _abi.make_osc_params(6), np.zeros((0, 6)), np.zeros((0, 6)), np.zeros((0, 6)))
     assert u.shape == (0, 6)
+
+
+def test_config_copies_take_their_own_registry_handle(L):
+    """copy / deepcopy / pickle of a user-arm config must not share its arm id: the first copy collected would hand
+    the slot back under the survivor"""
+    import copy
+    import pickle
+
+    from abr_control_amd.arms.base_config import BatchedConfig
+
+    rc = BatchedConfig(_abi.load_table("threejoint"), compiled=False)
+    first = rc.arm_id
+    assert first >= 5
+    back = _abi.ArmDesc()
+    for dup in (copy.copy(rc), copy.deepcopy(rc), pickle.loads(pickle.dumps(rc))):
+        assert dup._arm_id is None and dup.N_JOINTS == 3 and np.array_equal(dup.L, rc.L)
+        other = dup.arm_id
+        assert other != first and L.abrk_arm_get_desc(other, C.byref(back)) == 0
+        dup.close()
+        assert L.abrk_arm_get_desc(other, C.byref(back)) == -4  # the copy's handle is gone ...
+        assert L.abrk_arm_get_desc(first, C.byref(back)) == 0 and back.n_joints == 3  # ... the original's is not
+    rc.close()
+    assert L.abrk_arm_get_desc(first, C.byref(back)) == -4

@@ -634,6 +634,89 @@ def test_gpu_concurrent_host_calls_from_threads():
     assert np.median(cases.rel_err(u, uo)) < 1e-9
 
 
+def test_gpu_six_row_from_threads_on_default_stream():
+    """VERDICT r2 / ADVICE: the six-row law's deferred pass (>= 16 384 rows) keeps a worklist per (device, stream); every
+    Python call without an explicit stream is on the NULL stream and ctypes releases the GIL, so host threads share that
+    worklist.  Memset, first pass and second pass of a call must enter the stream as a unit (abrk_host.cpp
+    worklist_for): 8 threads, different batch sizes (so the buffer also grows under contention), orientation control,
+    an integral state that only a completed row may update - bit-equal to the same calls made one after the other."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    be = cases.GpuBackend("ur5")
+    params = cases.P(6, kp=100, ko=80, kv=15, ki=0.2, ctrlr_dof=[1] * 6)
+    sizes = (16384, 50000, 20001, 131072, 16385, 70000, 33333, 262144)
+
+    def work(i):
+        B = sizes[i]
+        q, dq, t = draw(900 + i, B, 6)
+        out = []
+        for rep in range(3):
+            ie = np.full((B, 6), 0.01 * rep)
+            u, ts = be.osc(params, q, dq, t, ie=ie)
+            out.append((u, ts, ie))
+        return q, dq, t, out
+
+    with ThreadPoolExecutor(8) as ex:
+        results = list(ex.map(work, range(8)))
+    for q, dq, t, out in results:
+        for rep, (u, ts, ie) in enumerate(out):
+            ie1 = np.full((len(q), 6), 0.01 * rep)
+            u1, ts1 = be.osc(params, q, dq, t, ie=ie1)  # the same call, nobody else on the stream
+            assert np.array_equal(u, u1) and np.array_equal(ts, ts1) and np.array_equal(ie, ie1)
+            assert np.isfinite(u).all()
+    # ... and right (4-5 % of random UR5 states take the truncating pinv with six task rows, i.e. the deferred pass)
+    from oracle.oracle import Oracle
+
+    q, dq, t, out = results[0]
+    ie0 = np.zeros((2048, 6))
+    uo, _ = Oracle(_abi.load_table("ur5")).osc_batch(params, q[:2048], dq[:2048], t[:2048], integrated_error=ie0,
+                                                      want_training=True)
+    err = cases.rel_err(out[0][0][:2048], uo)
+    assert np.median(err) < 1e-9 and np.max(err) < 1e-6
+    assert np.allclose(out[0][2][:2048], ie0, rtol=1e-12, atol=1e-12)
+
+
+def test_gpu_bench_two_ranks_share_one_device(tmp_path):
+    """the N > 1 launch contract on a one-GPU box (VERDICT r2 #5a): `torch.distributed.run --nproc-per-node 2 bench.py
+    --gpus 2` with both ranks on device 0 prints ONE contract line with n_gpus = 2, the strong-scaling leg cuts BASELINE
+    config 4's 2^20 rows into two contiguous shards, and each rank's shard of u is bit-equal to the same rows of the
+    unsharded call"""
+    import hashlib
+    import json
+    import subprocess
+    import sys
+
+    from tests.conftest import REPO
+
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "100",
+           "--warmup", "10", "--roofline-batch", "262144", "--roofline-steps", "5", "--sustain-seconds", "0.2",
+           "--dump-shard-u", str(tmp_path)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 100 and d["value"] > 1e6
+    assert d["config"]["global_batch"] == 2 * 4096 and "cpu_baseline" not in d
+    s4 = d["strong_scaling_cfg4"]
+    assert s4["n_gpus"] == 2 and s4["rows_per_gpu"] == 1 << 19 and s4["global_batch"] == 1 << 20 and s4["scaling"] == "strong"
+    per = d["roofline_per_gpu"]
+    assert [g["rank"] for g in per] == [0, 1] and all(0 < g["frac"] < 1 for g in per)
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["sustained"]["seconds"] >= 0.2
+    # the shards: rows [0, 2^19) and [2^19, 2^20) of the one seeded global batch, against the unsharded call
+    import bench
+
+    be = cases.GpuBackend("ur5")
+    q, dq, t = bench.make_inputs(1, 1 << 20, 6, 6, np.float64)
+    u, _ = be.osc(cases.P(6, kp=200, use_g=True, use_C=True), q, dq, t)
+    for r in (0, 1):
+        sh = json.load(open(tmp_path / f"shard_u_rank{r}.json"))
+        assert (sh["lo"], sh["hi"]) == (r << 19, (r + 1) << 19)
+        assert sh["sha256"] == hashlib.sha256(np.ascontiguousarray(u[sh["lo"]:sh["hi"]]).tobytes()).hexdigest()
+
+
 def test_gpu_secondary_controllers_properties_full_size():
     """size-independent properties at 2^20 rows (BASELINE config-4 size)"""
     be = cases.GpuBackend("ur5")

@@ -10,6 +10,59 @@ import pandas as pd
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
+
+
+def norm(k):
+    return k.split("(")[0].replace("void abrk::", "").replace(" ", "")
+
+
+def legs_of(path):
+    """every roofline-like block ({kernel, grid_threads, batch, ...}) of the bench JSON line(s) in a log file"""
+    out = []
+    try:
+        lines = [l for l in open(path) if l.startswith("{")]
+    except OSError:
+        return out
+
+    def walk(o):
+        if isinstance(o, dict):
+            if "kernel" in o and "batch" in o and "grid_threads" in o:
+                out.append(o)
+            for v in o.values():
+                walk(v)
+        elif isinstance(o, list):
+            for v in o:
+                walk(v)
+
+    for l in lines:
+        try:
+            walk(json.loads(l))
+        except ValueError:
+            pass
+    return out
+
+
+# (kernel, Grid_Size as rocprofv3 prints it) -> rows of the launch.  The grid-stride kernels (Sliding, AvoidObstacles,
+# the six-row OSC law's first pass) cap their grid, so rows != grid for them: bench.py states both for every leg.
+ROWS = {}
+for f in sorted(os.listdir(src)):
+    if f.endswith((".log", ".json")):
+        for leg in legs_of(os.path.join(src, f)):
+            ROWS[(norm(leg["kernel"]), int(leg["grid_threads"]))] = int(leg["batch"])
+
+
+def rows_for(kernel, grid):
+    """rows a launch of `kernel` with `grid` threads processed (the grid itself for one-lane-per-row kernels)"""
+    kn = norm(kernel)
+    if (kn, int(grid)) in ROWS:
+        return ROWS[(kn, int(grid))]
+    # the six-row law's second pass (PASS = 0 at a fixed 2048-block grid) belongs to the leg of its first pass
+    if kn.startswith("osc_kernel<") and kn.endswith(",0>") and int(grid) == 8 * 256 * 64:
+        first = kn[:-3] + ",1>"
+        big = [b for (k, g), b in ROWS.items() if k == first]
+        if big:
+            return max(big)
+    return int(grid)
 lines = ["# rocprofv3 evidence (MI355X, ROCm 7.2)", "",
          "Commands: `tools/gpu_profiles.sh` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
          "`--pmc` passes as MI355X_MICROARCH.md prescribes).  `FETCH_SIZE`/`WRITE_SIZE` are in KiB; on gfx950 "
@@ -33,11 +86,39 @@ if os.path.exists(ks):
     kt["dur"] = kt["End_Timestamp"] - kt["Start_Timestamp"]
     kt["kernel"] = kt["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:90]
     g = kt.groupby(["kernel", "Grid_Size_X"])["dur"].agg(["count", "mean", "min", "max"]).reset_index()
-    lines += ["", "per (kernel, grid) from the kernel trace of the same run:", "",
-              "| kernel | rows (grid) | launches | mean us | min us | max us |", "|---|---|---|---|---|---|"]
+    lines += ["", "per (kernel, grid) from the kernel trace of the same run (rows: what the launch processed - the "
+              "grid-stride kernels launch fewer threads than rows; the bench line of the run states both):", "",
+              "| kernel | grid threads | rows | launches | mean us | min us | max us |", "|---|---|---|---|---|---|---|"]
     for _, r in g.iterrows():
-        lines.append(f"| `{r['kernel']}` | {r['Grid_Size_X']} | {r['count']} | {r['mean']/1e3:.2f} | {r['min']/1e3:.2f} | "
-                     f"{r['max']/1e3:.2f} |")
+        lines.append(f"| `{r['kernel']}` | {r['Grid_Size_X']} | {rows_for(r['kernel'], r['Grid_Size_X'])} | {r['count']} | "
+                     f"{r['mean']/1e3:.2f} | {r['min']/1e3:.2f} | {r['max']/1e3:.2f} |")
+    # the figure every bench JSON's `roofline.frac` must reproduce: algorithmic bytes x rows / trace mean / 8 TB/s
+    legs = {}
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".log", ".json")):
+            for leg in legs_of(os.path.join(src, f)):
+                if leg["batch"] >= (1 << 20) and "bytes_per_eval" in leg:
+                    legs.setdefault((norm(leg["kernel"]), int(leg["grid_threads"])), []).append((f, leg))
+    if legs:
+        lines += ["", "HBM-sized legs: the kernel-trace mean of ALL launches of the leg's (kernel, grid) in the profiled run "
+                  "against the `roofline` blocks of the bench JSONs (frac = algorithmic bytes / time / 8 TB/s):", "",
+                  "| kernel | rows | B/row | launches in trace | trace mean us | frac from trace | bench JSONs: us (frac) |",
+                  "|---|---|---|---|---|---|---|"]
+        for (kn, grid), ll in sorted(legs.items()):
+            sel = kt[(kt["kernel"].str.replace(" ", "") == kn[:90]) & (kt["Grid_Size_X"] == grid)]
+            if sel.empty:
+                continue
+            leg = ll[0][1]
+            mean_us = sel["dur"].mean() / 1e3
+            extra = 0.0
+            if kn.startswith("osc_kernel<") and kn.endswith(",1>"):  # + the dense second pass of the same calls
+                s2 = kt[(kt["kernel"].str.replace(" ", "") == (kn[:-3] + ",0>")[:90]) & (kt["Grid_Size_X"] == 8 * 256 * 64)]
+                if not s2.empty:
+                    extra = s2["dur"].mean() / 1e3
+            frac = leg["batch"] * leg["bytes_per_eval"] / ((mean_us + extra) * 1e-6) / 8e12
+            js = "; ".join(f"{f}: {l['us_per_launch']:.1f} ({l['frac']:.3f})" for f, l in ll)
+            lines.append(f"| `{kn[:100]}` | {leg['batch']} | {leg['bytes_per_eval']} | {len(sel)} | {mean_us:.1f}"
+                         f"{f' + {extra:.1f} (second pass)' if extra else ''} | {frac:.3f} | {js} |")
     # the HBM-sized legs: launches in time order, and the mean of the last 30 = the launches bench.py's HIP events
     # bracket (the ones before are construction, warm-up and the untimed first replay of the timed graph)
     big = kt[kt["Grid_Size_X"] >= (1 << 22)].sort_values("Start_Timestamp")
@@ -46,8 +127,11 @@ if os.path.exists(ks):
               "`--roofline-steps` launches:", ""]
     for (kname, grid), grp in big.groupby(["kernel", "Grid_Size_X"], sort=False):
         d = (grp["dur"] / 1e3).round().astype(int).tolist()
-        tail = d[-30:] if len(d) >= 43 else d[-10:]
-        lines.append(f"* `{kname}`, {grid} rows: {d} -> mean of the timed launches {sum(tail) / len(tail):.1f} us")
+        t_end = ((grp["End_Timestamp"] - grp["Start_Timestamp"].iloc[0]) / 1e9).tolist()
+        last = [x for x, te in zip(d, t_end) if te > t_end[-1] - 1.0]
+        shown = d if len(d) <= 60 else d[:40] + ["..."] + d[-10:]
+        lines.append(f"* `{kname}`, {rows_for(kname, grid)} rows, {len(d)} launches over {t_end[-1]:.2f} s: {shown} -> mean of "
+                     f"all {sum(d) / len(d):.1f} us, of the last second {sum(last) / len(last):.1f} us")
 rows = []
 for d in sorted(os.listdir(src)):
     cc = os.path.join(src, d, "bench_counter_collection.csv")
@@ -68,7 +152,8 @@ if rows:
     traffic = {}
     for (k, gsz), r in piv.iterrows():
         if "FETCH_SIZE" in r and "WRITE_SIZE" in r and r["FETCH_SIZE"] == r["FETCH_SIZE"]:
-            traffic[f"{k.replace(' ', '')}:{int(gsz)}"] = {
+            traffic[f"{k.replace(' ', '')}:{rows_for(k, gsz)}"] = {
+                "grid_threads": int(gsz),
                 "read_bytes": float(r["FETCH_SIZE"] * 1024 * 2), "write_bytes": float(r["WRITE_SIZE"] * 1024),
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
     commit = os.environ.get("ABRK_PROFILE_COMMIT", "unknown")
@@ -89,33 +174,23 @@ if rows:
         for (k, gsz), grp in kt2.groupby(["kernel", "Grid_Size_X"]):
             durs[(k, int(gsz))] = float(grp["dur"].mean())
     counters = {"_commit": commit}
-    # grid-stride kernels (Sliding) launch fewer lanes than rows: the rows of each leg are in the bench line of the pass
-    rows_of = {}
-    try:
-        line = [l for l in open(os.path.join(src, "pmc_sq.log")) if l.startswith("{")][-1]
-        bj = json.loads(line)
-        legs = [bj.get("roofline"), bj.get("roofline_full_outputs")] + list((bj.get("also") or {}).values())
-        for leg in legs:
-            if leg:
-                rows_of[leg["kernel"].replace(" ", "")] = int(leg["batch"])
-    except (OSError, IndexError, ValueError, KeyError):
-        pass
     for (k, gsz), r in piv.iterrows():
         if "SQ_WAVES" not in r or r["SQ_WAVES"] != r["SQ_WAVES"] or gsz < 4096:
             continue
         w = r["SQ_WAVES"]
-        rows = rows_of.get(k.replace(" ", ""), 0)
-        if rows > gsz >= (1 << 20):  # more rows than lanes: per-row figures, keyed by the rows
+        rows = rows_for(k, gsz)
+        grid0 = int(gsz)
+        if rows != gsz:  # grid-stride kernel: per-row figures, keyed by the rows
             w = rows / 64.0
             gsz = rows
         e = {"valu_per_row": float(r["SQ_INSTS_VALU"] / w), "salu_per_row": float(r["SQ_INSTS_SALU"] / w),
              "wave_cycles_per_wave": float(4 * r["SQ_WAVE_CYCLES"] / w),
              "busy_cycles": float(r["SQ_BUSY_CYCLES"]) if "SQ_BUSY_CYCLES" in r else None}
-        if "GRBM_GUI_ACTIVE" in r and r["GRBM_GUI_ACTIVE"] == r["GRBM_GUI_ACTIVE"] and (k, int(gsz)) in durs:
+        if "GRBM_GUI_ACTIVE" in r and r["GRBM_GUI_ACTIVE"] == r["GRBM_GUI_ACTIVE"] and (k, grid0) in durs:
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs: shader clock = counter / 8 / kernel duration (of these short
             # PMC passes - the first launches after idle run above the sustained clock)
             gui = float(r["GRBM_GUI_ACTIVE"]) / 8.0
-            e["clock_ghz"] = round(gui / durs[(k, int(gsz))], 3)
+            e["clock_ghz"] = round(gui / durs[(k, grid0)], 3)
             # issue utilisation: executed VALU issue cycles (4 per fp64 wave-instruction, 2 per fp32) of all waves over
             # the SIMD-cycles the kernel was resident (1024 SIMDs x active cycles)
             cyc = 4 if "double" in k else 2
@@ -129,7 +204,7 @@ if rows:
         if "FETCH_SIZE" in r and "WRITE_SIZE" in r and r["FETCH_SIZE"] == r["FETCH_SIZE"]:
             rd, wr = r["FETCH_SIZE"] * 1024 * 2, r["WRITE_SIZE"] * 1024
             bits.append(f"HBM traffic = {rd/1e6:.1f} MB read (FETCH_SIZE x2) + {wr/1e6:.1f} MB written = "
-                        f"{(rd+wr)/gsz:.1f} B/row")
+                        f"{(rd+wr)/rows_for(k, gsz):.1f} B/row ({rows_for(k, gsz)} rows)")
         if "SQ_WAVES" in r and r["SQ_WAVES"] == r["SQ_WAVES"]:
             w = r["SQ_WAVES"]
             bits.append(f"{r['SQ_INSTS_VALU']/w:.0f} VALU + {r['SQ_INSTS_SALU']/w:.0f} SALU instr/wave; "
