@@ -54,6 +54,15 @@ def lib():
         L.abrk_osc_generate_sharded.argtypes = [
             C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
             C.POINTER(C.c_int)]
+        L.abrk_sliding_generate_sharded.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.SlidingParams), _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int,
+            C.POINTER(C.c_int)]
+        L.abrk_joint_generate_sharded.argtypes = [
+            C.c_int, C.c_int, C.POINTER(_abi.NullCtrl), C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, C.c_int,
+            C.POINTER(C.c_int)]
+        L.abrk_dynamics_sharded.argtypes = [
+            C.c_int, C.c_int, _i64, _vp, _vp, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.POINTER(_abi.DynOut),
+            C.c_int, C.POINTER(C.c_int)]
         L.abrk_osc_law_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64] + [_vp] * 14 + [C.c_int, _vp]
         L.abrk_osc_mx_batch.argtypes = [C.c_int, C.c_int, C.c_int, _i64, _vp, _vp, C.c_double, _vp, _vp, C.c_int, _vp]
         L.abrk_osc_velocity_limiting_batch.argtypes = [C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, C.c_int, _vp]

@@ -4,6 +4,9 @@ import numpy as np
 class Controller:
     """Base of all controllers (abr_control/controllers/controller.py:4-32)."""
 
+    # set by sharding.MultiDevice for the duration of one generate(): the devices a host batch is cut over
+    _shard_devices = None
+
     def __init__(self, robot_config):
         self.robot_config = robot_config
         self.offset_zeros = np.zeros(3)
@@ -32,6 +35,17 @@ class Controller:
                 a = np.broadcast_to(a, (B, a.shape[1]))
             out.append(np.ascontiguousarray(a))
         return out, single
+
+    def _joint_generate(self, ctrl, account_for_gravity, q2, dq2, t2=None, tv2=None):
+        """the Joint / Damping / RestingConfig kernel on one device, or - under MultiDevice - over several"""
+        from .. import engine
+
+        rc = self.robot_config
+        if self._shard_devices:
+            return engine.joint_generate_sharded(rc.arm_id, rc.N_JOINTS, ctrl, account_for_gravity, q2, dq2,
+                                                 self._shard_devices, t2, tv2, dtype=rc.dtype)
+        return engine.joint_generate(rc.arm_id, rc.N_JOINTS, ctrl, account_for_gravity, q2, dq2, t2, tv2, dtype=rc.dtype,
+                                     device=rc.device)
 
     def _require_batched_config(self):
         from ..arms.base_config import BatchedConfig

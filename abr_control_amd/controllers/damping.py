@@ -14,8 +14,7 @@ class Damping(Controller):
     def generate(self, q, dq):
         rc = self.robot_config
         (q2, dq2), single = self._rows(q, dq)
-        u = engine.joint_generate(rc.arm_id, rc.N_JOINTS, _abi.make_damping(self.kv), False, q2, dq2,
-                                  dtype=rc.dtype, device=rc.device)
+        u = self._joint_generate(_abi.make_damping(self.kv), False, q2, dq2)
         if isinstance(u, np.ndarray) and rc.reference_dtypes:
             u = u.astype(np.float64)
         return u[0] if single else u

@@ -28,8 +28,7 @@ class Joint(Controller):
     def generate(self, q, dq, target, target_velocity=None):
         rc = self.robot_config
         (q2, dq2, t2, tv2), single = self._rows(q, dq, target, target_velocity)
-        u = engine.joint_generate(rc.arm_id, rc.N_JOINTS, self._ctrl(), self.account_for_gravity, q2, dq2, t2, tv2,
-                                  dtype=rc.dtype, device=rc.device)
+        u = self._joint_generate(self._ctrl(), self.account_for_gravity, q2, dq2, t2, tv2)
         if isinstance(u, np.ndarray) and rc.reference_dtypes:
             u = u.astype(np.float64)
         return u[0] if single else u

@@ -29,8 +29,12 @@ class Sliding(Controller):
             return v
 
         (q2, dq2, t2, tv2, ta2), single = self._rows(q, dq, target, bc(target_velocity), bc(target_acc))
-        u, s = engine.sliding_generate(rc.arm_id, n, params, q2, dq2, t2, tv2, ta2, want_s=True, dtype=rc.dtype,
-                                       device=rc.device)
+        if self._shard_devices:  # under sharding.MultiDevice: contiguous row shards over several devices
+            u, s = engine.sliding_generate_sharded(rc.arm_id, n, params, q2, dq2, t2, self._shard_devices, tv2, ta2,
+                                                   want_s=True, dtype=rc.dtype)
+        else:
+            u, s = engine.sliding_generate(rc.arm_id, n, params, q2, dq2, t2, tv2, ta2, want_s=True, dtype=rc.dtype,
+                                           device=rc.device)
         if isinstance(u, DeviceArray):
             self.s = s
             return u

@@ -136,6 +136,22 @@ ABRK_INL void symv(const T (&S)[K * (K + 1) / 2], const T (&v)[K], T (&o)[K]) {
     o[i()] = acc;
   });
 }
+// L^-1 (lower, packed) of a Cholesky factor
+template <int K, class T>
+ABRK_INL void chol_factor_inverse(const T (&L)[K * (K + 1) / 2], const T (&il)[K], T (&Li)[K * (K + 1) / 2]) {
+  sfor<K>([&](auto j) ABRK_LAMBDA {
+    Li[tri(j(), j())] = il[j()];
+    sfor<K - 1 - j()>([&](auto ii) ABRK_LAMBDA {
+      constexpr int i = j() + 1 + ii();
+      T acc = T(-0.0);
+      sfor<i - j()>([&](auto kk) ABRK_LAMBDA {
+        constexpr int k = j() + kk();
+        acc -= L[tri(i, k)] * Li[tri(k, j())];
+      });
+      Li[tri(i, j())] = acc * il[i];
+    });
+  });
+}
 // inverse of an SPD matrix from its Cholesky factor: Sinv = L^-T L^-1 (packed)
 template <int K, class T>
 ABRK_INL void chol_inverse(const T (&L)[K * (K + 1) / 2], const T (&il)[K], T (&Sinv)[K * (K + 1) / 2]) {
@@ -820,6 +836,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   bool sel[KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA { sel[r()] = P.dof[r()] != 0; });
 
+  ABRK_MARK("law6:task_forces");
   // desired task-space forces (osc.py:250-259)
   T ut[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   if (P.pos_on) sfor<3>([&](auto r) ABRK_LAMBDA { ut[r()] = p[r()] - tgt[r()]; });
@@ -853,6 +870,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       ut[3 + r()] *= P.ko;
     });
   }
+  ABRK_MARK("law6:vel_comp");
   // velocity compensation (osc.py:274-282)
   bool tv_zero = true;
   if (FEAT >= 2 && tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
@@ -891,6 +909,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     }
   }
 
+  ABRK_MARK("law6:chol_M");
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T = Y Y^T, Y = J L^-T (rows y_r = L^-1 j_r)
   T L[N * (N + 1) / 2], il[N];
   chol<N>(Ms, L, il);
@@ -905,6 +924,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       });
     }
   }
+  ABRK_MARK("law6:Y_Am");
   T Am[KM * (KM + 1) / 2];
   auto yrow = [&](auto r, T(&y)[N]) ABRK_LAMBDA {
     T b[N];
@@ -929,6 +949,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       sfor<r() + 1>([&](auto c) ABRK_LAMBDA { Am[tri(3 + r(), 3 + c())] = ydot(Yb[r()], Yb[c()]); });
     });
   }
+  ABRK_MARK("law6:chol_A");
   T trace = T(0);
   sfor<KM>([&](auto r) ABRK_LAMBDA {
     trace += sel[r()] ? Am[tri(r(), r())] : T(0);
@@ -947,12 +968,23 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     sfor<KM>([&](auto r) ABRK_LAMBDA { bound *= sel[r()] ? trace : T(1); });
     bool truncates = !(okA && det > bound);
     if (truncates && okA) {
-      if constexpr (FEAT == 0) chol_inverse<KM>(LA, ila, Mx);
+      // second certificate: trace(A) trace(A^-1) < 1 / rcond.  Without secondary controllers the inverse itself is
+      // not needed (f comes from the factor): trace(A^-1) = |L^-1|_F^2 over the selected columns, half the work
       T tinv = T(0);
-      sfor<KM>([&](auto r) ABRK_LAMBDA { tinv += sel[r()] ? Mx[tri(r(), r())] : T(0); });
+      if constexpr (FEAT == 0) {
+        T Li[KM * (KM + 1) / 2];
+        chol_factor_inverse<KM>(LA, ila, Li);
+        sfor<KM>([&](auto r) ABRK_LAMBDA {
+          T cs = T(-0.0);
+          sfor<KM - r()>([&](auto kk) ABRK_LAMBDA { cs = Rm<T>::fma(Li[tri(r() + kk(), r())], Li[tri(r() + kk(), r())], cs); });
+          tinv += sel[r()] ? cs : T(0);
+        });
+      } else {
+        sfor<KM>([&](auto r) ABRK_LAMBDA { tinv += sel[r()] ? Mx[tri(r(), r())] : T(0); });
+      }
       if (trace * tinv * rcond < T(1)) {
         truncates = false;
-        mx_explicit = true;
+        if constexpr (FEAT != 0) mx_explicit = true;
       }
     }
     if (truncates && (Rows::kDeferOnly || defer)) {
@@ -983,6 +1015,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     }
   }
 
+  ABRK_MARK("law6:f");
   // f = Mx u_task[ctrlr_dof] (osc.py:285-288); f2 = Mx (J v) for the null-space filter
   T f[KM], f2[FEAT >= 1 ? KM : 1];
   if (mx_explicit) {
@@ -1005,6 +1038,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       symv<KM>(Mx, jv, f2);
     }
   }
+  ABRK_MARK("law6:JTf");
   // u = u0 - J^T f [- C dq]; training signal; + g; + (I - J^T Jbar^T) u_null = M v - J^T Mx (J v)
   T a1[N], a2[FEAT >= 1 ? N : 1];
   sfor<N>([&](auto i) ABRK_LAMBDA { a1[i()] = T(-0.0); });
@@ -1079,6 +1113,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
       kin_dyn_hook(arm, q, dq, jt, d, XR, xo, cap_, [](auto, const T(&)[3]) ABRK_LAMBDA {}, sincos_policy());
     }
   };
+  ABRK_MARK("row:dynamics");
   if constexpr (FAST) {
     NoCap nc;
     dynamics_pass(nc);
@@ -1103,6 +1138,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     });
     m = P.m_joints;
   }
+  ABRK_MARK("row:jacobian");
   // task Jacobian, rows masked (osc.py:242-244)
   if constexpr (FAST) {
     T Jv[N][3], Jw[N][3];

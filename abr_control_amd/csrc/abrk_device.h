@@ -39,6 +39,12 @@
 #define ABRK_SCHED_FENCE() ((void)0)
 #endif
 
+// development aid: -DABRK_MARKS puts "; MARK <name>" comments into the ISA at phase boundaries (tools/phase_counts.py)
+#if defined(ABRK_MARKS) && defined(__HIP_DEVICE_COMPILE__)
+#define ABRK_MARK(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; MARK " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ABRK_MARK(name) ((void)0)
+#endif
 #ifndef ABRK_SINCOS_AHEAD
 #define ABRK_SINCOS_AHEAD 1
 #endif

@@ -856,24 +856,30 @@ ShardCtx* shard_ctx(int device, int slot, size_t need) {
 }
 }  // namespace
 
-extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
-                                         const void* dq, const void* target, const void* target_velocity,
-                                         void* integrated_error, const void* u_null_ext, void* u,
-                                         void* training_signal, int n_shards, const int* devices) {
+namespace {
+// One host batch over several devices: [0, B) is cut into n_shards contiguous row ranges (sizes differing by at most one
+// row - abr_control_amd/sharding.py shard_range), the pieces of shard g are staged to devices[g] on a stream of its own,
+// `launch(dev, rows, stream)` enqueues the kernel(s) on it (dev[k]: device address of piece k, null for an absent one),
+// and only when every shard is in flight are the results collected.  No collective: rows are independent.
+struct ShardPiece {
+  const void* host_in;
+  void* host_out;
+  size_t per_row;  // bytes
+};
+template <class Launch>
+int run_sharded(int64_t B, int n_shards, const int* devices, const ShardPiece* pieces, int n_pieces, Launch&& launch) {
   if (n_shards < 1 || !devices) return fail(ABRK_EINVAL, "n_shards must be >= 1 and devices non-NULL");
-  if (recording()) return fail(ABRK_EINVAL, "the sharded entry point cannot be recorded into a plan");
-  // argument checks of the single-device entry point (B = 0 returns right after them)
-  if (int rc = osc_generate_impl(arm_id, dtype, P, 0, q, dq, target, target_velocity, integrated_error, u_null_ext, u,
-                                 training_signal, 0, nullptr, devices[0], nullptr))
-    return rc;
+  if (recording()) return fail(ABRK_EINVAL, "a sharded entry point cannot be recorded into a plan");
   if (B < 0) return fail(ABRK_EINVAL, "negative batch %lld", (long long)B);
   if (B == 0) return 0;
-  const void* all[] = {q, dq, target, target_velocity, integrated_error, u_null_ext, u, training_signal};
-  for (const void* p : all) {
-    hipPointerAttribute_t at;
-    if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice)
-      return fail(ABRK_EINVAL, "the sharded entry point takes host arrays (a device pointer lives on one device)");
-    (void)hipGetLastError();  // plain malloc'ed memory is "invalid value" to HIP
+  for (int k = 0; k < n_pieces; k++) {
+    const void* ptrs[2] = {pieces[k].host_in, pieces[k].host_out};
+    for (const void* p : ptrs) {
+      hipPointerAttribute_t at;
+      if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice)
+        return fail(ABRK_EINVAL, "the sharded entry points take host arrays (a device pointer lives on one device)");
+      (void)hipGetLastError();  // plain malloc'ed memory is "invalid value" to HIP
+    }
   }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -882,31 +888,18 @@ extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_p
   }
   for (int g = 0; g < n_shards; g++)
     if (devices[g] < 0 || devices[g] >= ndev) return fail(ABRK_EINVAL, "device %d outside 0..%d", devices[g], ndev - 1);
-  ArmEntry* a = get_arm(arm_id);
-  const int n = a->desc.n_joints;
-  const size_t s = esz(dtype);
-  void* ie = (P->ki != 0) ? integrated_error : nullptr;
-  const OscP<double> p64 = make_oscp<double>(*P, n);
-  const OscP<float> p32 = make_oscp<float>(*P, n);
-  struct Piece {
-    const void* host_in;
-    void* host_out;
-    size_t per_row;  // bytes
-  };
-  const Piece pieces[8] = {{q, nullptr, n * s},           {dq, nullptr, n * s},        {target, nullptr, 6 * s},
-                           {target_velocity, nullptr, 6 * s}, {ie, ie, 6 * s},          {u_null_ext, nullptr, n * s},
-                           {nullptr, u, n * s},           {nullptr, training_signal, n * s}};
+  constexpr int kMaxPieces = 16;
+  if (n_pieces > kMaxPieces) return fail(ABRK_EINVAL, "too many arrays for one sharded call");
   std::lock_guard<std::mutex> lk(g_shard_mu);
   struct Shard {
     ShardCtx* c;
     int device;
     int64_t r0, rows;
-    char* dev[8];
+    char* dev[kMaxPieces];
   };
   std::vector<Shard> shards;
   std::vector<int> per_dev(ndev, 0);
   for (int g = 0; g < n_shards; g++) {
-    // sizes differ by at most one row (abr_control_amd/sharding.py shard_range)
     const int64_t base = B / n_shards, extra = B % n_shards;
     const int64_t r0 = g * base + (g < extra ? g : extra), r1 = r0 + base + (g < extra ? 1 : 0);
     if (r1 == r0) continue;
@@ -915,8 +908,8 @@ extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_p
     sh.r0 = r0;
     sh.rows = r1 - r0;
     size_t need = 0;
-    for (const Piece& pc : pieces)
-      if (pc.host_in || pc.host_out) need += (sh.rows * pc.per_row + 255) & ~size_t(255);
+    for (int k = 0; k < n_pieces; k++)
+      if (pieces[k].host_in || pieces[k].host_out) need += (sh.rows * pieces[k].per_row + 255) & ~size_t(255);
     HIPCHK(hipSetDevice(sh.device));
     t_current_device = sh.device;
     sh.c = shard_ctx(sh.device, per_dev[sh.device]++, need);
@@ -925,8 +918,8 @@ extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_p
       return fail(ABRK_ENOMEM, "shard %d: stream / %zu bytes of scratch on device %d", g, need, sh.device);
     }
     size_t off = 0;
-    for (int k = 0; k < 8; k++) {
-      const Piece& pc = pieces[k];
+    for (int k = 0; k < n_pieces; k++) {
+      const ShardPiece& pc = pieces[k];
       sh.dev[k] = nullptr;
       if (!pc.host_in && !pc.host_out) continue;
       sh.dev[k] = sh.c->base + off;
@@ -935,32 +928,141 @@ extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_p
         HIPCHK(hipMemcpyAsync(sh.dev[k], (const char*)pc.host_in + r0 * pc.per_row, sh.rows * pc.per_row,
                               hipMemcpyHostToDevice, sh.c->stream));
     }
-    OscArgs oa;
-    oa.q = sh.dev[0];
-    oa.dq = sh.dev[1];
-    oa.target = sh.dev[2];
-    oa.tv = sh.dev[3];
-    oa.ierr = sh.dev[4];
-    oa.une = sh.dev[5];
-    oa.u = sh.dev[6];
-    oa.ts = sh.dev[7];
-    oa.use_C = P->use_C ? 1 : 0;
-    oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
-    oa.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
-    HIPCHK(a->ops->osc(dtype, LaunchArgs{arm_table(a, dtype), (long)sh.rows, sh.c->stream}, oa));
+    HIPCHK(launch(sh.dev, sh.rows, sh.c->stream));
     shards.push_back(sh);
   }
   // every kernel is enqueued; now collect (a device-to-host copy into pageable memory waits for its shard)
   for (Shard& sh : shards) {
     HIPCHK(hipSetDevice(sh.device));
     t_current_device = sh.device;
-    for (int k = 0; k < 8; k++)
+    for (int k = 0; k < n_pieces; k++)
       if (pieces[k].host_out && sh.dev[k])
         HIPCHK(hipMemcpyAsync((char*)pieces[k].host_out + sh.r0 * pieces[k].per_row, sh.dev[k],
                               sh.rows * pieces[k].per_row, hipMemcpyDeviceToHost, sh.c->stream));
     HIPCHK(hipStreamSynchronize(sh.c->stream));
   }
   return 0;
+}
+}  // namespace
+
+extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_params* P, int64_t B, const void* q,
+                                         const void* dq, const void* target, const void* target_velocity,
+                                         void* integrated_error, const void* u_null_ext, void* u,
+                                         void* training_signal, int n_shards, const int* devices) {
+  if (n_shards < 1 || !devices) return fail(ABRK_EINVAL, "n_shards must be >= 1 and devices non-NULL");
+  // argument checks of the single-device entry point (B = 0 returns right after them)
+  if (int rc = osc_generate_impl(arm_id, dtype, P, 0, q, dq, target, target_velocity, integrated_error, u_null_ext, u,
+                                 training_signal, 0, nullptr, devices[0], nullptr))
+    return rc;
+  ArmEntry* a = get_arm(arm_id);
+  const int n = a->desc.n_joints;
+  const size_t s = esz(dtype);
+  void* ie = (P->ki != 0) ? integrated_error : nullptr;
+  const OscP<double> p64 = make_oscp<double>(*P, n);
+  const OscP<float> p32 = make_oscp<float>(*P, n);
+  const ShardPiece pieces[8] = {{q, nullptr, n * s},           {dq, nullptr, n * s},        {target, nullptr, 6 * s},
+                                {target_velocity, nullptr, 6 * s}, {ie, ie, 6 * s},          {u_null_ext, nullptr, n * s},
+                                {nullptr, u, n * s},           {nullptr, training_signal, n * s}};
+  const int use_C = P->use_C ? 1 : 0, fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
+  return run_sharded(B, n_shards, devices, pieces, 8, [&](char* const* dev, int64_t rows, hipStream_t st) {
+    OscArgs oa;
+    oa.q = dev[0];
+    oa.dq = dev[1];
+    oa.target = dev[2];
+    oa.tv = dev[3];
+    oa.ierr = dev[4];
+    oa.une = dev[5];
+    oa.u = dev[6];
+    oa.ts = dev[7];
+    oa.use_C = use_C;
+    oa.fast = fast;
+    oa.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return a->ops->osc(dtype, LaunchArgs{arm_table(a, dtype), (long)rows, st}, oa);
+  });
+}
+
+extern "C" int abrk_sliding_generate_sharded(int arm_id, int dtype, const abrk_sliding_params* P, int64_t B,
+                                             const void* q, const void* dq, const void* target,
+                                             const void* target_velocity, const void* target_acc, void* u, void* s_out,
+                                             int n_shards, const int* devices) {
+  if (n_shards < 1 || !devices) return fail(ABRK_EINVAL, "n_shards must be >= 1 and devices non-NULL");
+  if (int rc = abrk_sliding_generate_batch(arm_id, dtype, P, 0, q, dq, target, target_velocity, target_acc, u, s_out,
+                                           devices[0], nullptr))
+    return rc;
+  ArmEntry* a = get_arm(arm_id);
+  const int n = a->desc.n_joints, nt = P->cartesian ? 3 : n;
+  const size_t s = esz(dtype);
+  const SlidingP<double> p64 = make_slidingp<double>(*P, n);
+  const SlidingP<float> p32 = make_slidingp<float>(*P, n);
+  const ShardPiece pieces[7] = {{q, nullptr, n * s},  {dq, nullptr, n * s},         {target, nullptr, nt * s},
+                                {target_velocity, nullptr, nt * s}, {target_acc, nullptr, nt * s},
+                                {nullptr, u, n * s},  {nullptr, s_out, n * s}};
+  return run_sharded(B, n_shards, devices, pieces, 7, [&](char* const* dev, int64_t rows, hipStream_t st) {
+    SlidingArgs sa;
+    sa.q = dev[0];
+    sa.dq = dev[1];
+    sa.target = dev[2];
+    sa.tv = dev[3];
+    sa.ta = dev[4];
+    sa.u = dev[5];
+    sa.s = dev[6];
+    sa.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return a->ops->sliding(dtype, LaunchArgs{arm_table(a, dtype), (long)rows, st}, sa);
+  });
+}
+
+extern "C" int abrk_joint_generate_sharded(int arm_id, int dtype, const abrk_null_ctrl* ctrl, int account_for_gravity,
+                                           int64_t B, const void* q, const void* dq, const void* target,
+                                           const void* target_velocity, void* u, int n_shards, const int* devices) {
+  if (n_shards < 1 || !devices) return fail(ABRK_EINVAL, "n_shards must be >= 1 and devices non-NULL");
+  if (int rc = abrk_joint_generate_batch(arm_id, dtype, ctrl, account_for_gravity, 0, q, dq, target, target_velocity, u,
+                                         devices[0], nullptr))
+    return rc;
+  ArmEntry* a = get_arm(arm_id);
+  const int n = a->desc.n_joints;
+  const size_t s = esz(dtype);
+  const JointP<double> p64 = make_jointp<double>(*ctrl, account_for_gravity);
+  const JointP<float> p32 = make_jointp<float>(*ctrl, account_for_gravity);
+  const ShardPiece pieces[5] = {{q, nullptr, n * s}, {dq, nullptr, n * s}, {target, nullptr, n * s},
+                                {target_velocity, nullptr, n * s}, {nullptr, u, n * s}};
+  return run_sharded(B, n_shards, devices, pieces, 5, [&](char* const* dev, int64_t rows, hipStream_t st) {
+    JointArgs ja;
+    ja.q = dev[0];
+    ja.dq = dev[1];
+    ja.target = dev[2];
+    ja.tv = dev[3];
+    ja.u = dev[4];
+    ja.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
+    return a->ops->joint(dtype, LaunchArgs{arm_table(a, dtype), (long)rows, st}, ja);
+  });
+}
+
+extern "C" int abrk_dynamics_sharded(int arm_id, int dtype, int64_t B, const void* q, const void* dq, int frame,
+                                     const double* x_off, uint32_t want, const abrk_dyn_out* out, int n_shards,
+                                     const int* devices) {
+  if (n_shards < 1 || !devices) return fail(ABRK_EINVAL, "n_shards must be >= 1 and devices non-NULL");
+  if (int rc = abrk_dynamics_batch(arm_id, dtype, 0, q, dq, frame, x_off, want, out, devices[0], nullptr)) return rc;
+  ArmEntry* a = get_arm(arm_id);
+  const int n = a->desc.n_joints;
+  const size_t s = esz(dtype);
+  void* const* outs = reinterpret_cast<void* const*>(out);
+  const size_t per[10] = {3, (size_t)6 * n, (size_t)n * n, (size_t)n, (size_t)n * n, (size_t)6 * n, 9, 16, 16, 4};
+  const bool vel = (want & (ABRK_WANT_C | ABRK_WANT_DJ)) != 0;
+  ShardPiece pieces[12] = {{q, nullptr, n * s}, {vel ? dq : nullptr, nullptr, n * s}};
+  for (int i = 0; i < 10; i++) pieces[2 + i] = {nullptr, (want >> i & 1) ? outs[i] : nullptr, per[i] * s};
+  DynArgs da0;
+  memset(&da0, 0, sizeof da0);
+  da0.frame = frame;
+  da0.m = frame_m(frame, n);
+  for (int r = 0; r < 3; r++) da0.off[r] = x_off ? x_off[r] : 0.0;
+  da0.want = want;
+  return run_sharded(B, n_shards, devices, pieces, 12, [&](char* const* dev, int64_t rows, hipStream_t st) {
+    DynArgs da = da0;
+    da.q = dev[0];
+    da.dq = dev[1];
+    for (int i = 0; i < 10; i++) da.out[i] = dev[2 + i];
+    return a->ops->dyn(dtype, LaunchArgs{arm_table(a, dtype), (long)rows, st}, da);
+  });
 }
 
 // ------------------------------------------------------------------------------- Sliding

@@ -83,8 +83,15 @@ dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, con
 #ifndef ABRK_KM6_TWO_WAVES
 #define ABRK_KM6_TWO_WAVES 1  // six-row law with its Jacobian rows in LDS (osc_law6)
 #endif
+#ifndef ABRK_KM6_TWO_WAVES_GENERAL
+#define ABRK_KM6_TWO_WAVES_GENERAL 0
+#endif
 constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho, int pass = 0) {
-  if (km == 6) return (pass == 1 && ABRK_KM6_TWO_WAVES && ABRK_KM6_LDS && (!use_c || ortho) && feat <= 1) ? 2 : ABRK_MIN_WAVES;
+  // six-row law: the first pass of orthogonal chains fits 256 registers (UR5: 100-216 B of scratch, all of it in cold
+  // branches); general chains carry a 3 x 3 W per joint through the kinematics and would spill 250-650 B in the hot
+  // path (ABRK_KM6_TWO_WAVES_GENERAL = 1 forces them too - a measurement switch)
+  if (km == 6)
+    return (pass == 1 && ABRK_KM6_TWO_WAVES && ABRK_KM6_LDS && (ortho || ABRK_KM6_TWO_WAVES_GENERAL) && feat <= 1) ? 2 : ABRK_MIN_WAVES;
   return ((!use_c || (ABRK_C_TWO_WAVES && ortho)) && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES)))
              ? 2
              : ABRK_MIN_WAVES;

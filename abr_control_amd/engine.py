@@ -208,6 +208,64 @@ def osc_generate_sharded(arm_id, n, params, q, dq, target, devices, target_veloc
     return (uo, tso) if tso is not None else uo
 
 
+def _host_only(**arrays):
+    for name, arr in arrays.items():
+        if isinstance(arr, DeviceArray):
+            raise TypeError(f"{name}: the sharded calls take NumPy arrays (a DeviceArray lives on one device)")
+
+
+def sliding_generate_sharded(arm_id, n, params, q, dq, target, devices, target_velocity=None, target_acc=None,
+                             want_s=False, dtype=np.float64):
+    """Sliding.generate of ONE host batch over several devices (abrk_sliding_generate_sharded)"""
+    _host_only(q=q, dq=dq, target=target, target_velocity=target_velocity, target_acc=target_acc)
+    a = _Args(dtype)
+    B = q.shape[0]
+    nt = 3 if params.cartesian else n
+    qp, dqp = a.inp(q, (B, n), "q"), a.inp(dq, (B, n), "dq")
+    tp = a.inp(target, (B, nt), "target")
+    tvp, tap = a.inp(target_velocity, (B, nt), "target_velocity"), a.inp(target_acc, (B, nt), "target_acc")
+    up, uo = a.out(None, (B, n), 0, "u")
+    sp, so = a.out(None, (B, n), 0, "s") if want_s else (None, None)
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    check(lib().abrk_sliding_generate_sharded(arm_id, a.code, C.byref(params), B, qp, dqp, tp, tvp, tap, up, sp,
+                                              len(devices), devs))
+    return (uo, so) if want_s else uo
+
+
+def joint_generate_sharded(arm_id, n, ctrl, account_for_gravity, q, dq, devices, target=None, target_velocity=None,
+                           dtype=np.float64):
+    """Joint / Damping / RestingConfig.generate of ONE host batch over several devices (abrk_joint_generate_sharded)"""
+    _host_only(q=q, dq=dq, target=target, target_velocity=target_velocity)
+    a = _Args(dtype)
+    B = q.shape[0]
+    qp, dqp = a.inp(q, (B, n), "q"), a.inp(dq, (B, n), "dq")
+    tp, tvp = a.inp(target, (B, n), "target"), a.inp(target_velocity, (B, n), "target_velocity")
+    up, uo = a.out(None, (B, n), 0, "u")
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    check(lib().abrk_joint_generate_sharded(arm_id, a.code, C.byref(ctrl), int(bool(account_for_gravity)), B, qp, dqp, tp,
+                                            tvp, up, len(devices), devs))
+    return uo
+
+
+def dynamics_sharded(arm_id, n, q, devices, dq=None, frame=None, x_off=None, want=("M",), dtype=np.float64):
+    """robot_config.{Tx,J,M,g,C,dJ,R,T,T_inv,quaternion} of ONE host batch over several devices (abrk_dynamics_sharded)"""
+    _host_only(q=q, dq=dq)
+    a = _Args(dtype)
+    B = q.shape[0]
+    frame = 2 * n + 1 if frame is None else frame
+    qp, dqp = a.inp(q, (B, n), "q"), a.inp(dq, (B, n), "dq")
+    bits, do, res = 0, _abi.DynOut(), {}
+    for name in want:
+        bits |= _WANT_BITS[name]
+        ptr, obj = a.out(None, (B,) + _OUT_SHAPES[name](n), 0, name)
+        setattr(do, name, ptr)
+        res[name] = obj
+    xo = None if x_off is None else (C.c_double * 3)(*[float(v) for v in x_off])
+    devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+    check(lib().abrk_dynamics_sharded(arm_id, a.code, B, qp, dqp, frame, xo, bits, C.byref(do), len(devices), devs))
+    return res
+
+
 def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=None, target_velocity=None,
             integrated_error=None, u_null_ext=None, training_signal=False, dtype=np.float64, device=0, stream=None):
     """The OSC control law on caller-supplied dynamics (abrk_osc_law_batch): J [B,6,n], M [B,n,n] and,

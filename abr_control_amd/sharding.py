@@ -36,7 +36,8 @@ class MultiDevice:
         md = MultiDevice()                  # every visible device
         u = md.generate(ctrlr, Q, dQ, targets)
 
-    `ctrlr`: an abr_control_amd OSC whose secondary controllers are the fused ones (Damping / RestingConfig)."""
+    `ctrlr`: an abr_control_amd OSC whose secondary controllers are the fused ones (Damping / RestingConfig), or a
+    Sliding / Joint / Damping / RestingConfig; `md.dynamics(robot_config, q, ...)` shards the robot_config functions."""
 
     def __init__(self, devices=None):
         import abr_control_amd as a
@@ -48,7 +49,43 @@ class MultiDevice:
         if not self.devices or any(d < 0 or d >= n for d in self.devices):
             raise ValueError(f"devices {self.devices} outside 0..{n - 1}")
 
-    def generate(self, ctrlr, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None):
+    def generate(self, ctrlr, q, dq, *args, **kwargs):
+        """ctrlr.generate(q, dq, ...) with the host batch cut over this object's devices.  OSC (fused null controllers),
+        Sliding, Joint, Damping, RestingConfig; arguments and results as the controller's own generate()."""
+        from .controllers import OSC
+
+        if isinstance(ctrlr, OSC):
+            return self._generate_osc(ctrlr, q, dq, *args, **kwargs)
+        if not hasattr(ctrlr, "_joint_generate"):
+            raise TypeError(f"MultiDevice.generate: {type(ctrlr).__name__} has no sharded entry point")
+        from ._lib import DeviceArray
+
+        if isinstance(q, DeviceArray):
+            raise TypeError("MultiDevice takes NumPy arrays (a DeviceArray lives on one device)")
+        ctrlr._shard_devices = self.devices
+        try:
+            return ctrlr.generate(q, dq, *args, **kwargs)
+        finally:
+            ctrlr._shard_devices = None
+
+    def dynamics(self, robot_config, q, dq=None, name="EE", x=None, want=("Tx", "J", "M", "g")):
+        """robot_config.dynamics(...) - several robot_config functions from one launch per device - over this
+        object's devices: {name: [B, ...]} in the kernel dtype"""
+        import numpy as np
+
+        from . import engine
+
+        rc = robot_config
+        q2, dq2, single, dev = rc._prep(q, dq)
+        if dev:
+            raise TypeError("MultiDevice takes NumPy arrays (a DeviceArray lives on one device)")
+        xo = None if x is None or np.allclose(x, 0) else np.asarray(x, dtype=float)
+        res = engine.dynamics_sharded(rc.arm_id, rc.N_JOINTS, np.ascontiguousarray(q2), self.devices,
+                                      None if dq2 is None else np.ascontiguousarray(dq2), rc.frame_id(name), xo,
+                                      tuple(want), rc.dtype)
+        return {k: v[0] for k, v in res.items()} if single else res
+
+    def _generate_osc(self, ctrlr, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None):
         import numpy as np
 
         from . import engine
