@@ -188,20 +188,6 @@ int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_params* para
                               void* integrated_error, const void* u_null_ext, void* u, void* training_signal,
                               int n_shards, const int* devices);
 
-/* The same for Sliding.generate (sliding.py:34-99; BASELINE config 5), Joint / Damping / RestingConfig.generate
- * (joint.py:104-131, damping.py:21-32, resting_config.py:18-42) and the robot_config functions (base_config.py:210-415):
- * arguments as the *_batch entry point of the same name, host arrays only, n_shards contiguous row ranges on
- * devices[0..n_shards-1], every kernel in flight before the first result is collected, no collective.              */
-int abrk_sliding_generate_sharded(int arm_id, int dtype, const abrk_sliding_params* params, int64_t B, const void* q,
-                                  const void* dq, const void* target, const void* target_velocity,
-                                  const void* target_acc, void* u, void* s_out, int n_shards, const int* devices);
-int abrk_joint_generate_sharded(int arm_id, int dtype, const abrk_null_ctrl* ctrl, int account_for_gravity, int64_t B,
-                                const void* q, const void* dq, const void* target, const void* target_velocity, void* u,
-                                int n_shards, const int* devices);
-int abrk_dynamics_sharded(int arm_id, int dtype, int64_t B, const void* q, const void* dq, int frame,
-                          const double* x_off, uint32_t want, const abrk_dyn_out* out, int n_shards,
-                          const int* devices);
-
 /* The same control law (osc.py:244-318) on CALLER-SUPPLIED dynamics: keeps `OSC(robot_config=<any duck
  * type>)` working for configs whose arithmetic lives elsewhere (the reference's MujocoConfig,
  * abr_control/arms/mujoco_config.py:201-451: J/M/g/Tx/R read from mjData).  Per row, row-major:
@@ -353,6 +339,20 @@ int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_ctrl* ctrl,
                               int account_for_gravity, int64_t B, const void* q,
                               const void* dq, const void* target, const void* target_velocity,
                               void* u, int device, void* stream);
+
+/* The same for Sliding.generate (sliding.py:34-99; BASELINE config 5), Joint / Damping / RestingConfig.generate
+ * (joint.py:104-131, damping.py:21-32, resting_config.py:18-42) and the robot_config functions (base_config.py:210-415):
+ * arguments as the *_batch entry point of the same name, host arrays only, n_shards contiguous row ranges on
+ * devices[0..n_shards-1], every kernel in flight before the first result is collected, no collective.              */
+int abrk_sliding_generate_sharded(int arm_id, int dtype, const abrk_sliding_params* params, int64_t B, const void* q,
+                                  const void* dq, const void* target, const void* target_velocity,
+                                  const void* target_acc, void* u, void* s_out, int n_shards, const int* devices);
+int abrk_joint_generate_sharded(int arm_id, int dtype, const abrk_null_ctrl* ctrl, int account_for_gravity, int64_t B,
+                                const void* q, const void* dq, const void* target, const void* target_velocity, void* u,
+                                int n_shards, const int* devices);
+int abrk_dynamics_sharded(int arm_id, int dtype, int64_t B, const void* q, const void* dq, int frame,
+                          const double* x_off, uint32_t want, const abrk_dyn_out* out, int n_shards,
+                          const int* devices);
 
 /* ---------------------------------------------------------------------------------
  * The remaining secondary controllers.  Each writes u [B,n]; with accumulate != 0 it
