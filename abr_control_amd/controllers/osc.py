@@ -152,7 +152,7 @@ class OSC(Controller):
     def generate(self, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None, return_dynamics=None):
         """Control signal(s) moving `ref_frame` to `target` (osc.py:217-320).
 
-        return_dynamics (extension): a subset of ("Tx", "J", "M", "g") -> returns (u, {name: array}) with the
+        return_dynamics (extension): a subset of ("Tx", "J", "M", "g", "C", "dJ") -> returns (u, {name: array}) with the
         robot_config outputs of `ref_frame` / `xyz_offset` that the law consumed, from the same kernel launch
         (one forward kinematics instead of two; full precision, kernel dtype).
 

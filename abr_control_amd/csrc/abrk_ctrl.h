@@ -1069,9 +1069,12 @@ struct NoEmit {
   template <class... X>
   ABRK_INL void operator()(X&&...) const {}
 };
-// `emit(p, Jv, Jw, Ms, gz)` sees the task point, its Jacobian columns, M (packed lower) and the gravity accumulators
-// the law is about to consume - the fused "u + robot_config outputs" kernel stores them from there (SURVEY 8d Mode F).
-template <class A, class T, int KM, bool USE_C, int FEAT, class Late, class Scr, class Emit = NoEmit>
+// `emit(p, Jv, Jw, d, jt, m)` sees the task point, its Jacobian columns, the dynamics accumulators (M packed lower, the
+// gravity sums, with MAT the Christoffel matrix) and the joint frames the law is about to consume - the fused "u +
+// robot_config outputs" kernel stores them from there (SURVEY 8d Mode F).
+// MAT: the dynamics pass also assembles the full C(q,dq) (base_config.py:678-727) - Mode F with `C` among the outputs;
+// the law's Coriolis vector is then C dq from that matrix instead of the body recursion.
+template <class A, class T, int KM, bool USE_C, int FEAT, bool MAT = false, class Late, class Scr, class Emit = NoEmit>
 ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
                       bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
                       const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late, Scr& scr,
@@ -1083,9 +1086,10 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   // in `scr` - LDS on the GPU, so the 12 N registers they would take stay free and the kernel keeps two waves per
   // SIMD -; one backward sweep (rne_backward) then projects the sums onto the joint axes.  (Until round 2 the
   // recursion ran as a pass of its own with a second forward kinematics: +128 instructions per row.)
-  constexpr bool TWO_PASS = USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0);
+  constexpr bool TWO_PASS = USE_C && !MAT && A::kOrtho && (ABRK_C_TWO_PASS != 0);
   Joints<A, T> jt;
-  Dyn<A, T, (USE_C && !TWO_PASS) ? CMODE_VEC : CMODE_NONE> d;
+  Dyn<A, T, MAT ? CMODE_MAT : (USE_C && !TWO_PASS) ? CMODE_VEC : CMODE_NONE> d;
+  T cvm[(MAT && USE_C) ? N : 1];  // C dq from the matrix
   T XR[9], xo[3];
   T p[3], RF[9];
   T cv2[TWO_PASS ? N : 1];
@@ -1139,14 +1143,24 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     m = P.m_joints;
   }
   ABRK_MARK("row:jacobian");
+  if constexpr (MAT && USE_C) {
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      T acc = T(-0.0);
+      sfor<N>([&](auto j) ABRK_LAMBDA { acc += d.Cm[i() * N + j()] * dq[j()]; });
+      cvm[i()] = acc;
+    });
+  }
   // task Jacobian, rows masked (osc.py:242-244)
   if constexpr (FAST) {
     T Jv[N][3], Jw[N][3];
     jacobian(jt, p, m, Jv, Jw);
-    emit(p, Jv, Jw, d.Ms, d.gz);
+    emit(p, Jv, Jw, d, jt, m);
     ABRK_SCHED_FENCE();
     late();
-    if constexpr (TWO_PASS)
+    if constexpr (MAT && USE_C)
+      osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cvm, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
+                                    ierr, have_ext, une, u, ts, scr.defer_ptr());
+    else if constexpr (TWO_PASS)
       osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
                                     ierr, have_ext, une, u, ts, scr.defer_ptr());
     else if constexpr (USE_C)
@@ -1160,7 +1174,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
       // the six rows go to the row store (the LDS slab on the GPU - free again: rne_backward has read the wrenches)
       T Jv[N][3], Jw[N][3];
       jacobian(jt, p, m, Jv, Jw);
-      emit(p, Jv, Jw, d.Ms, d.gz);
+      emit(p, Jv, Jw, d, jt, m);
       sfor<6>([&](auto r) ABRK_LAMBDA {
         const bool on = P.dof[r()] != 0;
         T row[N];
@@ -1174,7 +1188,10 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     }
     ABRK_SCHED_FENCE();
     late();
-    if constexpr (TWO_PASS)
+    if constexpr (MAT && USE_C)
+      osc_law6<N, T, true, FEAT>(P, d.Ms, d.gz, T(9.81), cvm, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+                                 have_ext, une, u, ts, scr.defer_ptr());
+    else if constexpr (TWO_PASS)
       osc_law6<N, T, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
                                  have_ext, une, u, ts, scr.defer_ptr());
     else if constexpr (USE_C)

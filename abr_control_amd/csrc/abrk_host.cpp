@@ -695,8 +695,9 @@ extern "C" int abrk_osc_generate_full_batch(int arm_id, int dtype, const abrk_os
                                             void* integrated_error, const void* u_null_ext, void* u,
                                             void* training_signal, uint32_t want, const abrk_dyn_out* out, int device,
                                             void* stream) {
-  const uint32_t ok = ABRK_WANT_TX | ABRK_WANT_J | ABRK_WANT_M | ABRK_WANT_G;
-  if (!want || (want & ~ok)) return fail(ABRK_EINVAL, "want must be a non-empty subset of Tx | J | M | g (0x%x)", want);
+  const uint32_t ok = ABRK_WANT_TX | ABRK_WANT_J | ABRK_WANT_M | ABRK_WANT_G | ABRK_WANT_C | ABRK_WANT_DJ;
+  if (!want || (want & ~ok))
+    return fail(ABRK_EINVAL, "want must be a non-empty subset of Tx | J | M | g | C | dJ (0x%x)", want);
   if (!out) return fail(ABRK_EINVAL, "out is NULL");
   return osc_generate_impl(arm_id, dtype, P, B, q, dq, target, target_velocity, integrated_error, u_null_ext, u,
                            training_signal, want, out, device, stream);
@@ -723,8 +724,9 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   if (k == 0) return fail(ABRK_EINVAL, "ctrlr_dof selects no task-space dimension");
   if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
   if (P->ki != 0 && !integrated_error) return fail(ABRK_EINVAL, "ki != 0 needs the integrated_error state array");
-  void* const wout[4] = {out ? out->Tx : nullptr, out ? out->J : nullptr, out ? out->M : nullptr, out ? out->g : nullptr};
-  for (int i = 0; i < 4; i++)
+  void* const wout[6] = {out ? out->Tx : nullptr, out ? out->J : nullptr, out ? out->M : nullptr, out ? out->g : nullptr,
+                         out ? out->C : nullptr,  out ? out->dJ : nullptr};
+  for (int i = 0; i < 6; i++)
     if ((want >> i & 1) && !wout[i]) return fail(ABRK_EINVAL, "output %d requested but its pointer is NULL", i);
   if (B == 0) return 0;
   if (int rc = use_device(device)) return rc;
@@ -739,13 +741,13 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   const void* une_ = st.add(u_null_ext, B * n * s, true, false);
   void* u_ = st.add(u, B * n * s, false, true);
   void* ts_ = st.add(training_signal, B * n * s, false, true);
-  const size_t per[4] = {3, (size_t)6 * n, (size_t)n * n, (size_t)n};
-  void* o_[4];
-  for (int i = 0; i < 4; i++) o_[i] = (want >> i & 1) ? st.add(wout[i], B * per[i] * s, false, true) : nullptr;
+  const size_t per[6] = {3, (size_t)6 * n, (size_t)n * n, (size_t)n, (size_t)n * n, (size_t)6 * n};
+  void* o_[6];
+  for (int i = 0; i < 6; i++) o_[i] = (want >> i & 1) ? st.add(wout[i], B * per[i] * s, false, true) : nullptr;
   if (int rc = st.reserve()) return rc;
   OscArgs oa;
   oa.want = want;
-  for (int i = 0; i < 4; i++) oa.out[i] = (want >> i & 1) ? st.fix(o_[i], wout[i]) : nullptr;
+  for (int i = 0; i < 6; i++) oa.out[i] = (want >> i & 1) ? st.fix(o_[i], wout[i]) : nullptr;
   oa.q = st.fix(q_, q);
   oa.dq = st.fix(dq_, dq);
   oa.target = st.fix(t_, target);

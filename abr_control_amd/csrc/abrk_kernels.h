@@ -265,33 +265,34 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 // Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
 // cooperative stores and (use_C) the scratch of the Coriolis recursion, which is dead by the time the first row is
 // parked.  FEAT is 0 (the plain law) or 2 (every optional input).
-template <class A, class T, int KM, bool USE_C, int FEAT>
-__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
+template <class A, class T, int KM, bool USE_C, int FEAT, bool VEL = false>
+__global__ void __launch_bounds__(kBlock, VEL ? ABRK_MIN_WAVES : osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
 osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                 const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
                 const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, unsigned want, DynOutP<T> out) {
-  __shared__ __attribute__((aligned(16))) T slab[kBlock * max_row(A::N)];
-  static_assert(max_row(A::N) >= 6 * A::N, "the slab also holds the 6 N scratch values of the Coriolis recursion");
+  // the slab: cooperative stores, scratch of the Coriolis recursion, row store of the six-row law - one after the other
+  constexpr int kSlabT = max_row(A::N) > 2 * slab_pairs<A::N>() ? max_row(A::N) : 2 * slab_pairs<A::N>();
+  __shared__ __attribute__((aligned(16))) T slab[kBlock * kSlabT];
   const long row0 = (long)blockIdx.x * kBlock;
   const long b = row0 + threadIdx.x;
   LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
   constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
   __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
   if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);
-  if constexpr (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) {
+  if constexpr ((USE_C && !VEL && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) || (KM == 6 && (ABRK_KM6_LDS != 0))) {
     using V2 = typename LdsScratch<T, A::N>::V2;
     LdsScratch<T, A::N> scr;
     scr.slab = reinterpret_cast<V2*>(slab);
     scr.lane = (int)threadIdx.x;
     scr.sctab = sctab;
-    osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
+    osc_full_body<A, T, KM, USE_C, FEAT, VEL>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
   } else if constexpr (kTab) {
     TabScratch<T, A::N> scr;
     scr.sctab = sctab;
-    osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
+    osc_full_body<A, T, KM, USE_C, FEAT, VEL>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
   } else {
     RegScratch<T, A::N> scr;
-    osc_full_body<A, T, KM, USE_C, FEAT>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
+    osc_full_body<A, T, KM, USE_C, FEAT, VEL>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
   }
 }
 
@@ -474,8 +475,8 @@ struct OscArgs {
   const void *q, *dq, *target, *tv, *une;
   void *ierr, *u, *ts;
   int* wl = nullptr;  // worklist of B + 1 ints: rows that need the Jacobi sweeps are deferred to a dense second pass
-  unsigned want = 0;  // != 0: the fused Mode-F kernel also writes Tx / J / M / g (W_TX | W_J | W_M | W_G)
-  void* out[4] = {nullptr, nullptr, nullptr, nullptr};
+  unsigned want = 0;  // != 0: the fused Mode-F kernel also writes Tx / J / M / g / C / dJ (W_TX | ... | W_DJ)
+  void* out[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 struct SlidingArgs {
   const void* P;  // SlidingP<T>
@@ -550,22 +551,27 @@ struct Launch {
     if (nulls) return osc_launch<KM, UC, 1>(la, a);
     return osc_launch<KM, UC, 0>(la, a);
   }
-  template <int KM, bool UC, int FEAT>
+  template <int KM, bool UC, int FEAT, bool VEL>
   static void osc_full_launch(const LaunchArgs& la, const OscArgs& a) {
     DynOutP<T> o{};
     o.Tx = (T*)a.out[0];
     o.J = (T*)a.out[1];
     o.M = (T*)a.out[2];
     o.g = (T*)a.out[3];
-    hipLaunchKernelGGL((osc_full_kernel<A, T, KM, UC, FEAT>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
+    o.C = (T*)a.out[4];
+    o.dJ = (T*)a.out[5];
+    hipLaunchKernelGGL((osc_full_kernel<A, T, KM, UC, FEAT, VEL>), grid_for(la.B), dim3(kBlock), 0, la.stream, arm_of(la),
                        *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
                        (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, a.want, o);
   }
   template <int KM, bool UC>
   static void osc_full_feat(const LaunchArgs& la, const OscArgs& a) {
     const bool plain = !(a.tv || a.ierr || a.une) && static_cast<const OscP<T>*>(a.P)->n_null == 0;
-    if (plain) osc_full_launch<KM, UC, 0>(la, a);
-    else osc_full_launch<KM, UC, 2>(la, a);
+    // C / dJ among the outputs: the variant whose dynamics pass assembles the Christoffel matrix (FEAT 2 only: the
+    // velocity-dependent outputs are the rarer request and one instantiation per (KM, use_C) keeps the build in bounds)
+    if (a.want & (W_C | W_DJ)) osc_full_launch<KM, UC, 2, true>(la, a);
+    else if (plain) osc_full_launch<KM, UC, 0, false>(la, a);
+    else osc_full_launch<KM, UC, 2, false>(la, a);
   }
   static hipError_t osc_full(const LaunchArgs& la, const OscArgs& a) {
     // the two-row kernel of the planar examples is not duplicated: x,y control of a small arm takes the six-row form

@@ -189,7 +189,10 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
 // robot_config.J/M/g/Tx next to ctrlr.generate (osc.py:242-301 consumers, training-signal users) would otherwise
 // pay a second forward kinematics for.  Cooperative stores (St = LdsStore on the GPU): padding lanes of the last
 // wavefront evaluate a clamped row and only take part in the stores.
-template <class A, class T, int KM, bool USE_C, int FEAT, class Scr, class St>
+// VEL: `want` may also name C [B,n,n] (base_config.py:320-336) and dJ [B,6,n] (:225-247) of the same frame / offset -
+// the two velocity-dependent robot_config functions (+288 B per UR5 row each); the dynamics pass then
+// assembles the Christoffel matrix (osc_row MAT).
+template <class A, class T, int KM, bool USE_C, int FEAT, bool VEL = false, class Scr, class St>
 ABRK_INL void osc_full_body(long b, bool active, St& st, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg,
                             const T* __restrict__ dqg, const T* __restrict__ tg, const T* __restrict__ tvg,
                             T* __restrict__ ierrg, const T* __restrict__ uneg, T* __restrict__ ug,
@@ -210,8 +213,9 @@ ABRK_INL void osc_full_body(long b, bool active, St& st, const A& arm, const Osc
     if (have_ext) load_row<N>(uneg, bl, une);
     else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
   };
-  auto emit = [&](const T(&p)[3], const T(&Jv)[N][3], const T(&Jw)[N][3], const T(&Ms)[N * (N + 1) / 2],
-                  const T(&gz)[N]) ABRK_LAMBDA {
+  auto emit = [&](const T(&p)[3], const T(&Jv)[N][3], const T(&Jw)[N][3], const auto& d, const auto& jt, int m) ABRK_LAMBDA {
+    const auto& Ms = d.Ms;
+    const auto& gz = d.gz;
     if (want & W_TX) st.template put<3>(out.Tx, b, active, p);
     if (want & W_J) {
       T row[6 * N];
@@ -233,8 +237,24 @@ ABRK_INL void osc_full_body(long b, bool active, St& st, const A& arm, const Osc
       sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = T(-9.81) * gz[i()]; });
       st.template put<N>(out.g, b, active, row);
     }
+    if constexpr (VEL) {
+      if (want & W_C) st.template put<N * N>(out.C, b, active, d.Cm);
+      if (want & W_DJ) {
+        T dJv[N][3], dJw[N][3];
+        jacobian_dot(jt, dq, Jv, m, dJv, dJw);
+        T row[6 * N];
+        sfor<3>([&](auto r) ABRK_LAMBDA {
+          sfor<N>([&](auto i) ABRK_LAMBDA {
+            row[r() * N + i()] = dJv[i()][r()];
+            row[(3 + r()) * N + i()] = dJw[i()][r()];
+          });
+        });
+        st.template put<6 * N>(out.dJ, b, active, row);
+      }
+    }
   };
-  osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr, emit);
+  osc_row<A, T, KM, USE_C, FEAT, VEL>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr,
+                                      emit);
   if (active) {
     store_row<N>(ug, b, u);
     if (tsg) store_row<N>(tsg, b, ts);

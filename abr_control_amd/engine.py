@@ -118,7 +118,7 @@ def osc_generate(arm_id, n, params, q, dq, target, target_velocity=None, integra
                  want=None, out=None):
     """OSC.generate for a batch.  `integrated_error` ([B,6]) is updated in place when ki != 0.
     Returns u, or (u, training_signal) when training_signal is True / an output array.
-    want: subset of ("Tx", "J", "M", "g") -> the fused kernel (abrk_osc_generate_full_batch) also writes those
+    want: subset of ("Tx", "J", "M", "g", "C", "dJ") -> the fused kernel (abrk_osc_generate_full_batch) also writes those
     robot_config outputs of the controller's ref_frame / xyz_offset; the return value gains a dict of them
     (`out`: optional dict of preallocated arrays)."""
     a = _Args(dtype)
@@ -145,8 +145,8 @@ def osc_generate(arm_id, n, params, q, dq, target, target_velocity=None, integra
     if want:
         bits, do, res = 0, _abi.DynOut(), {}
         for name in want:
-            if name not in ("Tx", "J", "M", "g"):
-                raise ValueError(f"the fused kernel offers Tx, J, M, g - not {name!r}")
+            if name not in ("Tx", "J", "M", "g", "C", "dJ"):
+                raise ValueError(f"the fused kernel offers Tx, J, M, g, C, dJ - not {name!r}")
             bits |= _WANT_BITS[name]
             ptr, obj = a.out(None if out is None else out.get(name), (B,) + _OUT_SHAPES[name](n), device, name)
             setattr(do, name, ptr)

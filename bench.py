@@ -57,6 +57,8 @@ WORKLOADS = {
     # SURVEY 8d "Mode F": the control signal AND the robot_config outputs it consumed (Tx, J, M, g of the EE) from ONE
     # launch of the fused kernel (abrk_osc_generate_full_batch) - 192 + 648 = 840 B per row, HBM-bound
     "oscF": ("ur5", 4096, "f64", "osc_full", dict(kp=200), 3500),
+    # ... plus the Christoffel matrix C(q, dq) [n,n] (base_config.py:320-336; SURVEY 8d: +288 B per row = 1128 B)
+    "oscFC": ("ur5", 4096, "f64", "osc_full", dict(kp=200, want=("Tx", "J", "M", "g", "C")), 10000),
     # SURVEY 8f-1 (first "next" row): the examples' closed loop on the device - OSC.generate followed by the
     # two-link plant step (arms/twojoint/arm_sim.py:101-137), `rollout_steps` control steps per launch
     "rollout": ("twojoint", 4096, "f64", "rollout", dict(kp=20, use_C=True, ctrlr_dof=[1, 1, 0, 0, 0, 0]), 600),
@@ -87,8 +89,9 @@ def algorithmic_bytes(n, esz, kind, want=None):
     if kind == "dyn":
         want = want or ("Tx", "J", "M", "g")
         return esz * n * (2 if ("C" in want or "dJ" in want) else 1) + esz * sum(DYN_OUT(n)[w] for w in want)
-    if kind == "osc_full":  # Mode U (q, dq, target in; u out) + Tx, J, M, g out
-        return esz * (2 * n + 6) + esz * n + esz * (3 + 6 * n + n * n + n)
+    if kind == "osc_full":  # Mode U (q, dq, target in; u out) + the requested robot_config outputs
+        want = want or ("Tx", "J", "M", "g")
+        return esz * (2 * n + 6) + esz * n + esz * sum(DYN_OUT(n)[w] for w in want)
     if kind == "ik":  # per launch and row: q, target in; position + velocity paths out
         return esz * (n + 6) + esz * 2 * 200 * n
     if kind == "rollout":  # per launch and row: q, dq in/out + target; amortised over ROLLOUT_STEPS
@@ -163,7 +166,7 @@ class Runner:
             self.want = kw.get("want", ("Tx", "J", "M", "g"))
             self.dyn_out = {w: a.DeviceArray((B,) + shapes[w], self.dt, device) for w in self.want}
             if kind == "osc_full":
-                self.params = _abi.make_osc_params(self.n, **kw)
+                self.params = _abi.make_osc_params(self.n, **{k: v for k, v in kw.items() if k != "want"})
         elif kind == "sliding":
             self.params = _abi.make_sliding_params(self.n)
         elif kind == "limits":
@@ -198,7 +201,7 @@ class Runner:
             self.step()
             stream.sync()
         self.bytes_per_eval = algorithmic_bytes(self.n, np.dtype(self.dt).itemsize, kind,
-                                                getattr(self, "want", None) if kind == "dyn" else None)
+                                                getattr(self, "want", None) if kind in ("dyn", "osc_full") else None)
         self.evals_per_launch = B * (ROLLOUT_STEPS if kind == "rollout" else kw["n_timesteps"] if kind == "ik" else 1)
 
     def kernel_name(self):
@@ -218,7 +221,9 @@ class Runner:
         if k == "dyn":
             return f"dyn_kernel<{arm}, {t}, {'true' if ('C' in self.want or 'dJ' in self.want) else 'false'}>"
         if k == "osc_full":
-            return f"osc_full_kernel<{arm}, {t}, 3, {'true' if self.params.use_C else 'false'}, 0>"
+            vel = "C" in self.want or "dJ" in self.want
+            return (f"osc_full_kernel<{arm}, {t}, 3, {'true' if self.params.use_C else 'false'}, {2 if vel else 0}, "
+                    f"{'true' if vel else 'false'}>")
         if k == "limits":
             return f"limits_kernel<{self.n}, {t}>"
         if k == "rollout":
@@ -583,8 +588,10 @@ def cpu_baseline(workload, budget_s=12.0):
         p = _abi.make_obstacles_params(**kw)
         fn = lambda: o.avoid_obstacles_batch(p, q)
     elif kind == "osc_full":
-        p = _abi.make_osc_params(o.n, **kw)
-        fn = lambda: (o.osc_batch(p, q, dq, t), [(o.Tx("EE", q[i]), o.J("EE", q[i]), o.M(q[i]), o.g(q[i])) for i in range(Bs)])
+        p = _abi.make_osc_params(o.n, **{k: v for k, v in kw.items() if k != "want"})
+        withC = "C" in kw.get("want", ())
+        fn = lambda: (o.osc_batch(p, q, dq, t), [(o.Tx("EE", q[i]), o.J("EE", q[i]), o.M(q[i]), o.g(q[i])) +
+                                                 ((o.C(q[i], dq[i]),) if withC else ()) for i in range(Bs)])
     else:
         nulls = [_abi.make_damping(10)] if kind == "osc_damp" else []
         p = _abi.make_osc_params(o.n, null_controllers=nulls, **kw)

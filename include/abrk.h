@@ -160,8 +160,10 @@ int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_params* params
  *   J  [B,6,n] = robot_config.J(ref_frame, q, x=xyz_offset)  (:249-270)
  *   M  [B,n,n] = robot_config.M(q)                            (:272-285)
  *   g  [B,n]   = robot_config.g(q)                            (:210-223)
- * selected by `want` (ABRK_WANT_TX | ABRK_WANT_J | ABRK_WANT_M | ABRK_WANT_G; the other fields of `out` are
- * ignored), in the kernel's arithmetic type.  For callers that read those next to ctrlr.generate - adaptive terms on
+ *   C  [B,n,n] = robot_config.C(q, dq)                        (:320-336)   } the velocity-dependent functions:
+ *   dJ [B,6,n] = robot_config.dJ(ref_frame, q, dq, x=xyz_offset) (:225-247) } +288 B per UR5 row each
+ * selected by `want` (ABRK_WANT_TX | ABRK_WANT_J | ABRK_WANT_M | ABRK_WANT_G | ABRK_WANT_C | ABRK_WANT_DJ; the other
+ * fields of `out` are ignored), in the kernel's arithmetic type.  For callers that read those next to ctrlr.generate - adaptive terms on
  * training_signal, logging, a second controller on the same state (the consumers of osc.py:242-301) - and would
  * otherwise evaluate the kinematics twice.  840 B of algorithmic traffic per UR5 row in fp64: the HBM-bound form of
  * the path (SURVEY.md 8d "Mode F").  Everything else as abrk_osc_generate_batch.                              */

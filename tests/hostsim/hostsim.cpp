@@ -93,16 +93,20 @@ int run_osc_full(const A& arm, int n, const abrk_osc_params* P, int64_t B, const
   o.J = (T*)outs[1];
   o.M = (T*)outs[2];
   o.g = (T*)outs[3];
+  o.C = (T*)outs[4];
+  o.dJ = (T*)outs[5];
+  const bool vel = (want & (W_C | W_DJ)) != 0;
   DirectStore<T> st;
   RegScratch<T, A::N> scr;
   for (long b = 0; b < B; b++) {
-#define FULL(KM, UC, FT)                                                                                            \
-  osc_full_body<A, T, KM, UC, FT>(b, true, st, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, \
-                                  (T*)ie, (const T*)une, (T*)u, (T*)ts, want, o, scr)
-#define FULLF(KM, UC)        \
-  do {                       \
-    if (plain) FULL(KM, UC, 0); \
-    else FULL(KM, UC, 2);    \
+#define FULL(KM, UC, FT, VEL)                                                                                            \
+  osc_full_body<A, T, KM, UC, FT, VEL>(b, true, st, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, \
+                                       (T*)ie, (const T*)une, (T*)u, (T*)ts, want, o, scr)
+#define FULLF(KM, UC)                   \
+  do {                                  \
+    if (vel) FULL(KM, UC, 2, true);     \
+    else if (plain) FULL(KM, UC, 0, false); \
+    else FULL(KM, UC, 2, false);        \
   } while (0)
     if (fast == 3) {
       if (P->use_C) FULLF(3, true); else FULLF(3, false);

@@ -1270,6 +1270,17 @@ def test_gpu_fused_full_outputs_equal_separate_calls(arm, kw, variant):
         # a subset of outputs leaves the others untouched
         only = be.e.osc_generate(be.arm_id, n, p, q, dq, t, dtype=dtype, want=("M",))[1]
         assert list(only) == ["M"] and np.array_equal(only["M"], dyn["M"])
+        # the velocity-dependent robot_config functions too: C(q, dq) and dJ of the same frame / offset
+        allw = ("Tx", "J", "M", "g", "C", "dJ")
+        u2, ts2, dyn2 = be.e.osc_generate(be.arm_id, n, p, q, dq, t, training_signal=True, dtype=dtype, want=allw)
+        ref2 = be.e.dynamics(be.arm_id, n, q, dq, _abi.frame_id(frame, n), off, allw, dtype, 0)
+        assert np.max(np.abs(u2.astype(float) - u0)) <= tol * scale(u0) * 1e3
+        assert np.max(np.abs(ts2.astype(float) - ts0)) <= tol * scale(ts0) * 1e3
+        for k in allw:
+            assert dyn2[k].shape == ref2[k].shape and dyn2[k].dtype == dtype
+            assert np.max(np.abs(dyn2[k].astype(float) - ref2[k])) <= 10 * tol * scale(ref2[k]), (arm, variant, k)
+        cdj = be.e.osc_generate(be.arm_id, n, p, q, dq, t, dtype=dtype, want=("dJ",))[1]
+        assert list(cdj) == ["dJ"] and np.array_equal(cdj["dJ"], dyn2["dJ"])
 
 
 def test_gpu_osc_generate_return_dynamics_python_api():
@@ -1285,6 +1296,13 @@ def test_gpu_osc_generate_return_dynamics_python_api():
     assert np.allclose(dyn["g"], rc.g(q), atol=1e-5) and np.allclose(dyn["Tx"], rc.Tx("EE", q), atol=1e-12)
     u1, d1 = c.generate(q[0], dq[0], t[0], return_dynamics=("M",))
     assert u1.shape == (6,) and d1["M"].shape == (6, 6)
+    # ... and the reference's two most expensive functions from the same launch, against its own outputs
+    g = golden("ur5")
+    qg, dqg = g["dyn_q"], g["dyn_dq"]
+    tg = np.zeros((len(qg), 6))
+    _, d2 = c.generate(qg, dqg, tg, return_dynamics=("C", "dJ"))
+    assert d2["C"].shape == g["C"].shape and np.max(np.abs(d2["C"] - g["C"])) < 1e-5 * max(1, np.abs(g["C"]).max())
+    assert np.max(np.abs(d2["dJ"] - g["dJ_EE"])) < 1e-5 * max(1, np.abs(g["dJ_EE"]).max())
 
 
 # ---------------------------------------------------------------------------- one call over several devices

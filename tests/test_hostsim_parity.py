@@ -399,6 +399,17 @@ def test_rows_fused_full_outputs(arm, kw):
         assert np.allclose(u1, u0, rtol=1e-12, atol=1e-12) and np.allclose(ts1, ts0, rtol=1e-12, atol=1e-12)
         for k in ("Tx", "J", "M", "g"):
             assert np.allclose(dyn[k], ref[k], rtol=1e-13, atol=1e-13), (arm, k)
+        # with the velocity-dependent outputs (C, dJ): the variant whose dynamics pass assembles the Christoffel matrix
+        # and whose Coriolis vector is C dq from it
+        allw = ("Tx", "J", "M", "g", "C", "dJ")
+        u2, ts2, dyn2 = hostsim.osc_generate_full(a, p, q, dq, t, want=allw)
+        ref2 = hostsim.dynamics(a, q, dq, _abi.frame_id(frame, n), off, allw, np.float64)
+        scale = max(1.0, float(np.max(np.abs(u0))))
+        assert np.max(np.abs(u2 - u0)) <= 1e-11 * scale and np.max(np.abs(ts2 - ts0)) <= 1e-11 * scale
+        for k in allw:
+            assert np.allclose(dyn2[k], ref2[k], rtol=1e-12, atol=1e-12), (arm, k)
+        only = hostsim.osc_generate_full(a, p, q, dq, t, want=("C",))[2]
+        assert list(only) == ["C"] and np.allclose(only["C"], ref2["C"], rtol=1e-12, atol=1e-12)
 
 
 def test_rows_direct_sym3_eigensolver():
