@@ -1074,11 +1074,14 @@ struct NoEmit {
 // robot_config outputs" kernel stores them from there (SURVEY 8d Mode F).
 // MAT: the dynamics pass also assembles the full C(q,dq) (base_config.py:678-727) - Mode F with `C` among the outputs;
 // the law's Coriolis vector is then C dq from that matrix instead of the body recursion.
-template <class A, class T, int KM, bool USE_C, int FEAT, bool MAT = false, class Late, class Scr, class Emit = NoEmit>
+// `emit_pre(d)` runs right after the dynamics pass (MAT: the Christoffel matrix leaves for its output array there, so
+// that its N^2 values are not carried through the Jacobian and the law).
+template <class A, class T, int KM, bool USE_C, int FEAT, bool MAT = false, class Late, class Scr, class Emit = NoEmit,
+          class EmitPre = NoEmit>
 ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const T (&dq)[A::N], const T (&tgt)[6],
                       bool tv_given, const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext,
                       const T (&une)[A::N], T (&u)[A::N], T (&ts)[A::N], Late&& late, Scr& scr,
-                      Emit&& emit = Emit{}) {
+                      Emit&& emit = Emit{}, EmitPre&& emit_pre = EmitPre{}) {
   constexpr int N = A::N;
   constexpr bool FAST = (KM <= 3);
   // OSC(use_C) on orthogonal chains (ABRK_C_TWO_PASS): the Coriolis vector rides on the dynamics pass.  The link
@@ -1150,6 +1153,8 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
       cvm[i()] = acc;
     });
   }
+  emit_pre(d);
+  ABRK_SCHED_FENCE();
   // task Jacobian, rows masked (osc.py:242-244)
   if constexpr (FAST) {
     T Jv[N][3], Jw[N][3];

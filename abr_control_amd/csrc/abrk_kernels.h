@@ -265,8 +265,11 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 // Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
 // cooperative stores and (use_C) the scratch of the Coriolis recursion, which is dead by the time the first row is
 // parked.  FEAT is 0 (the plain law) or 2 (every optional input).
+#ifndef ABRK_VEL_WAVES
+#define ABRK_VEL_WAVES ABRK_MIN_WAVES  // measurement switch: 2 caps the C / dJ variant at 256 registers (364-424 B of scratch)
+#endif
 template <class A, class T, int KM, bool USE_C, int FEAT, bool VEL = false>
-__global__ void __launch_bounds__(kBlock, VEL ? ABRK_MIN_WAVES : osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
+__global__ void __launch_bounds__(kBlock, VEL ? (ABRK_VEL_WAVES) : osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
 osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                 const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
                 const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, unsigned want, DynOutP<T> out) {

@@ -238,7 +238,6 @@ ABRK_INL void osc_full_body(long b, bool active, St& st, const A& arm, const Osc
       st.template put<N>(out.g, b, active, row);
     }
     if constexpr (VEL) {
-      if (want & W_C) st.template put<N * N>(out.C, b, active, d.Cm);
       if (want & W_DJ) {
         T dJv[N][3], dJw[N][3];
         jacobian_dot(jt, dq, Jv, m, dJv, dJw);
@@ -253,8 +252,13 @@ ABRK_INL void osc_full_body(long b, bool active, St& st, const A& arm, const Osc
       }
     }
   };
+  auto emit_pre = [&](const auto& d) ABRK_LAMBDA {
+    if constexpr (VEL) {
+      if (want & W_C) st.template put<N * N>(out.C, b, active, d.Cm);
+    }
+  };
   osc_row<A, T, KM, USE_C, FEAT, VEL>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr,
-                                      emit);
+                                      emit, emit_pre);
   if (active) {
     store_row<N>(ug, b, u);
     if (tsg) store_row<N>(tsg, b, ts);
