@@ -328,6 +328,17 @@ extern "C" int abrk_stream_destroy(int device, void* stream) {
 }
 extern "C" int abrk_stream_sync(int device, void* stream) {
   if (int rc = use_device(device)) return rc;
+  // ABRK_SYNC_SPIN=1 (measurement switch): poll the stream instead of blocking in hipStreamSynchronize - whether the
+  // wake-up latency of the blocking wait shows in a 20-step replay (it does not: profiles/round3/launch_latency.txt)
+  static const bool spin = getenv("ABRK_SYNC_SPIN") != nullptr;
+  if (spin) {
+    hipError_t e;
+    while ((e = hipStreamQuery((hipStream_t)stream)) == hipErrorNotReady) {
+    }
+    (void)hipGetLastError();
+    HIPCHK(e);
+    return 0;
+  }
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   return 0;
 }
@@ -1689,9 +1700,8 @@ extern "C" int abrk_plan_launch_graph(int plan, int repeat) {
     if (le != hipSuccess || ce != hipSuccess)
       return fail(ABRK_ENODEV, "graph capture failed: %s", hipGetErrorString(le != hipSuccess ? le : ce));
     HIPCHK(hipGraphInstantiate(&pl->graph_exec, pl->graph, nullptr, nullptr, 0));
-    // stage the executable graph's launch state on the device now, not inside the first launch (a short replay - the
-    // driver's 20 steps - is otherwise charged for it)
-    if (hipGraphUpload(pl->graph_exec, pl->stream) != hipSuccess) (void)hipGetLastError();  // optional: the launch uploads
+    // (hipGraphUpload here was measured in round 3: no change to a 20-step replay - 4.83 us per step of wall clock with
+    //  and without, the graph's first launch is an untimed warm-up anyway - and one more call for rocprofv3 to trip over)
     pl->graph_repeat = repeat;
   }
   HIPCHK(hipGraphLaunch(pl->graph_exec, pl->stream));

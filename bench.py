@@ -256,7 +256,9 @@ class Runner:
         a = self.a
         chunk = max(1, min(64, int(20.0 / max(est_ms, 1e-3))))          # ~20 ms of GPU time per chunk
         n_chunks = max(4, int(np.ceil(seconds * 1e3 / (chunk * est_ms) * 1.15)))  # the limiter slows the run down
-        graph = self.plan is not None and chunk > 1
+        # HBM-sized launches (hundreds of microseconds each) need no graph to keep the stream fed: plain launches from the
+        # recorded plan; only launch-bound kernels (< 50 us) are chunked into hipGraph replays
+        graph = self.plan is not None and chunk > 1 and est_ms < 0.05
         if graph:
             self.plan.launch_graph(chunk)  # builds the graph (untimed)
             self.stream.sync()
