@@ -37,7 +37,9 @@ FP64_VALU_PEAK_TF = 78.6   # = 1/2 of the 157.3 TF fp32 vector peak
 # fp64 (a wave64 v_fma_f64 issues in 4 cycles), x 32 lanes/clk for fp32 (2 cycles; v_pk_* take 4 - no packed gain).
 # Measured by tools/microbench/valu_rates.hip on a short boost-clock run: 36.7 T (fp64), 65.1 T (fp32).
 ISSUE_PEAK_NOMINAL = {"f64": 1024 * 16 * 2.4e9, "f32": 1024 * 32 * 2.4e9}
-PROFILE_DIRS = ("round3", "round2", "round1")  # committed rocprofv3 evidence, newest first
+# committed rocprofv3 evidence.  (Earlier rounds are not consulted: kernel names changed - a template parameter was added -
+# and round 2's traffic.json keyed the grid-stride kernels by grid threads instead of rows.)
+PROFILE_DIRS = ("round3",)
 
 WORKLOADS = {
     # name: (arm, batch per GPU, dtype, kind, params kwargs, algorithmic flops per eval)

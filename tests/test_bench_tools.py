@@ -1,0 +1,77 @@
+"""CPU checks of the measurement tooling: the sustained-rate statistic bench.py quotes as `roofline.frac`, the contract
+fields of its workloads table, and tools/summarize_profiles.py's mapping of a grid-stride kernel's launch back to the
+rows it processed (`traffic.json` was keyed by grid x 64 and made bench_cfg5.json print 2.00 x the
+algorithmic bytes for a kernel that moves exactly the algorithmic bytes)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from tests.conftest import REPO
+
+
+def test_sustained_stats_is_the_mean_of_the_last_second():
+    sys.path.insert(0, REPO)
+    import bench
+
+    # 100 launches per event; 0.4 ms per launch for the first 1.2 s (30 chunks of 40 ms), then 0.5 ms (25 chunks of 50 ms)
+    per = [0.4] * 30 + [0.5] * 25
+    st = bench.sustained_stats(per, 100)
+    assert abs(st["seconds"] - 2.45) < 1e-9 and st["launches"] == 5500
+    assert st["us_per_launch_last_second"] == 500.0 and st["us_per_launch_first_second"] == 400.0
+    assert st["us_per_launch_min_chunk"] == 400.0 and st["us_per_launch_max_chunk"] == 500.0
+    # a run shorter than a second is averaged whole
+    assert bench.sustained_stats([0.3, 0.5], 10)["us_per_launch_last_second"] == 400.0
+
+
+def test_algorithmic_bytes_follow_the_survey():
+    import bench
+
+    assert bench.algorithmic_bytes(6, 8, "osc") == 192 and bench.algorithmic_bytes(2, 8, "osc") == 96  # SURVEY 8d Mode U
+    assert bench.algorithmic_bytes(3, 4, "sliding") == 48
+    assert bench.algorithmic_bytes(6, 8, "osc_full") == 840                                            # Mode F
+    assert bench.algorithmic_bytes(6, 8, "osc_full", ("Tx", "J", "M", "g", "C")) == 840 + 288
+    assert bench.algorithmic_bytes(6, 8, "osc_full", ("Tx", "J", "M", "g", "C", "dJ")) == 840 + 576
+    assert bench.algorithmic_bytes(6, 8, "dyn", ("Tx", "J", "M", "g")) == 696
+
+
+def test_summarize_profiles_keys_grid_stride_kernels_by_rows(tmp_path):
+    src, dst = tmp_path / "run", tmp_path / "out"
+    (src / "pmc_FETCH_SIZE").mkdir(parents=True)
+    (src / "pmc_WRITE_SIZE").mkdir()
+    kn = "void abrk::sliding_kernel<abrk::StaticArm<abrk::Tab_threejoint>, float>(abrk::StaticArm<abrk::Tab_threejoint>, ...)"
+    rows, grid = 8388608, 256 * 32 * 4 * 64  # the launcher caps the grid at kSlidingMaxBlocks: 2 097 152 threads
+    hdr = "Kernel_Name,Grid_Size,Counter_Name,Counter_Value,VGPR_Count,Accum_VGPR_Count,Scratch_Size,LDS_Block_Size\n"
+    # 36 B read + 12 B written per row = algorithmic (FETCH_SIZE counts 64 B per 128-B request on gfx950, in KiB)
+    (src / "pmc_FETCH_SIZE" / "bench_counter_collection.csv").write_text(
+        hdr + f'"{kn}",{grid},FETCH_SIZE,{rows * 36 / 2 / 1024},68,0,0,1024\n')
+    (src / "pmc_WRITE_SIZE" / "bench_counter_collection.csv").write_text(
+        hdr + f'"{kn}",{grid},WRITE_SIZE,{rows * 12 / 1024},68,0,0,1024\n')
+    leg = {"kernel": "sliding_kernel<abrk::StaticArm<abrk::Tab_threejoint>, float>", "grid_threads": grid, "batch": rows,
+           "bytes_per_eval": 48, "us_per_launch": 100.0, "frac": 0.5}
+    (src / "pmc_FETCH_SIZE.log").write_text("noise\n" + json.dumps({"roofline": leg}) + "\n")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "tools", "summarize_profiles.py"), str(src), str(dst)],
+                       capture_output=True, text=True, env=dict(os.environ, ABRK_PROFILE_COMMIT="test"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    t = json.load(open(dst / "traffic.json"))
+    key = f"sliding_kernel<abrk::StaticArm<abrk::Tab_threejoint>,float>:{rows}"
+    assert key in t and t[key]["grid_threads"] == grid
+    assert np.isclose(t[key]["read_bytes"] + t[key]["write_bytes"], 48 * rows)
+    # what bench.py then prints for that leg: traffic / algorithmic = 1.00
+    sys.path.insert(0, REPO)
+    import bench
+
+    old = bench.PROFILE_DIRS
+    try:
+        os.makedirs(os.path.join(REPO, "profiles", "_test_tmp"), exist_ok=True)
+        json.dump(t, open(os.path.join(REPO, "profiles", "_test_tmp", "traffic.json"), "w"))
+        bench.PROFILE_DIRS = ("_test_tmp",)
+        traffic, _, commit = bench.profiled_traffic(leg["kernel"], rows)
+        assert commit == "test" and np.isclose(traffic, 48 * rows)
+    finally:
+        bench.PROFILE_DIRS = old
+        import shutil
+
+        shutil.rmtree(os.path.join(REPO, "profiles", "_test_tmp"), ignore_errors=True)

@@ -64,7 +64,7 @@ def rows_for(kernel, grid):
             return max(big)
     return int(grid)
 lines = ["# rocprofv3 evidence (MI355X, ROCm 7.2)", "",
-         "Commands: `tools/gpu_profiles.sh` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
+         "Commands: `tools/gpu_profiles_r3.sh` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
          "`--pmc` passes as MI355X_MICROARCH.md prescribes).  `FETCH_SIZE`/`WRITE_SIZE` are in KiB; on gfx950 "
          "FETCH_SIZE counts 64 B per 128-B request, so read bytes = FETCH_SIZE x 1024 x 2.", ""]
 for f in ("pytest_gpu.log", "smoke.log", "coop_ab.md", "rt_ab.md", "valu_rates.txt"):
@@ -95,7 +95,9 @@ if os.path.exists(ks):
     # the figure every bench JSON's `roofline.frac` must reproduce: algorithmic bytes x rows / trace mean / 8 TB/s
     legs = {}
     for f in sorted(os.listdir(src)):
-        if f.endswith((".log", ".json")):
+        # (the bench lines of the PMC passes are left out: counter collection serialises the launches and their short
+        #  runs are not the sustained protocol)
+        if f.endswith((".log", ".json")) and not f.startswith("pmc_"):
             for leg in legs_of(os.path.join(src, f)):
                 if leg["batch"] >= (1 << 20) and "bytes_per_eval" in leg:
                     legs.setdefault((norm(leg["kernel"]), int(leg["grid_threads"])), []).append((f, leg))
