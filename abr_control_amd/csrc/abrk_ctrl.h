@@ -199,18 +199,24 @@ ABRK_INL T jacobi_tan(T num, T den) {
 template <int K, class T>
 ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
   sfor<K>([&](auto i) ABRK_LAMBDA { sfor<K>([&](auto j) ABRK_LAMBDA { V[i()][j()] = (i() == j()) ? T(1) : T(0); }); });
+  // A rotation is applied while |a_pq| > eps sqrt(|a_pp a_qq|) (the relative criterion of Demmel & Veselic: what is
+  // left below it perturbs every eigenvalue - small ones included - by a few eps of itself) or, where a diagonal entry
+  // is itself rounding noise of a singular matrix, while |a_pq| > eps^2 |A|; a sweep that applies none ends the
+  // iteration.  (Until round 3 every non-zero a_pq was rotated until the off-diagonal mass fell below 1e-18 |A|: one to
+  // two sweeps of rotations by angles ~1e-17 that change nothing - on a lone lane, i.e. at the price of the whole
+  // wavefront's time.)
+  T dg0 = T(0);
+  sfor<K>([&](auto p) ABRK_LAMBDA { dg0 += S[tri(p(), p())] * S[tri(p(), p())]; });
+  const T floor2 = Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * dg0;  // (eps^2 |A|)^2
   for (int sweep = 0; sweep < 30; sweep++) {
-    T off = T(0), dg = T(0);
-    sfor<K>([&](auto p) ABRK_LAMBDA {
-      dg += S[tri(p(), p())] * S[tri(p(), p())];
-      sfor<p()>([&](auto q) ABRK_LAMBDA { off += S[tri(p(), q())] * S[tri(p(), q())]; });
-    });
-    if (!(off > Rm<T>::eps() * Rm<T>::eps() * T(1e-4) * dg)) break;
+    bool rotated = false;
     sfor<K>([&](auto qq) ABRK_LAMBDA {
       sfor<qq()>([&](auto pp) ABRK_LAMBDA {
         constexpr int p = pp(), q = qq();  // p < q
         T apq = S[tri(q, p)];
-        if (apq != T(0)) {
+        const T a2 = apq * apq;
+        if (a2 > Rm<T>::eps() * Rm<T>::eps() * Rm<T>::fabs(S[tri(p, p)] * S[tri(q, q)]) && a2 > floor2) {
+          rotated = true;
           T t = jacobi_tan(S[tri(q, q)] - S[tri(p, p)], T(2) * apq);
           T c = Rm<T>::rsqrt(t * t + T(1));
           T s = t * c;
@@ -232,6 +238,7 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
         }
       });
     });
+    if (!rotated) break;
   }
   sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = S[tri(i(), i())]; });
 }
