@@ -243,6 +243,155 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
   sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = S[tri(i(), i())]; });
 }
 
+// Eigen-decomposition of a symmetric K x K matrix by Householder tridiagonalisation and the implicit QL iteration
+// (the EISPACK tred2 / tql2 pair, restated with every index a compile-time constant: the matrices live in registers,
+// and run-time indexing would send them to scratch memory).  Same interface as jacobi_eig; the eigenpairs come out in
+// no particular order.  Why it is here: the truncating pinv of the six-row OSC law (osc.py:145) is rare per row (4.6 %
+// of random UR5 states) but runs on a lone lane while its 63 neighbours wait, so its LATENCY is the config-sized
+// step's critical path.  Cyclic Jacobi on a 6 x 6 matrix is ~6 sweeps x 15 rotations x ~75 instructions; this is ~400
+// for the reduction and ~65 per QL rotation, ~2 iterations per eigenvalue on blocks that shrink as eigenvalues deflate.
+// The predicated static unrolling executes every rotation slot of the active block (i >= m slots are skipped by the
+// execution mask), so the cost is (K - 1 - l) slots per iteration for eigenvalue l.
+// Accuracy: backward stable - eigenvalues to a few eps |A|, eigenvectors orthonormal to a few eps (jacobi_eig's
+// RELATIVE accuracy on tiny eigenvalues is not needed by its callers: eigenvalues below rcond * max are dropped, the
+// kept ones are at least 1e-4 |A|).
+template <int K, class T>
+ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
+  static_assert(K >= 3, "two rows: one Jacobi rotation is exact");
+  T a[K][K];
+  sfor<K>([&](auto i) ABRK_LAMBDA {
+    sfor<K>([&](auto j) ABRK_LAMBDA {
+      a[i()][j()] = S[tri(i(), j())];
+      V[i()][j()] = (i() == j()) ? T(1) : T(0);
+    });
+  });
+  T d[K], e[K];
+  sfor<K>([&](auto i) ABRK_LAMBDA { e[i()] = T(0); });
+  // ---- Householder: A <- H_k A H_k, H_k = I - beta v v^T acting on rows / columns k+1 .. K-1;  V <- V H_k
+  sfor<K - 2>([&](auto kc) ABRK_LAMBDA {
+    constexpr int k = kc(), m0 = k + 1, M = K - m0;  // the block that is transformed: indices m0 .. K-1 (M of them)
+    T x0 = a[m0][k];
+    T sigma2 = T(0);
+    sfor<M - 1>([&](auto j) ABRK_LAMBDA { sigma2 = Rm<T>::fma(a[m0 + 1 + j()][k], a[m0 + 1 + j()][k], sigma2); });
+    T alpha = x0;  // the new sub-diagonal entry
+    // nothing below the sub-diagonal (to rounding): the column is already tridiagonal
+    if (sigma2 > Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * (x0 * x0 + sigma2) && sigma2 > Rm<T>::tiny()) {
+      const T n2 = Rm<T>::fma(x0, x0, sigma2);
+      const T nrm = n2 * Rm<T>::rsqrt(n2);
+      alpha = x0 >= T(0) ? -nrm : nrm;
+      T v[M];
+      v[0] = x0 - alpha;
+      sfor<M - 1>([&](auto j) ABRK_LAMBDA { v[1 + j()] = a[m0 + 1 + j()][k]; });
+      const T vtv = Rm<T>::fma(v[0], v[0], sigma2);
+      const T beta = T(2) * Rm<T>::rcp(vtv);
+      T pv[M], kk = T(0);
+      sfor<M>([&](auto i) ABRK_LAMBDA {
+        T acc = T(-0.0);
+        sfor<M>([&](auto j) ABRK_LAMBDA { acc = Rm<T>::fma(a[m0 + i()][m0 + j()], v[j()], acc); });
+        pv[i()] = beta * acc;
+        kk = Rm<T>::fma(pv[i()], v[i()], kk);
+      });
+      kk *= T(0.5) * beta;
+      sfor<M>([&](auto i) ABRK_LAMBDA { pv[i()] = Rm<T>::fma(-kk, v[i()], pv[i()]); });  // q = p - (beta/2)(p.v) v
+      sfor<M>([&](auto i) ABRK_LAMBDA {
+        sfor<i() + 1>([&](auto j) ABRK_LAMBDA {
+          const T nv = a[m0 + i()][m0 + j()] - v[i()] * pv[j()] - pv[i()] * v[j()];
+          a[m0 + i()][m0 + j()] = nv;
+          a[m0 + j()][m0 + i()] = nv;
+        });
+      });
+      // V <- V H (row 0 of V is e_0 throughout: the reflectors never touch index 0)
+      sfor<K - 1>([&](auto rr) ABRK_LAMBDA {
+        constexpr int r = rr() + 1;
+        T sdot = T(-0.0);
+        sfor<M>([&](auto j) ABRK_LAMBDA { sdot = Rm<T>::fma(V[r][m0 + j()], v[j()], sdot); });
+        sdot *= beta;
+        sfor<M>([&](auto j) ABRK_LAMBDA { V[r][m0 + j()] = Rm<T>::fma(-sdot, v[j()], V[r][m0 + j()]); });
+      });
+    }
+    e[k] = alpha;
+  });
+  e[K - 2] = a[K - 1][K - 2];
+  sfor<K>([&](auto i) ABRK_LAMBDA { d[i()] = a[i()][i()]; });
+  // ---- implicit QL with Wilkinson shift on (d, e): e[i] couples i and i + 1
+  sfor<K>([&](auto lc) ABRK_LAMBDA {
+    constexpr int l = lc();
+    if constexpr (l < K - 1) {
+      for (int iter = 0; iter < 40; iter++) {
+        // smallest m >= l whose coupling e[m] is negligible (m = K - 1: none)
+        int m = K - 1;
+        sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
+          constexpr int j = K - 2 - jj();  // K-2 .. l
+          const T dd = Rm<T>::fabs(d[j]) + Rm<T>::fabs(d[j + 1]);
+          if (!(Rm<T>::fabs(e[j]) > Rm<T>::eps() * dd)) m = j;
+        });
+        if (m == l) break;
+        T g = (d[l + 1] - d[l]) * T(0.5) * Rm<T>::rcp(e[l] == T(0) ? T(1) : e[l]);
+        {
+          const T r2 = Rm<T>::fma(g, g, T(1));
+          const T r = r2 * Rm<T>::rsqrt(r2);
+          const T den = g + (g >= T(0) ? r : -r);
+          // d[m] - d[l] + e[l] / (g + sign(r, g)); m is a run-time index: select
+          T dm = d[K - 1];
+          sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
+            constexpr int j = l + jj();
+            dm = (m == j) ? d[j] : dm;
+          });
+          g = dm - d[l] + e[l] * Rm<T>::rcp(den);
+        }
+        T sn = T(1), cs = T(1), pp = T(0);
+        bool stop = false;  // a zero rotation radius ends the pass early (tql2's recovery from underflow)
+        sfor<K - 1 - l>([&](auto ii) ABRK_LAMBDA {
+          constexpr int i = K - 2 - ii();  // K-2 .. l
+          if (i < m && !stop) {
+            const T f = sn * e[i], b = cs * e[i];
+            const T r2 = Rm<T>::fma(f, f, g * g);
+            if (!(r2 > T(0))) {
+              d[i + 1] -= pp;
+              stop = true;
+            } else {
+              const T ir = Rm<T>::rsqrt(r2), r = r2 * ir;
+              if constexpr (i + 1 < K - 1) e[i + 1] = r;  // (i + 1 == m <= K - 1: e[K-1] does not exist and is not needed)
+              sn = f * ir;
+              cs = g * ir;
+              g = d[i + 1] - pp;
+              const T rr = Rm<T>::fma(d[i] - g, sn, T(2) * cs * b);
+              pp = sn * rr;
+              d[i + 1] = g + pp;
+              g = Rm<T>::fma(cs, rr, -b);
+              sfor<K>([&](auto kk) ABRK_LAMBDA {
+                const T fz = V[kk()][i + 1];
+                V[kk()][i + 1] = Rm<T>::fma(sn, V[kk()][i], cs * fz);
+                V[kk()][i] = Rm<T>::fma(cs, V[kk()][i], -(sn * fz));
+              });
+            }
+          }
+        });
+        // e[m] = 0 in either case
+        sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
+          constexpr int j = l + jj();
+          if (m == j) e[j] = T(0);
+        });
+        if (!stop) {
+          d[l] -= pp;
+          e[l] = g;
+        }
+      }
+    }
+  });
+  sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = d[i()]; });
+}
+
+#ifndef ABRK_EIG_QL
+#define ABRK_EIG_QL 1  // 0: cyclic Jacobi for every size (rounds 1-2)
+#endif
+// eigen-decomposition behind a truncating pinv: Jacobi up to 3 x 3 (one / three rotation pairs), QL above
+template <int K, class T>
+ABRK_INL void sym_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
+  if constexpr (K >= 4 && (ABRK_EIG_QL != 0)) ql_eig<K>(S, V, lam);
+  else jacobi_eig<K>(S, V, lam);
+}
+
 // Direct eigen-decomposition of a symmetric 3 x 3 matrix (packed lower in) - no sweeps, no data-dependent trip
 // count, so the lanes of a wavefront stay together (AvoidObstacles runs one truncated pinv per near segment-obstacle
 // pair; with the Jacobi sweeps that was ~12.7 k vector instructions per row).  The hybrid of the closed form and one
@@ -966,7 +1115,8 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   bool okA = chol<KM>(Am, LA, ila);
   T det = T(1);
   sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
-  bool mx_explicit = FEAT != 0;
+  bool mx_explicit = FEAT != 0, f_ready = false;
+  T f[KM], f2[FEAT >= 1 ? KM : 1];
   if constexpr (FEAT != 0) chol_inverse<KM>(LA, ila, Mx);
   const T thr = T(1e-3), rcond = T(1e-3) * T(0.1);
   if (!(okA && det >= thr)) {
@@ -1001,31 +1151,49 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     if constexpr (!Rows::kDeferOnly) if (truncates) {
       T S[KM * (KM + 1) / 2], V[KM][KM], lam[KM];
       sfor<KM*(KM + 1) / 2>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
-      jacobi_eig<KM>(S, V, lam);
+      // a masked row is an isolated diagonal entry: with 0 there its eigenpair is (0, e_r) - below every cut-off, so it
+      // drops out of the pseudo-inverse whatever position the solver leaves it in (ql_eig orders nothing)
+      sfor<KM>([&](auto r) ABRK_LAMBDA { S[tri(r(), r())] = sel[r()] ? S[tri(r(), r())] : T(0); });
+      sym_eig<KM>(S, V, lam);
       T smax = T(0);
-      sfor<KM>([&](auto r) ABRK_LAMBDA {
-        bool mine = sel[r()];  // a masked row is an isolated unit diagonal: Jacobi never rotates it (see osc_law)
-        lam[r()] = mine ? lam[r()] : T(0);
-        smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()]));
-      });
+      sfor<KM>([&](auto r) ABRK_LAMBDA { smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()])); });
       T cut = rcond * smax;
       T wv[KM];
-      sfor<KM>([&](auto r) ABRK_LAMBDA { wv[r()] = (Rm<T>::fabs(lam[r()]) > cut) ? rcp(lam[r()]) : T(0); });
-      sfor<KM>([&](auto a) ABRK_LAMBDA {
-        sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
-          T acc = T(-0.0);
-          sfor<KM>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
-          Mx[tri(a(), b())] = acc;
-        });
+      sfor<KM>([&](auto r) ABRK_LAMBDA {
+        const bool keep = Rm<T>::fabs(lam[r()]) > cut;
+        wv[r()] = keep ? rcp(keep ? lam[r()] : T(1)) : T(0);
       });
-      mx_explicit = true;
+      if constexpr (FEAT == 0) {
+        // Mx is applied once: f = V W V^T u_task without forming V W V^T (78 instead of 288 multiply-adds)
+        T tv[KM];
+        sfor<KM>([&](auto r) ABRK_LAMBDA {
+          T acc = T(-0.0);
+          sfor<KM>([&](auto a) ABRK_LAMBDA { acc = Rm<T>::fma(V[a()][r()], uts[a()], acc); });
+          tv[r()] = acc * wv[r()];
+        });
+        sfor<KM>([&](auto a) ABRK_LAMBDA {
+          T acc = T(-0.0);
+          sfor<KM>([&](auto r) ABRK_LAMBDA { acc = Rm<T>::fma(V[a()][r()], tv[r()], acc); });
+          f[a()] = acc;
+        });
+        f_ready = true;
+      } else {
+        sfor<KM>([&](auto a) ABRK_LAMBDA {
+          sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
+            T acc = T(-0.0);
+            sfor<KM>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
+            Mx[tri(a(), b())] = acc;
+          });
+        });
+        mx_explicit = true;
+      }
     }
   }
 
   ABRK_MARK("law6:f");
   // f = Mx u_task[ctrlr_dof] (osc.py:285-288); f2 = Mx (J v) for the null-space filter
-  T f[KM], f2[FEAT >= 1 ? KM : 1];
-  if (mx_explicit) {
+  if (f_ready) {
+  } else if (mx_explicit) {
     symv<KM>(Mx, uts, f);
   } else {
     T y[KM];
@@ -1768,12 +1936,10 @@ ABRK_INL void mx_row(const T (&Ms)[N * (N + 1) / 2], const T (&Jin)[N][6], int k
   } else {  // osc.py:142-145: pinv(rcond = 0.1 threshold) of a symmetric positive semi-definite matrix
     T S[21], V[6][6], lam[6];
     sfor<21>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
-    jacobi_eig<6>(S, V, lam);
+    sfor<6>([&](auto r) ABRK_LAMBDA { S[tri(r(), r())] = sel[r()] ? S[tri(r(), r())] : T(0); });  // masked rows: eigenvalue 0
+    sym_eig<6>(S, V, lam);
     T smax = T(0);
-    sfor<6>([&](auto r) ABRK_LAMBDA {
-      lam[r()] = sel[r()] ? lam[r()] : T(0);  // Jacobi never rotates an isolated unit diagonal: eigenpair r = (1, e_r)
-      smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()]));
-    });
+    sfor<6>([&](auto r) ABRK_LAMBDA { smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()])); });
     const T cut = T(0.1) * thr * smax;
     T wv[6];
     sfor<6>([&](auto r) ABRK_LAMBDA {

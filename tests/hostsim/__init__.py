@@ -225,6 +225,16 @@ def osc_mx(n, M, J, threshold=1e-3, dtype=np.float64):
     return Mx, Minv
 
 
+def sym6_eig(A, method):
+    """the device code's 6 x 6 symmetric eigen-solvers (abrk_ctrl.h): method 0 `jacobi_eig`, 1 `ql_eig` -> (lam [B,6], V [B,6,6])"""
+    A = _in(A, np.dtype(np.float64))
+    B = A.shape[0]
+    lam, V = np.full((B, 6), np.nan), np.full((B, 6, 6), np.nan)
+    rc = _lib_for(law=True).hostsim_sym6_eig(int(method), C.c_int64(B), _p(A), _p(lam), _p(V))
+    assert rc == 0, rc
+    return lam, V
+
+
 def sym3_eig(A, dtype=np.float64):
     """the device code's direct symmetric 3x3 eigen-solver (abrk_ctrl.h `sym3_eig`): -> (lam [B,3], V [B,3,3])"""
     dt = np.dtype(dtype)

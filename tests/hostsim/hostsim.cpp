@@ -291,6 +291,21 @@ extern "C" int hostsim_osc_mx(int n, int k, int dtype, int64_t B, const void* M,
   return -1;
 }
 // the direct symmetric 3x3 eigen-solver on its own (A: [B,3,3] symmetric; lam [B,3], V [B,3,3] columns = eigenvectors)
+// the 6 x 6 eigen-solvers behind the six-row law's truncating pinv: method 0 = cyclic Jacobi, 1 = Householder + QL
+extern "C" int hostsim_sym6_eig(int method, int64_t B, const double* A, double* lam, double* V) {
+  for (long b = 0; b < B; b++) {
+    double S[21], Vv[6][6], l[6];
+    for (int r = 0; r < 6; r++)
+      for (int c = 0; c <= r; c++) S[tri(r, c)] = A[b * 36 + r * 6 + c];
+    if (method == 0) jacobi_eig<6, double>(S, Vv, l);
+    else ql_eig<6, double>(S, Vv, l);
+    for (int r = 0; r < 6; r++) {
+      lam[b * 6 + r] = l[r];
+      for (int c = 0; c < 6; c++) V[b * 36 + r * 6 + c] = Vv[r][c];
+    }
+  }
+  return 0;
+}
 extern "C" int hostsim_sym3_eig(int dtype, int64_t B, const void* A, void* lam, void* V) {
   auto run = [&](auto tag) {
     using T = decltype(tag);

@@ -412,6 +412,56 @@ def test_rows_fused_full_outputs(arm, kw):
         assert list(only) == ["C"] and np.allclose(only["C"], ref2["C"], rtol=1e-12, atol=1e-12)
 
 
+def test_rows_six_by_six_eigensolvers():
+    """abrk_ctrl.h `ql_eig` (Householder tridiagonalisation + implicit QL, every index a compile-time constant) - what
+    the six-row OSC law's truncating pinv runs on since round 3 - and `jacobi_eig` (the cyclic Jacobi it replaced there,
+    still used up to 3 x 3) against numpy.linalg.eigh / pinv(rcond=1e-4) on the matrices that break eigen-solvers:
+    spectra graded over ten decades, multiples of the identity, rank 1 / 3 / 4, clustered pairs, one eigenvalue at
+    rounding level, indefinite matrices, isolated zero rows (what the law passes for unselected task rows), diagonal
+    and zero input."""
+    from tests import hostsim
+
+    rng = np.random.RandomState(3)
+    mats = []
+    for trial in range(6000):
+        kind = trial % 10
+        Q, _ = np.linalg.qr(rng.randn(6, 6))
+        lam = {0: lambda: 10 ** rng.uniform(-8, 2, 6), 1: lambda: np.ones(6) * rng.uniform(.1, 10),
+               2: lambda: np.r_[rng.uniform(.5, 2, 3), 0, 0, 0], 3: lambda: np.r_[rng.uniform(.5, 2, 1), np.zeros(5)],
+               4: lambda: np.r_[1.0, 1.0 + 1e-9, rng.uniform(0.1, 1, 4)],
+               5: lambda: np.r_[rng.uniform(1, 2, 5), 10 ** rng.uniform(-16, -6)], 6: lambda: rng.uniform(-1, 1, 6),
+               7: lambda: 10 ** rng.uniform(-3, 3, 6), 8: lambda: np.r_[10 ** rng.uniform(-2, 2, 4), 0, 0],
+               9: lambda: 10 ** rng.uniform(-5, 0, 6)}[kind]()
+        A = (Q * lam) @ Q.T
+        if kind == 8:
+            B4 = rng.randn(4, 4)
+            A = np.zeros((6, 6))
+            A[np.ix_([0, 2, 3, 5], [0, 2, 3, 5])] = B4 @ B4.T
+        if kind == 1 and trial % 20 == 1:
+            A = np.diag(10 ** rng.uniform(-3, 3, 6))
+        if kind == 3 and trial % 20 == 3:
+            A = np.zeros((6, 6))
+        mats.append((A + A.T) / 2)
+    A = np.array(mats)
+    ref = np.linalg.eigvalsh(A)
+    nrm = np.maximum(np.abs(ref).max(axis=1), 1e-300)
+    ratio = np.abs(ref) / nrm[:, None]
+    off_band = ~(np.abs(ratio - 1e-4) < 1e-9).any(axis=1)
+    Pn = np.array([np.linalg.pinv(a, rcond=1e-4, hermitian=True) for a in A])
+    for method in (0, 1):
+        lam, V = hostsim.sym6_eig(A, method)
+        assert np.isfinite(lam).all() and np.isfinite(V).all()
+        assert (np.abs(A @ V - V * lam[:, None, :]).max(axis=(1, 2)) / nrm).max() < 1e-14
+        assert np.abs(np.einsum("bki,bkj->bij", V, V) - np.eye(6)).max() < 2e-14
+        assert (np.abs(np.sort(lam, axis=1) - ref).max(axis=1) / nrm).max() < 1e-14
+        # the truncated pseudo-inverse as osc_law6 / mx_row assemble it
+        keep = np.abs(lam) > 1e-4 * np.abs(lam).max(axis=1, keepdims=True)
+        w = np.where(keep, 1 / np.where(keep, lam, 1), 0)
+        P = np.einsum("bai,bci,bi->bac", V, V, w)
+        err = np.abs(P - Pn).max(axis=(1, 2)) / np.maximum(np.abs(Pn).max(axis=(1, 2)), 1e-300)
+        assert err[off_band].max() < 1e-9, (method, err[off_band].max())
+
+
 def test_rows_direct_sym3_eigensolver():
     """abrk_ctrl.h `sym3_eig` (the sweep-free eigen-decomposition behind AvoidObstacles' truncated pinv) against
     numpy.linalg.eigvalsh / pinv on the matrices that break closed forms: rank 1 and rank 2 (what the first two
