@@ -255,6 +255,9 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
 // Accuracy: backward stable - eigenvalues to a few eps |A|, eigenvectors orthonormal to a few eps (jacobi_eig's
 // RELATIVE accuracy on tiny eigenvalues is not needed by its callers: eigenvalues below rcond * max are dropped, the
 // kept ones are at least 1e-4 |A|).
+#ifndef ABRK_QL_BRANCHFREE
+#define ABRK_QL_BRANCHFREE 1
+#endif
 template <int K, class T>
 ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
   static_assert(K >= 3, "two rows: one Jacobi rotation is exact");
@@ -341,6 +344,38 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
         }
         T sn = T(1), cs = T(1), pp = T(0);
         bool stop = false;  // a zero rotation radius ends the pass early (tql2's recovery from underflow)
+#if ABRK_QL_BRANCHFREE
+        // Every slot K-2 .. l is executed by every lane, inactive ones (i >= m, or after a stop) as the identity
+        // rotation: the pass is ONE basic block, so the six independent eigenvector updates of a slot overlap with the
+        // next slot's scalar recurrence (a lone lane is latency-bound: with a branch per slot nothing overlapped)
+        sfor<K - 1 - l>([&](auto ii) ABRK_LAMBDA {
+          constexpr int i = K - 2 - ii();  // K-2 .. l
+          const bool act = (i < m) && !stop;
+          const T f = sn * e[i], b = cs * e[i];
+          const T r2 = Rm<T>::fma(f, f, g * g);
+          const bool zero = !(r2 > T(0));
+          const bool go = act && !zero;
+          d[i + 1] = (act && zero) ? d[i + 1] - pp : d[i + 1];
+          stop = stop || (act && zero);
+          const T ir = Rm<T>::rsqrt(go ? r2 : T(1)), r = r2 * ir;
+          const T sn_n = f * ir, cs_n = g * ir;
+          const T g1 = d[i + 1] - pp;
+          const T rr = Rm<T>::fma(d[i] - g1, sn_n, T(2) * cs_n * b);
+          const T pp_n = sn_n * rr;
+          e[i + 1] = go ? r : e[i + 1];
+          d[i + 1] = go ? g1 + pp_n : d[i + 1];
+          g = go ? Rm<T>::fma(cs_n, rr, -b) : g;
+          sn = go ? sn_n : sn;
+          cs = go ? cs_n : cs;
+          pp = go ? pp_n : pp;
+          const T se = go ? sn_n : T(0), ce = go ? cs_n : T(1);
+          sfor<K>([&](auto kk) ABRK_LAMBDA {
+            const T fz = V[kk()][i + 1];
+            V[kk()][i + 1] = Rm<T>::fma(se, V[kk()][i], ce * fz);
+            V[kk()][i] = Rm<T>::fma(ce, V[kk()][i], -(se * fz));
+          });
+        });
+#else
         sfor<K - 1 - l>([&](auto ii) ABRK_LAMBDA {
           constexpr int i = K - 2 - ii();  // K-2 .. l
           if (i < m && !stop) {
@@ -351,7 +386,7 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
               stop = true;
             } else {
               const T ir = Rm<T>::rsqrt(r2), r = r2 * ir;
-              if constexpr (i + 1 < K - 1) e[i + 1] = r;  // (i + 1 == m <= K - 1: e[K-1] does not exist and is not needed)
+              e[i + 1] = r;
               sn = f * ir;
               cs = g * ir;
               g = d[i + 1] - pp;
@@ -367,6 +402,7 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
             }
           }
         });
+#endif
         // e[m] = 0 in either case
         sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
           constexpr int j = l + jj();
