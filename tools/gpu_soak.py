@@ -67,6 +67,21 @@ while time.time() - t4 < min(30.0, budget * 0.15):
             assert np.max(np.abs(dyn[k] - ref[k])) <= 1e-12 * max(1.0, np.max(np.abs(ref[k]))), k
         fin = np.isfinite(u_c[:3000]).all(axis=1) & np.isfinite(u1).all(axis=1)
         assert np.max(np.abs(u1[fin] - u_c[:3000][fin])) <= 1e-9 * max(1.0, np.max(np.abs(u_c[:3000][fin]))), "fused u"
+        # round 3: the velocity-dependent outputs from the fused kernel, and the one-call-every-device entry points
+        allw = ("Tx", "J", "M", "g", "C", "dJ")
+        u2, _, dyn2 = be.e.osc_generate(be.arm_id, n, p, q[:3000], dq[:3000], t[:3000], training_signal=True, want=allw)
+        ref2 = be.e.dynamics(be.arm_id, n, q[:3000], dq[:3000], _abi.frame_id("EE", n), None, allw, np.float64, 0)
+        for k in allw:
+            assert np.max(np.abs(dyn2[k] - ref2[k])) <= 1e-11 * max(1.0, np.max(np.abs(ref2[k]))), "VEL " + k
+        fin2 = fin & np.isfinite(u2).all(axis=1)
+        assert np.max(np.abs(u2[fin2] - u_c[:3000][fin2])) <= 1e-8 * max(1.0, np.max(np.abs(u_c[:3000][fin2]))), "VEL u"
+        devs = [0] * int(rng.randint(1, 6))
+        ds = be.e.dynamics_sharded(be.arm_id, n, q[:3000], devs, dq[:3000], _abi.frame_id("EE", n), None, allw)
+        assert all(np.array_equal(ds[k], ref2[k], equal_nan=True) for k in allw), "sharded dynamics"
+        ps = _abi.make_sliding_params(n)
+        us = be.e.sliding_generate(be.arm_id, n, ps, q[:3000], dq[:3000], t[:3000, :3])
+        assert np.array_equal(be.e.sliding_generate_sharded(be.arm_id, n, ps, q[:3000], dq[:3000], t[:3000, :3], devs), us,
+                              equal_nan=True), "sharded sliding"
     except Exception as e:  # noqa: BLE001
         fails.append(("deferred/fused", s4, n, repr(e)[:300]))
     n_def += 1
