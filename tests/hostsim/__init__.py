@@ -30,7 +30,8 @@ def _so(part):
 def build(force=False):
     srcs = [os.path.join(_HERE, "hostsim.cpp")] + [
         os.path.join(_CSRC, f)
-        for f in ("abrk_device.h", "abrk_ctrl.h", "abrk_rows.h", "abrk_params.h", "abrk_rt.h", "abrk_arms_builtin.h")]
+        for f in ("abrk_device.h", "abrk_ctrl.h", "abrk_rows.h", "abrk_params.h", "abrk_rt.h", "abrk_arms_builtin.h",
+                  "abrk_sincos_table.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     procs = []
     for part, defs in PARTS.items():
