@@ -1082,6 +1082,10 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   }
   T uts[KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
+  // no training signal wanted (osc.py:297 is the only reader of u before gravity): u0 takes the gravity term now
+  if constexpr (Rows::kNoTs) {
+    if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u0[i()] = Rm<T>::fma(gscale, gz[i()], u0[i()]); });
+  }
 
   // secondary controllers (osc.py:310-318): v with u_null = M v, and un = M v while M is at hand
   const bool nulls = FEAT >= 1 && (P.n_null > 0 || (FEAT >= 2 && have_ext));
@@ -1264,8 +1268,10 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   });
   sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = u0[i()] - a1[i()]; });
   if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= cvec[i()]; });  // osc.py:291-292
-  sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297
-  if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gscale, gz[i()], u[i()]); });  // osc.py:300-301
+  sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297 (kNoTs: not stored)
+  if constexpr (!Rows::kNoTs) {
+    if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gscale, gz[i()], u[i()]); });  // osc.py:300-301
+  }
   if constexpr (FEAT >= 1) {
     if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += un[i()] - a2[i()]; });
   }

@@ -891,6 +891,10 @@ struct ScratchBase {
   // true in the first pass of the six-row kernels (DeferOnly below): the row program is compiled WITHOUT the eigen-
   // decomposition - a row that needs it is always deferred - so its registers do not weigh on the two-wave budget
   static constexpr bool kDeferOnly = false;
+  // true where the caller asked for no training signal (NoTs below): the six-row law then folds the gravity term into
+  // its velocity term BEFORE the factorisations - six values fewer to carry through them, which is what the first
+  // pass's 256-register budget was short of (it spilled them: 86 B per row of scratch writes, PMC)
+  static constexpr bool kNoTs = false;
   bool allow_defer = false, deferred = false;
   ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
 };
@@ -928,6 +932,10 @@ struct RegScratch : ScratchBase {
 template <class Scr>
 struct DeferOnly : Scr {
   static constexpr bool kDeferOnly = true;
+};
+template <class Scr>
+struct NoTs : Scr {
+  static constexpr bool kNoTs = true;
 };
 
 // a + al x d + w (w . d) - w2 d : acceleration of a point at offset d from a point of the same body whose

@@ -203,7 +203,8 @@ constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(
 // ~1700 without the sweeps).
 // PASS (six-row kernels): 0 = the complete row program (modes 0 and 2: the sweeps are compiled in; one wave per SIMD),
 // 1 = the first pass (mode 1) - no eigen-decomposition in the code at all, two waves per SIMD.
-template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0>
+// NOTS (first pass of the plain six-row law only): the caller wants no training signal - see ScratchBase::kNoTs.
+template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOTS = false>
 __global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
@@ -224,7 +225,14 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
         wl[16 * kWlLists + sub * wl_capacity(B) + atomicAdd(wl + 16 * sub, 1)] = (int)b;
       }
     };
-    if constexpr (kLds) {
+    if constexpr (kLds && NOTS) {
+      static_assert(PASS == 1 && KM == 6 && FEAT == 0, "NOTS is instantiated for the first pass of the plain six-row law");
+      NoTs<DeferOnly<LdsScratch<T, A::N>>> scr;
+      scr.slab = slab;
+      scr.lane = (int)threadIdx.x;
+      scr.sctab = sctab;
+      go(scr);
+    } else if constexpr (kLds) {
       std::conditional_t<PASS == 1, DeferOnly<LdsScratch<T, A::N>>, LdsScratch<T, A::N>> scr;
       scr.slab = slab;
       scr.lane = (int)threadIdx.x;
@@ -531,13 +539,20 @@ struct Launch {
                          *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
                          (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl);
     };
+    auto go_nots = [&](dim3 grid) {  // first pass, plain law, no training signal asked for
+      if constexpr (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0))
+        hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, 1, true>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
+                           *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
+                           (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)nullptr, 1, a.wl);
+    };
     if constexpr (KM == 6) {
       if (a.wl) {
         // stale counters would let pass 1 append past its sub-lists: no launch without the memset
         if (hipError_t e = hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream); e != hipSuccess) return e;
         dim3 g1 = grid_for(la.B);
         if (ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;  // a multiple of kWlLists
-        go(ic<1>{}, g1, 1);
+        if (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0) && !a.ts) go_nots(g1);
+        else go(ic<1>{}, g1, 1);
         go(ic<0>{}, dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
         return hipSuccess;
       }

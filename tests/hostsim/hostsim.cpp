@@ -71,6 +71,16 @@ int run_osc(const A& arm, int n, const abrk_osc_params* P, int64_t B, const void
       if constexpr (A::N <= 3) {
         if (P->use_C) CALL(2, true); else CALL(2, false);
       }
+    } else if (feat == 0 && !ts) {
+      // what the first pass of the plain six-row kernels runs when no training signal is asked for (NoTs: the gravity
+      // term folded into the velocity term ahead of the factorisations)
+      NoTs<RegScratch<T, A::N>> scr;
+      if (P->use_C)
+        osc_body<A, T, 6, true, 0>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, (T*)ie,
+                                   (const T*)une, (T*)u, (T*)ts, scr);
+      else
+        osc_body<A, T, 6, false, 0>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, (T*)ie,
+                                    (const T*)une, (T*)u, (T*)ts, scr);
     } else {
       if (P->use_C) CALL(6, true); else CALL(6, false);
     }

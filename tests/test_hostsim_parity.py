@@ -412,6 +412,25 @@ def test_rows_fused_full_outputs(arm, kw):
         assert list(only) == ["C"] and np.allclose(only["C"], ref2["C"], rtol=1e-12, atol=1e-12)
 
 
+def test_rows_six_row_law_without_training_signal():
+    """the NoTs variant of the six-row law (no training signal asked for: the gravity term joins the velocity term before
+    the factorisations, which is what lets the GPU's first-pass kernel keep its law free of spills) against the plain
+    variant: the same u to rounding, on the UR5 (orthogonal chain, with and without the Coriolis term) and Jaco2"""
+    from tests import hostsim
+
+    rng = np.random.RandomState(11)
+    for arm, kw in (("ur5", dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6)),
+                    ("ur5", dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6, use_C=True, orientation_algorithm=1)),
+                    ("ur5", dict(kp=50, ctrlr_dof=[1, 1, 0, 1, 0, 1], use_g=False)),
+                    ("jaco2", dict(kp=80, ko=40, ctrlr_dof=[1] * 6, use_C=True))):
+        p = cases.P(6, **kw)
+        q, dq, t = rng.uniform(0, 2 * np.pi, (300, 6)), rng.uniform(0, 5, (300, 6)), rng.uniform(-1, 1, (300, 6))
+        u_ts, _ = hostsim.osc_generate(arm, p, q, dq, t, training_signal=True)
+        u_no = hostsim.osc_generate(arm, p, q, dq, t, training_signal=False)
+        scale = np.max(np.abs(u_ts), axis=1, keepdims=True)
+        assert np.max(np.abs(u_no - u_ts) / scale) < 1e-13, (arm, kw)
+
+
 def test_rows_six_by_six_eigensolvers():
     """abrk_ctrl.h `ql_eig` (Householder tridiagonalisation + implicit QL, every index a compile-time constant) - what
     the six-row OSC law's truncating pinv runs on since round 3 - and `jacobi_eig` (the cyclic Jacobi it replaced there,

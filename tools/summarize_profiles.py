@@ -57,9 +57,10 @@ def rows_for(kernel, grid):
     if (kn, int(grid)) in ROWS:
         return ROWS[(kn, int(grid))]
     # the six-row law's second pass (PASS = 0 at a fixed 2048-block grid) belongs to the leg of its first pass
-    if kn.startswith("osc_kernel<") and kn.endswith(",0>") and int(grid) == 8 * 256 * 64:
-        first = kn[:-3] + ",1>"
-        big = [b for (k, g), b in ROWS.items() if k == first]
+    # (PASS = 1, with or without the training-signal output)
+    if kn.startswith("osc_kernel<") and kn.endswith(",0,false>") and int(grid) == 8 * 256 * 64:
+        stem = kn[: -len(",0,false>")]
+        big = [b for (k, g), b in ROWS.items() if k in (stem + ",1,true>", stem + ",1,false>")]
         if big:
             return max(big)
     return int(grid)
@@ -113,8 +114,9 @@ if os.path.exists(ks):
             leg = ll[0][1]
             mean_us = sel["dur"].mean() / 1e3
             extra = 0.0
-            if kn.startswith("osc_kernel<") and kn.endswith(",1>"):  # + the dense second pass of the same calls
-                s2 = kt[(kt["kernel"].str.replace(" ", "") == (kn[:-3] + ",0>")[:90]) & (kt["Grid_Size_X"] == 8 * 256 * 64)]
+            if kn.startswith("osc_kernel<") and kn.endswith((",1,true>", ",1,false>")):  # + the dense second pass of the same calls
+                stem = kn[: kn.rindex(",1,")]
+                s2 = kt[(kt["kernel"].str.replace(" ", "") == (stem + ",0,false>")[:90]) & (kt["Grid_Size_X"] == 8 * 256 * 64)]
                 if not s2.empty:
                     extra = s2["dur"].mean() / 1e3
             frac = leg["batch"] * leg["bytes_per_eval"] / ((mean_us + extra) * 1e-6) / 8e12
