@@ -261,21 +261,17 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
 template <int K, class T>
 ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
   static_assert(K >= 3, "two rows: one Jacobi rotation is exact");
-  T a[K][K];
-  sfor<K>([&](auto i) ABRK_LAMBDA {
-    sfor<K>([&](auto j) ABRK_LAMBDA {
-      a[i()][j()] = S[tri(i(), j())];
-      V[i()][j()] = (i() == j()) ? T(1) : T(0);
-    });
-  });
+  T a[K * (K + 1) / 2];  // packed lower triangle (the reduction works on a copy)
+  sfor<K*(K + 1) / 2>([&](auto e) ABRK_LAMBDA { a[e()] = S[e()]; });
+  sfor<K>([&](auto i) ABRK_LAMBDA { sfor<K>([&](auto j) ABRK_LAMBDA { V[i()][j()] = (i() == j()) ? T(1) : T(0); }); });
   T d[K], e[K];
   sfor<K>([&](auto i) ABRK_LAMBDA { e[i()] = T(0); });
   // ---- Householder: A <- H_k A H_k, H_k = I - beta v v^T acting on rows / columns k+1 .. K-1;  V <- V H_k
   sfor<K - 2>([&](auto kc) ABRK_LAMBDA {
     constexpr int k = kc(), m0 = k + 1, M = K - m0;  // the block that is transformed: indices m0 .. K-1 (M of them)
-    T x0 = a[m0][k];
+    T x0 = a[tri(m0, k)];
     T sigma2 = T(0);
-    sfor<M - 1>([&](auto j) ABRK_LAMBDA { sigma2 = Rm<T>::fma(a[m0 + 1 + j()][k], a[m0 + 1 + j()][k], sigma2); });
+    sfor<M - 1>([&](auto j) ABRK_LAMBDA { sigma2 = Rm<T>::fma(a[tri(m0 + 1 + j(), k)], a[tri(m0 + 1 + j(), k)], sigma2); });
     T alpha = x0;  // the new sub-diagonal entry
     // nothing below the sub-diagonal (to rounding): the column is already tridiagonal
     if (sigma2 > Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * (x0 * x0 + sigma2) && sigma2 > Rm<T>::tiny()) {
@@ -284,13 +280,13 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
       alpha = x0 >= T(0) ? -nrm : nrm;
       T v[M];
       v[0] = x0 - alpha;
-      sfor<M - 1>([&](auto j) ABRK_LAMBDA { v[1 + j()] = a[m0 + 1 + j()][k]; });
+      sfor<M - 1>([&](auto j) ABRK_LAMBDA { v[1 + j()] = a[tri(m0 + 1 + j(), k)]; });
       const T vtv = Rm<T>::fma(v[0], v[0], sigma2);
       const T beta = T(2) * Rm<T>::rcp(vtv);
       T pv[M], kk = T(0);
       sfor<M>([&](auto i) ABRK_LAMBDA {
         T acc = T(-0.0);
-        sfor<M>([&](auto j) ABRK_LAMBDA { acc = Rm<T>::fma(a[m0 + i()][m0 + j()], v[j()], acc); });
+        sfor<M>([&](auto j) ABRK_LAMBDA { acc = Rm<T>::fma(a[tri(m0 + i(), m0 + j())], v[j()], acc); });
         pv[i()] = beta * acc;
         kk = Rm<T>::fma(pv[i()], v[i()], kk);
       });
@@ -298,9 +294,7 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
       sfor<M>([&](auto i) ABRK_LAMBDA { pv[i()] = Rm<T>::fma(-kk, v[i()], pv[i()]); });  // q = p - (beta/2)(p.v) v
       sfor<M>([&](auto i) ABRK_LAMBDA {
         sfor<i() + 1>([&](auto j) ABRK_LAMBDA {
-          const T nv = a[m0 + i()][m0 + j()] - v[i()] * pv[j()] - pv[i()] * v[j()];
-          a[m0 + i()][m0 + j()] = nv;
-          a[m0 + j()][m0 + i()] = nv;
+          a[tri(m0 + i(), m0 + j())] = a[tri(m0 + i(), m0 + j())] - v[i()] * pv[j()] - pv[i()] * v[j()];
         });
       });
       // V <- V H (row 0 of V is e_0 throughout: the reflectors never touch index 0)
@@ -314,19 +308,24 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
     }
     e[k] = alpha;
   });
-  e[K - 2] = a[K - 1][K - 2];
-  sfor<K>([&](auto i) ABRK_LAMBDA { d[i()] = a[i()][i()]; });
+  e[K - 2] = a[tri(K - 1, K - 2)];
+  sfor<K>([&](auto i) ABRK_LAMBDA { d[i()] = a[tri(i(), i())]; });
   // ---- implicit QL with Wilkinson shift on (d, e): e[i] couples i and i + 1
   sfor<K>([&](auto lc) ABRK_LAMBDA {
     constexpr int l = lc();
     if constexpr (l < K - 1) {
       for (int iter = 0; iter < 40; iter++) {
-        // smallest m >= l whose coupling e[m] is negligible (m = K - 1: none)
+        // smallest m >= l whose coupling e[m] is negligible (m = K - 1: none), and d[m] with it (picked up here, under
+        // the same conditions: selecting d[m] by comparing m with every index afterwards is turned into a table
+        // look-up in scratch memory by the compiler)
         int m = K - 1;
+        T dm = d[K - 1];
         sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
           constexpr int j = K - 2 - jj();  // K-2 .. l
           const T dd = Rm<T>::fabs(d[j]) + Rm<T>::fabs(d[j + 1]);
-          if (!(Rm<T>::fabs(e[j]) > Rm<T>::eps() * dd)) m = j;
+          const bool small = !(Rm<T>::fabs(e[j]) > Rm<T>::eps() * dd);
+          m = small ? j : m;
+          dm = small ? d[j] : dm;
         });
         if (m == l) break;
         T g = (d[l + 1] - d[l]) * T(0.5) * Rm<T>::rcp(e[l] == T(0) ? T(1) : e[l]);
@@ -334,13 +333,7 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
           const T r2 = Rm<T>::fma(g, g, T(1));
           const T r = r2 * Rm<T>::rsqrt(r2);
           const T den = g + (g >= T(0) ? r : -r);
-          // d[m] - d[l] + e[l] / (g + sign(r, g)); m is a run-time index: select
-          T dm = d[K - 1];
-          sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
-            constexpr int j = l + jj();
-            dm = (m == j) ? d[j] : dm;
-          });
-          g = dm - d[l] + e[l] * Rm<T>::rcp(den);
+          g = dm - d[l] + e[l] * Rm<T>::rcp(den);  // d[m] - d[l] + e[l] / (g + sign(r, g))
         }
         T sn = T(1), cs = T(1), pp = T(0);
         bool stop = false;  // a zero rotation radius ends the pass early (tql2's recovery from underflow)
@@ -403,10 +396,11 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
           }
         });
 #endif
-        // e[m] = 0 in either case
+        // e[m] = 0 in either case (as value selects: an `if (m == j) e[j] = 0` chain becomes ONE store through a
+        // selected pointer, which sends e[] to scratch memory)
         sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
           constexpr int j = l + jj();
-          if (m == j) e[j] = T(0);
+          e[j] = (m == j) ? T(0) : e[j];
         });
         if (!stop) {
           d[l] -= pp;
@@ -1019,6 +1013,9 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
 //   * Y is held three rows at a time: Mx_inv = Y Y^T in two row blocks of three (+3 forward solves, -18 live values).
 // Same arithmetic per entry as osc_law (Gram form of Mx_inv, Cholesky, the two certificates, Jacobi behind them);
 // only the order of independent steps differs.  Two waves per SIMD on the six-joint arms.
+#ifndef ABRK_LAW6_YB
+#define ABRK_LAW6_YB 3  // rows of Y held at a time (2 was measured: 12 instead of 9 solves cost more than 16 B of scratch)
+#endif
 template <int N, class T, bool USE_C, int FEAT, class Rows>
 ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
                        const T (&cvec)[N], const Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
@@ -1133,19 +1130,27 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     return acc;
   };
   {
-    T Ya[3][N];
-    sfor<3>([&](auto r) ABRK_LAMBDA { yrow(r, Ya[r()]); });
-    sfor<3>([&](auto r) ABRK_LAMBDA { sfor<r() + 1>([&](auto c) ABRK_LAMBDA { Am[tri(r(), c())] = ydot(Ya[r()], Ya[c()]); }); });
-    T Yb[3][N];
-    sfor<3>([&](auto r) ABRK_LAMBDA {
-      yrow(ic<3 + r()>{}, Yb[r()]);
-      sfor<3>([&](auto c) ABRK_LAMBDA { Am[tri(3 + r(), c())] = ydot(Yb[r()], Ya[c()]); });
-    });
-    sfor<3>([&](auto r) ABRK_LAMBDA {
-      sfor<r() + 1>([&](auto c) ABRK_LAMBDA { Am[tri(3 + r(), 3 + c())] = ydot(Yb[r()], Yb[c()]); });
+    // Y is held YB rows at a time: the diagonal block of Mx_inv from the rows at hand, the blocks below it from one
+    // more row at a time (recomputed when its own block comes up).  Three rows per block cost 9 forward solves for the
+    // six rows, two rows 12 (measured with the training signal among the outputs, where u0 AND the gravity sums stay
+    // live across the law: 957 us against 937 us at 8 M UR5 rows - the 16 B of scratch it saves do not pay for 3 solves)
+    constexpr int YB = ABRK_LAW6_YB;
+    static_assert(KM % YB == 0, "block size divides the six rows");
+    sfor<KM / YB>([&](auto bi) ABRK_LAMBDA {
+      constexpr int r0 = bi() * YB;
+      T Ya[YB][N];
+      sfor<YB>([&](auto r) ABRK_LAMBDA { yrow(ic<r0 + r()>{}, Ya[r()]); });
+      sfor<YB>([&](auto r) ABRK_LAMBDA {
+        sfor<r() + 1>([&](auto c) ABRK_LAMBDA { Am[tri(r0 + r(), r0 + c())] = ydot(Ya[r()], Ya[c()]); });
+      });
+      sfor<KM - r0 - YB>([&](auto rr) ABRK_LAMBDA {
+        constexpr int r = r0 + YB + rr();
+        T yb[N];
+        yrow(ic<r>{}, yb);
+        sfor<YB>([&](auto c) ABRK_LAMBDA { Am[tri(r, r0 + c())] = ydot(yb, Ya[c()]); });
+      });
     });
   }
-  ABRK_MARK("law6:chol_A");
   T trace = T(0);
   sfor<KM>([&](auto r) ABRK_LAMBDA {
     trace += sel[r()] ? Am[tri(r(), r())] : T(0);

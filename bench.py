@@ -311,6 +311,13 @@ class Runner:
         elif self.kind == "obstacles":
             self.engine.avoid_obstacles_generate(self.arm_id, self.n, self.params, self.q, u=self.u, dtype=self.dt,
                                                  device=self.device, stream=self.stream)
+        elif os.environ.get("ABRK_BENCH_TS"):
+            # measurement switch: also ask for the training signal (osc.py:297) - what the Python OSC class always does;
+            # + 8 n bytes per row of output, and the six-row first pass is then the instantiation that carries it
+            if not hasattr(self, "ts"):
+                self.ts = self.a.DeviceArray((self.B, self.n), self.dt, self.device)
+            self.engine.osc_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
+                                     training_signal=self.ts, dtype=self.dt, device=self.device, stream=self.stream)
         else:
             self.engine.osc_generate(self.arm_id, self.n, self.params, self.q, self.dq, self.t, u=self.u,
                                      dtype=self.dt, device=self.device, stream=self.stream)

@@ -1529,11 +1529,14 @@ def test_gpu_six_row_deferred_pass_equals_inline_sweeps(variant):
             _zero(u)
             plan.launch()
             s.sync()
-            assert np.array_equal(u.numpy(), u_big)
+            # no training signal asked for: the first pass is the NOTS instantiation (gravity joins the velocity term
+            # before the factorisations) - the same u to rounding, not to the bit
+            u_plan = u.numpy()
+            assert np.max(np.abs(u_plan - u_big) / np.max(np.abs(u_big), axis=1, keepdims=True)) < 1e-13
             _zero(u)
             plan.launch_graph(3)
             s.sync()
-            assert np.array_equal(u.numpy(), u_big)
+            assert np.array_equal(u.numpy(), u_plan)
             plan.close()
     # the fp32 instantiation takes the same two passes
     p = _abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6)
@@ -1541,7 +1544,17 @@ def test_gpu_six_row_deferred_pass_equals_inline_sweeps(variant):
     big = be.e.osc_generate(be.arm_id, 6, p, q32, dq32, t32, dtype=np.float32)
     chunks = [be.e.osc_generate(be.arm_id, 6, p, q32[lo:lo + 8000], dq32[lo:lo + 8000], t32[lo:lo + 8000], dtype=np.float32)
               for lo in range(0, B, 8000)]
-    assert big.dtype == np.float32 and np.array_equal(big, np.concatenate(chunks), equal_nan=True)
+    chunks = np.concatenate(chunks)
+    assert big.dtype == np.float32 and np.array_equal(np.isnan(big), np.isnan(chunks))
+    # (no training signal: NOTS first pass against the inline program of the chunks - equal to fp32 rounding; the rows
+    #  the second pass works off run the very same program in both and are bit-equal)
+    fin = np.isfinite(big).all(axis=1)
+    rel = np.max(np.abs(big[fin].astype(float) - chunks[fin]), axis=1) / np.max(np.abs(chunks[fin]), axis=1)
+    assert np.median(rel) < 1e-6 and np.percentile(rel, 99) < 1e-4
+    big_ts = be.e.osc_generate(be.arm_id, 6, p, q32, dq32, t32, training_signal=True, dtype=np.float32)[0]
+    chunks_ts = np.concatenate([be.e.osc_generate(be.arm_id, 6, p, q32[lo:lo + 8000], dq32[lo:lo + 8000], t32[lo:lo + 8000],
+                                                  training_signal=True, dtype=np.float32)[0] for lo in range(0, B, 8000)])
+    assert np.array_equal(big_ts, chunks_ts, equal_nan=True)  # with it: the same arithmetic, bit for bit
 
 
 def test_gpu_table_sincos_negative_and_large_angles():
