@@ -86,7 +86,15 @@ dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, con
 #ifndef ABRK_KM6_TWO_WAVES_GENERAL
 #define ABRK_KM6_TWO_WAVES_GENERAL 0
 #endif
-constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho, int pass = 0) {
+// Runtime-table arms (the table rides in SGPRs, every frame product is a dense 3 x 4 multiply, every joint carries a
+// 3 x 3 W): capped at 256 registers the three-row kernels spill 130-220 B per lane in the hot path.  One wave per SIMD
+// without spills is faster (round 3, UR5's table as a user arm, 8 M rows: 908 -> 787 us; Jaco2's: 906 -> 782 us; the
+// 4096-row step 8.55 -> 7.50 us).  1 = the round-2 behaviour.
+#ifndef ABRK_RT_TWO_WAVES
+#define ABRK_RT_TWO_WAVES 0
+#endif
+constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho, int pass = 0, bool is_static = true) {
+  if (!is_static && !ABRK_RT_TWO_WAVES && km <= 3) return ABRK_MIN_WAVES;
   // six-row law: the first pass of orthogonal chains fits 256 registers (UR5: 100-216 B of scratch, all of it in cold
   // branches); general chains carry a 3 x 3 W per joint through the kinematics and would spill 250-650 B in the hot
   // path (ABRK_KM6_TWO_WAVES_GENERAL = 1 forces them too - a measurement switch)
@@ -205,7 +213,7 @@ constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(
 // 1 = the first pass (mode 1) - no eigen-decomposition in the code at all, two waves per SIMD.
 // NOTS (first pass of the plain six-row law only): the caller wants no training signal - see ScratchBase::kNoTs.
 template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOTS = false>
-__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS))
+__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl) {
