@@ -220,7 +220,7 @@ class Runner:
             six_two_pass = (not fast) and self.B >= 16384
             km = 3 if fast else (2 if dof == [1, 1, 0, 0, 0, 0] and self.n <= 3 and p.ref_frame == 2 * self.n + 1 else 6)
             # ... and, the bench never asking for the training signal, the plain law's first pass is the NOTS variant
-            nots = six_two_pass and not p.n_null
+            nots = six_two_pass and not p.n_null and not os.environ.get("ABRK_BENCH_TS")
             return (f"osc_kernel<{arm}, {t}, {km}, {b(p.use_C)}, {1 if p.n_null else 0}, {1 if six_two_pass else 0}, "
                     f"{b(nots)}>")
         if k == "dyn":
