@@ -37,6 +37,12 @@ WORKLOADS = {
     "cfg3": ("jaco2", "OSC(rc, kp=200, null_controllers=[Damping(rc, kv=10)], ctrlr_dof=[True, True, True, False, False, False])", 6),
     "cfg4": ("ur5", "OSC(rc, kp=200, use_g=True, use_C=True, ctrlr_dof=[True, True, True, False, False, False])", 6),
     "cfg5": ("threejoint", "Sliding(rc)", 3),
+    # the reference's one published benchmark (examples/timing_plots.py:34-39; README.rst:159-162): OSC with its default
+    # gains, per arm.  Its two Jaco2 lines pass `hand_attached=...`, which today's arms/jaco2/config.py forwards into
+    # BaseConfig.__init__ -> TypeError; the arm as it constructs today stands in for the first.
+    "tp_twojoint": ("twojoint", "OSC(rc)", 6),
+    "tp_ur5": ("ur5", "OSC(rc, ctrlr_dof=[True] * 6)", 6),
+    "tp_jaco2": ("jaco2", "OSC(rc, ctrlr_dof=[True] * 5 + [False])", 6),
 }
 
 WORKER = r'''
@@ -61,6 +67,20 @@ print(done, time.perf_counter() - t0, kind)
 '''
 
 
+def numpy2_shim(pkg_root):
+    """the ONE edit a scratch copy of the reference gets (the same oracle/gen_golden.py applies): numpy >= 2 rejects
+    `numpy.array(..., copy=False)` (abr_control/utils/transformations.py:1225), which breaks robot_config.quaternion and
+    with it every OSC with orientation rows -> numpy.asarray.  Returns the number of sites replaced."""
+    import re
+
+    path = os.path.join(pkg_root, "abr_control", "utils", "transformations.py")
+    src = open(path).read()
+    src, n = re.subn(r"numpy\.array\(([^()]*?), dtype=numpy\.float64, copy=False\)",
+                     r"numpy.asarray(\1, dtype=numpy.float64)", src)
+    open(path, "w").write(src)
+    return n
+
+
 def ref_env(pkg_root, home=None):
     """environment of a reference process: its package on the path, one BLAS thread, HOME = where its function cache
     lives (utils/paths.py:9 expands ~/.cache/abr_control)"""
@@ -81,7 +101,7 @@ def run_workers(name, procs, budget, env):
     for p, (o, e) in zip(ps, outs):
         if p.returncode:
             raise RuntimeError(f"{name}: reference worker failed:\n{e[-2000:]}")
-    rows = [o.split() for o, _ in outs]
+    rows = [o.strip().splitlines()[-1].split() for o, _ in outs]  # last line: OSC prints a notice for twojoint + xyz
     rate = sum(int(r[0]) / float(r[1]) for r in rows)  # each worker's own timed region (start-up excluded)
     return rate, rows[0][2], wall
 
@@ -141,6 +161,7 @@ def main():
         if os.path.isdir(SCRATCH):
             shutil.rmtree(SCRATCH)
         shutil.copytree(REF, SCRATCH)
+        numpy2_shim(SCRATCH)
         cpu, _ = host_description()
         res = {"measured_on": f"build container ({cpu}, {cores} cores) - NOT the GPU box's host",
                "what": "abr_control's own Cython path: ctrlr.generate(q[b], dq[b], target[b]) per row (no batch API), "

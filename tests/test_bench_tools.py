@@ -75,3 +75,23 @@ def test_summarize_profiles_keys_grid_stride_kernels_by_rows(tmp_path):
         import shutil
 
         shutil.rmtree(os.path.join(REPO, "profiles", "_test_tmp"), ignore_errors=True)
+
+
+def test_timing_plots_replica_settings_have_a_staged_reference_workload():
+    """tools/timing_plots_replica.py times the reference's published benchmark on both sides: every setting names a
+    workload oracle/time_reference.py knows (so that oracle/stage_reference.py staged its functions), for an arm this
+    package ships, with the keyword arguments of examples/timing_plots.py:34-39"""
+    import importlib.util
+
+    from oracle import time_reference
+
+    spec = importlib.util.spec_from_file_location("tp_replica", os.path.join(REPO, "tools", "timing_plots_replica.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert [s[0] for s in mod.SETTINGS] == ["Two joint", "UR5", "Jaco2"]
+    for label, arm, kw, wl in mod.SETTINGS:
+        ref_arm, factory, nt = time_reference.WORKLOADS[wl]
+        assert ref_arm == arm and nt == 6
+        assert os.path.isdir(os.path.join(REPO, "abr_control_amd", "arms", arm))
+        want = "OSC(rc)" if not kw else "OSC(rc, ctrlr_dof=" + ("[True] * 6" if all(kw["ctrlr_dof"]) else "[True] * 5 + [False]") + ")"
+        assert factory == want
