@@ -29,6 +29,10 @@ template <class T>
 struct OscP {
   T kp, ko, kv, ki;
   T vmax0, vmax1;
+  // velocity limiting (osc.py:110-115, 198-215), formed once on the host in T: vmax0 / kp * kv, vmax1 / ko * kv, kp / kv,
+  // ko / kv.  (Computed in the kernels they were loop invariants: the six-row kernel's persistent loop kept the four
+  // quotients - divisions of a branch most launches never take - in vector registers it does not have.)
+  T sat_xyz, sat_abg, lamb_xyz, lamb_abg;
   T off[3];
   int use_vmax, use_g, alg;
   int dof[6];
@@ -83,17 +87,25 @@ ABRK_INL T rcp(T x) {
 
 // Cholesky of a symmetric K x K matrix in lower-triangular packed storage.
 // L overwrites a copy; il[j] = 1/L_jj.  ok=false if a pivot is not positive.
-template <int K, class T>
+// GUARD = false (fp64): the pivots are tested (the return value) but L and il are not sanitised - no two double selects
+// per pivot (four v_cndmask: a double select costs as much as three FMAs on gfx950, tools/microbench/valu_rates.hip; 24
+// issue slots of a 6 x 6 factor, and the compares go too where the caller ignores the result).  After a pivot <= 0, L and
+// il hold non-finite values: for callers that read them only when ok (the task-space factor of the six-row law) or whose
+// matrix is positive definite by construction (the joint-space inertia matrix of an arm with mass - a singular one gives
+// non-finite torques where the reference raises LinAlgError).  The first failing pivot is a real number <= 0, so the
+// flag does not depend on how comparisons treat the NaNs that follow it (-ffinite-math-only).
+template <int K, class T, bool GUARD = true>
 ABRK_INL bool chol(const T (&S)[K * (K + 1) / 2], T (&L)[K * (K + 1) / 2], T (&il)[K]) {
+  constexpr bool kGuard = GUARD || sizeof(T) < 8;  // fp32: a pivot of an ill-conditioned M can round to <= 0
   bool ok = true;
   sfor<K>([&](auto j) ABRK_LAMBDA {
     T dgn = S[tri(j(), j())];
     sfor<j()>([&](auto k) ABRK_LAMBDA { dgn = Rm<T>::fma(-L[tri(j(), k())], L[tri(j(), k())], dgn); });
-    bool pos = dgn > T(0);
+    const bool pos = dgn > T(0);
     ok = ok && pos;
-    T dsafe = pos ? dgn : T(1);
-    T rs = Rm<T>::rsqrt(dsafe);
-    T inv = pos ? rs : T(0);
+    const T dsafe = kGuard ? (pos ? dgn : T(1)) : dgn;
+    const T rs = Rm<T>::rsqrt(dsafe);
+    const T inv = kGuard ? (pos ? rs : T(0)) : rs;
     L[tri(j(), j())] = dsafe * rs;
     il[j()] = inv;
     sfor<K - 1 - j()>([&](auto ii) ABRK_LAMBDA {
@@ -103,6 +115,38 @@ ABRK_INL bool chol(const T (&S)[K * (K + 1) / 2], T (&L)[K * (K + 1) / 2], T (&i
       L[tri(i, j())] = acc * inv;
     });
   });
+  return ok;
+}
+// Inverse and determinant of a symmetric 3 x 3 / 2 x 2 matrix by cofactors (packed lower: a00 a10 a11 a20 a21 a22):
+// one reciprocal instead of the three reciprocal square roots of a Cholesky factor (v_rcp_f64 / v_rsq_f64 issue in 16
+// cycles, four FMAs' worth), no pivot selects, and the inverse itself - which the null-space filter and the second
+// certificate of the pinv branch want anyway - instead of two triangular solves: ~40 issue slots for the x,y,z law
+// against ~95.  ok = positive definite (leading minors); the entries carry a relative error of cond(A) eps like the
+// factor's.  When !ok, Inv is the adjugate (finite, unused by the callers).
+template <int K, class T>
+ABRK_INL bool spd_inverse_small(const T (&A)[K * (K + 1) / 2], T (&Inv)[K * (K + 1) / 2], T& det) {
+  static_assert(K == 2 || K == 3, "closed forms for 2 x 2 and 3 x 3");
+  bool ok;
+  if constexpr (K == 3) {
+    const T a00 = A[0], a10 = A[1], a11 = A[2], a20 = A[3], a21 = A[4], a22 = A[5];
+    Inv[0] = Rm<T>::fma(a11, a22, -(a21 * a21));
+    Inv[1] = Rm<T>::fma(a21, a20, -(a10 * a22));
+    Inv[2] = Rm<T>::fma(a00, a22, -(a20 * a20));
+    Inv[3] = Rm<T>::fma(a10, a21, -(a20 * a11));
+    Inv[4] = Rm<T>::fma(a10, a20, -(a00 * a21));
+    Inv[5] = Rm<T>::fma(a00, a11, -(a10 * a10));
+    det = Rm<T>::fma(a20, Inv[3], Rm<T>::fma(a10, Inv[1], a00 * Inv[0]));
+    ok = a00 > T(0) && Inv[5] > T(0) && det > Rm<T>::tiny();
+  } else {
+    const T a00 = A[0], a10 = A[1], a11 = A[2];
+    Inv[0] = a11;
+    Inv[1] = -a10;
+    Inv[2] = a00;
+    det = Rm<T>::fma(a00, a11, -(a10 * a10));
+    ok = a00 > T(0) && det > Rm<T>::tiny();
+  }
+  const T rd = ok ? rcp(ok ? det : T(1)) : T(1);
+  sfor<K*(K + 1) / 2>([&](auto e) ABRK_LAMBDA { Inv[e()] *= rd; });
   return ok;
 }
 // x = L^-1 b
@@ -603,7 +647,11 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3], T rcond, T (&P)[N][3]) {
 // non-orthogonality of R and three power steps from its heaviest column converge to
 // rounding (error ratio^3 with ratio ~ |R^T R - I|).  Returns unit (w,x,y,z), w >= 0
 // (sign rule transformations.py:1269; unit_vector base_config.py:315).
-template <class T>
+// The iterate is normalised once, at the end: the dominant eigenvalue is 4/3, so STEPS steps scale it by (4/3)^STEPS
+// and nothing can overflow (a reciprocal square root per step was a sixth of the orientation error's cost).
+// STEPS = 1 where R is a product of exact joint rotations (orthogonal to rounding: the frame rotation of an orthogonal
+// chain inside the fused kernels) - the heaviest column is then already the eigenvector to ~1e-16.
+template <class T, int STEPS = 3>
 ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
   const T m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7],
           m22 = R[8];
@@ -632,12 +680,10 @@ ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
   sfor<4>([&](auto i) ABRK_LAMBDA {
     v[i()] = best == 0 ? Bm[i()][0] : best == 1 ? Bm[i()][1] : best == 2 ? Bm[i()][2] : Bm[i()][3];
   });
-  sfor<3>([&](auto it) ABRK_LAMBDA {
-    T nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    T inv = Rm<T>::rsqrt(nn);
+  sfor<STEPS>([&](auto it) ABRK_LAMBDA {
     T w[4];
     sfor<4>([&](auto i) ABRK_LAMBDA {
-      w[i()] = (Bm[i()][0] * v[0] + Bm[i()][1] * v[1] + Bm[i()][2] * v[2] + Bm[i()][3] * v[3]) * inv;
+      w[i()] = Bm[i()][0] * v[0] + Bm[i()][1] * v[1] + Bm[i()][2] * v[2] + Bm[i()][3] * v[3];
     });
     sfor<4>([&](auto i) ABRK_LAMBDA { v[i()] = w[i()]; });
   });
@@ -725,12 +771,13 @@ ABRK_INL void quat_mul(const T (&q1)[4], const T (&q0)[4], T (&r)[4]) {
 }
 
 // _calc_orientation_forces (osc.py:149-196)
-template <class T>
+// QSTEPS: power steps of quat_from_R (1 where Re is orthogonal to rounding)
+template <class T, int QSTEPS = 3>
 ABRK_INL void orientation_forces(int alg, const T (&Re)[9], const T (&abg)[3], T (&uo)[3]) {
   if (alg == 0) {
     T qd[4], qe[4], qec[4], qr[4];
     quat_from_euler_rxyz(abg[0], abg[1], abg[2], qd);
-    quat_from_R(Re, qe);
+    quat_from_R<T, QSTEPS>(Re, qe);
     qec[0] = qe[0];
     qec[1] = -qe[1];
     qec[2] = -qe[2];
@@ -747,7 +794,7 @@ ABRK_INL void orientation_forces(int alg, const T (&Re)[9], const T (&abg)[3], T
                              Re[2 * 3 + r()] * Rd[2 * 3 + c()];
       });
     });
-    quat_from_R(Red, qed);
+    quat_from_R<T, QSTEPS>(Red, qed);
     sfor<3>([&](auto r) ABRK_LAMBDA {
       uo[r()] = -(Re[r() * 3 + 0] * qed[1] + Re[r() * 3 + 1] * qed[2] + Re[r() * 3 + 2] * qed[3]);
     });
@@ -784,6 +831,9 @@ ABRK_INL void opaque(T& x) {
 #endif
 }
 
+#ifndef ABRK_SMALL_INVERSE
+#define ABRK_SMALL_INVERSE 1  // measurement switch: 0 = the three-row law's Mx through a Cholesky factor (rounds 1-2)
+#endif
 // ---------------------------------------------------------------- OSC.generate, one row
 // KM = 3 or 2 (FAST: task rows are exactly x,y,z / x,y of the EE) or 6 (all six task rows, unselected
 // rows masked: their Jacobian row is zeroed and Mx_inv gets a unit diagonal there, which
@@ -811,9 +861,11 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     });
   });
 
+  ABRK_MARK("law3:chol_M");
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T through the Cholesky factor of M
   T L[N * (N + 1) / 2], il[N];
-  chol<N>(Ms, L, il);
+  chol<N, T, false>(Ms, L, il);
+  ABRK_MARK("law3:Y");
   T Y[N][KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA {
     T b[N], x[N];
@@ -821,6 +873,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     chol_fwd<N>(L, il, b, x);
     sfor<N>([&](auto i) ABRK_LAMBDA { Y[i()][r()] = x[i()]; });
   });
+  ABRK_MARK("law3:Am");
   T Am[KM * (KM + 1) / 2];
   T trace = T(0);
   sfor<KM>([&](auto r) ABRK_LAMBDA {
@@ -832,13 +885,21 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     trace += sel[r()] ? Am[tri(r(), r())] : T(0);
     if (!sel[r()]) Am[tri(r(), r())] = T(1);
   });
+  ABRK_MARK("law3:cholA_cert");
   T LA[KM * (KM + 1) / 2], ila[KM], Mx[KM * (KM + 1) / 2];
-  bool okA = chol<KM>(Am, LA, ila);
+  // x,y,z / x,y: Mx by cofactors (spd_inverse_small); otherwise through the Cholesky factor of Mx_inv
+  constexpr bool kClosed = FAST && (ABRK_SMALL_INVERSE != 0);
+  bool okA;
   T det = T(1);
-  sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
-  // FEAT = false needs Mx only once (Mx u_task): solved with the factor instead of forming the inverse
-  bool mx_explicit = FEAT != 0;
-  if constexpr (FEAT != 0) chol_inverse<KM>(LA, ila, Mx);
+  if constexpr (kClosed) {
+    okA = spd_inverse_small<KM>(Am, Mx, det);
+  } else {
+    okA = chol<KM>(Am, LA, ila);
+    sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
+  }
+  // (factor form) FEAT = 0 needs Mx only once (Mx u_task): solved with the factor instead of forming the inverse
+  bool mx_explicit = kClosed || FEAT != 0;
+  if constexpr (!kClosed && FEAT != 0) chol_inverse<KM>(LA, ila, Mx);
   const T thr = T(1e-3), rcond = T(1e-3) * T(0.1);
   if (!(okA && det >= thr)) {
     // pinv branch (osc.py:142-145).  pinv == inv unless some singular value is below
@@ -850,7 +911,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
       // second, much tighter certificate (the determinant bound is hopeless for six rows of mixed units):
       // lam_max(A) <= trace(A) and 1/lam_min(A) <= trace(A^-1), so trace(A) trace(A^-1) < 1/rcond proves
       // every singular value is above rcond * max - pinv is the inverse the factor already gives
-      if constexpr (FEAT == 0) chol_inverse<KM>(LA, ila, Mx);
+      if constexpr (!kClosed && FEAT == 0) chol_inverse<KM>(LA, ila, Mx);
       T tinv = T(0);
       sfor<KM>([&](auto r) ABRK_LAMBDA { tinv += sel[r()] ? Mx[tri(r(), r())] : T(0); });
       if (trace * tinv * rcond < T(1)) {
@@ -889,6 +950,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     }
   }
 
+  ABRK_MARK("law3:forces");
   // desired task-space forces (osc.py:250-259)
   T ut[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
   if (FAST || P.pos_on) sfor<3>([&](auto r) ABRK_LAMBDA { ut[r()] = p[r()] - tgt[r()]; });
@@ -908,12 +970,12 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   }
   // gains / velocity limiting (osc.py:266-272, 198-215; constants osc.py:89-115)
   if (P.use_vmax) {
-    T sat_xyz = P.vmax0 / P.kp * P.kv, sat_abg = P.vmax1 / P.ko * P.kv;
+    T sat_xyz = P.sat_xyz, sat_abg = P.sat_abg;
     T nx = Rm<T>::sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
     T na = Rm<T>::sqrt(ut[3] * ut[3] + ut[4] * ut[4] + ut[5] * ut[5]);
     T sx = (nx > sat_xyz) ? sat_xyz / nx : T(1);
     T sa = (na > sat_abg) ? sat_abg / na : T(1);
-    T lx = P.kp / P.kv, la = P.ko / P.kv;
+    T lx = P.lamb_xyz, la = P.lamb_abg;
     sfor<3>([&](auto r) ABRK_LAMBDA {
       ut[r()] = P.kv * sx * lx * ut[r()];
       ut[3 + r()] = P.kv * sa * la * ut[3 + r()];
@@ -924,6 +986,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
       ut[3 + r()] *= P.ko;
     });
   }
+  ABRK_MARK("law3:vel_comp");
   // velocity compensation (osc.py:274-282)
   bool tv_zero = true;
   if (FEAT >= 2 && tv_given) sfor<6>([&](auto r) ABRK_LAMBDA { tv_zero = tv_zero && (tvin[r()] == T(0)); });
@@ -941,10 +1004,13 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     });
     sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(0); });
   }
+  ABRK_MARK("law3:f_JTf");
   // u -= J^T (Mx u_task[ctrlr_dof]) (osc.py:285-288)
   T uts[KM], f[KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
-  if (mx_explicit) {
+  if constexpr (kClosed) {
+    symv<KM>(Mx, uts, f);
+  } else if (mx_explicit) {
     symv<KM>(Mx, uts, f);
   } else {
     T y[KM];
@@ -958,8 +1024,12 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   });
   if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= cvec[i()]; });  // osc.py:291-292
   sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297
-  if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gscale, gz[i()], u[i()]); }); // osc.py:300-301
+  // osc.py:300-301.  use_g is uniform over the launch: a zero gain (a scalar select) instead of the N double selects
+  // the compiler makes of `if (P.use_g)` - u + 0 g is u
+  const T gsc = P.use_g ? gscale : T(0);
+  sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gsc, gz[i()], u[i()]); });
 
+  ABRK_MARK("law3:null");
   // secondary controllers through the null-space filter I - J^T Jbar^T (osc.py:310-318).
   // With u_null = M v the filtered signal is M v - J^T Mx (J v) (Jbar^T M = Mx J).
   if (FEAT >= 1 && (P.n_null > 0 || (FEAT >= 2 && have_ext))) {
@@ -1016,14 +1086,20 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
 #ifndef ABRK_LAW6_YB
 #define ABRK_LAW6_YB 3  // rows of Y held at a time (2 was measured: 12 instead of 9 solves cost more than 16 B of scratch)
 #endif
-template <int N, class T, bool USE_C, int FEAT, class Rows>
+template <int N, class T, bool USE_C, int FEAT, class Rows, int QSTEPS = 3>
 ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
                        const T (&cvec)[N], const Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
                        const T (&dq)[N], const T (&tgt)[6], bool tv_given, const T (&tvin)[6], bool have_ierr,
                        T (&ierr)[6], bool have_ext, const T (&une)[N], T (&u)[N], T (&ts)[N], bool* defer = nullptr) {
   constexpr int KM = 6;
-  bool sel[KM];
-  sfor<KM>([&](auto r) ABRK_LAMBDA { sel[r()] = P.dof[r()] != 0; });
+  // ctrlr_dof is uniform over the launch.  With all six rows selected (the reference benchmark's UR5 setting) nothing
+  // is masked; the masked forms sit in blocks of their own behind scalar branches (ABRK_UNIFORM_BLOCK) instead of
+  // costing every launch two v_cndmask per `sel ? x : y`.
+  bool sel[KM], all_sel = true;
+  sfor<KM>([&](auto r) ABRK_LAMBDA {
+    sel[r()] = P.dof[r()] != 0;
+    all_sel = all_sel && sel[r()];
+  });
 
   ABRK_MARK("law6:task_forces");
   // desired task-space forces (osc.py:250-259)
@@ -1031,7 +1107,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   if (P.pos_on) sfor<3>([&](auto r) ABRK_LAMBDA { ut[r()] = p[r()] - tgt[r()]; });
   if (P.ori_on) {
     T abg[3] = {tgt[3], tgt[4], tgt[5]}, uo[3];
-    orientation_forces(P.alg, RF, abg, uo);
+    orientation_forces<T, QSTEPS>(P.alg, RF, abg, uo);
     sfor<3>([&](auto r) ABRK_LAMBDA { ut[3 + r()] = uo[r()]; });
   }
   // integral term (osc.py:262-264).  (A deferred row returns below without its state being stored.)
@@ -1043,12 +1119,12 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   }
   // gains / velocity limiting (osc.py:266-272, 198-215; constants osc.py:89-115)
   if (P.use_vmax) {
-    T sat_xyz = P.vmax0 / P.kp * P.kv, sat_abg = P.vmax1 / P.ko * P.kv;
+    T sat_xyz = P.sat_xyz, sat_abg = P.sat_abg;
     T nx = Rm<T>::sqrt(ut[0] * ut[0] + ut[1] * ut[1] + ut[2] * ut[2]);
     T na = Rm<T>::sqrt(ut[3] * ut[3] + ut[4] * ut[4] + ut[5] * ut[5]);
     T sx = (nx > sat_xyz) ? sat_xyz / nx : T(1);
     T sa = (na > sat_abg) ? sat_abg / na : T(1);
-    T lx = P.kp / P.kv, la = P.ko / P.kv;
+    T lx = P.lamb_xyz, la = P.lamb_abg;
     sfor<3>([&](auto r) ABRK_LAMBDA {
       ut[r()] = P.kv * sx * lx * ut[r()];
       ut[3 + r()] = P.kv * sa * la * ut[3 + r()];
@@ -1078,10 +1154,15 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     sfor<N>([&](auto i) ABRK_LAMBDA { u0[i()] = T(0); });
   }
   T uts[KM];
-  sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
+  sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = ut[r()]; });
+  if (!all_sel) {  // (a select, not a factor: an unselected target entry may be anything - osc.py:285 indexes it away)
+    ABRK_UNIFORM_BLOCK();
+    sfor<KM>([&](auto r) ABRK_LAMBDA { uts[r()] = sel[r()] ? ut[r()] : T(0); });
+  }
   // no training signal wanted (osc.py:297 is the only reader of u before gravity): u0 takes the gravity term now
   if constexpr (Rows::kNoTs) {
-    if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u0[i()] = Rm<T>::fma(gscale, gz[i()], u0[i()]); });
+    const T gsc = P.use_g ? gscale : T(0);  // uniform: a zero gain instead of N double selects
+    sfor<N>([&](auto i) ABRK_LAMBDA { u0[i()] = Rm<T>::fma(gsc, gz[i()], u0[i()]); });
   }
 
   // secondary controllers (osc.py:310-318): v with u_null = M v, and un = M v while M is at hand
@@ -1105,7 +1186,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   ABRK_MARK("law6:chol_M");
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T = Y Y^T, Y = J L^-T (rows y_r = L^-1 j_r)
   T L[N * (N + 1) / 2], il[N];
-  chol<N>(Ms, L, il);
+  chol<N, T, false>(Ms, L, il);
   if constexpr (FEAT >= 2) {
     if (have_ext) {  // caller-evaluated u_null: v_ext = M^-1 u_ext
       T y[N], w[N];
@@ -1152,12 +1233,15 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     });
   }
   T trace = T(0);
+  // a masked row of J is zero: so is its diagonal entry, which becomes the unit diagonal.  (Selects on purpose: a block
+  // behind a scalar branch at this spot - the register peak of the law - makes the allocator spill 70 values.)
   sfor<KM>([&](auto r) ABRK_LAMBDA {
-    trace += sel[r()] ? Am[tri(r(), r())] : T(0);
-    if (!sel[r()]) Am[tri(r(), r())] = T(1);
+    trace += Am[tri(r(), r())];
+    Am[tri(r(), r())] = sel[r()] ? Am[tri(r(), r())] : T(1);
   });
   T LA[KM * (KM + 1) / 2], ila[KM], Mx[KM * (KM + 1) / 2];
-  bool okA = chol<KM>(Am, LA, ila);
+  // unsanitised factor: LA / ila are only read where okA holds (every use below sits behind it or behind `truncates`)
+  bool okA = chol<KM, T, false>(Am, LA, ila);
   T det = T(1);
   sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
   bool mx_explicit = FEAT != 0, f_ready = false;
@@ -1167,22 +1251,35 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   if (!(okA && det >= thr)) {
     // pinv branch (osc.py:142-145); the two certificates of osc_law
     T bound = rcond;
-    sfor<KM>([&](auto r) ABRK_LAMBDA { bound *= sel[r()] ? trace : T(1); });
+    if (all_sel) {
+      sfor<KM>([&](auto r) ABRK_LAMBDA { bound *= trace; });
+    } else {
+      ABRK_UNIFORM_BLOCK();
+      sfor<KM>([&](auto r) ABRK_LAMBDA { bound *= sel[r()] ? trace : T(1); });
+    }
     bool truncates = !(okA && det > bound);
     if (truncates && okA) {
       // second certificate: trace(A) trace(A^-1) < 1 / rcond.  Without secondary controllers the inverse itself is
       // not needed (f comes from the factor): trace(A^-1) = |L^-1|_F^2 over the selected columns, half the work
       T tinv = T(0);
+      auto add_diag = [&](auto r, T cs) ABRK_LAMBDA {  // + (A^-1)_rr of a selected row
+        if (all_sel) {
+          tinv += cs;
+        } else {
+          ABRK_UNIFORM_BLOCK();
+          tinv += sel[r()] ? cs : T(0);
+        }
+      };
       if constexpr (FEAT == 0) {
         T Li[KM * (KM + 1) / 2];
         chol_factor_inverse<KM>(LA, ila, Li);
         sfor<KM>([&](auto r) ABRK_LAMBDA {
           T cs = T(-0.0);
           sfor<KM - r()>([&](auto kk) ABRK_LAMBDA { cs = Rm<T>::fma(Li[tri(r() + kk(), r())], Li[tri(r() + kk(), r())], cs); });
-          tinv += sel[r()] ? cs : T(0);
+          add_diag(r, cs);
         });
       } else {
-        sfor<KM>([&](auto r) ABRK_LAMBDA { tinv += sel[r()] ? Mx[tri(r(), r())] : T(0); });
+        sfor<KM>([&](auto r) ABRK_LAMBDA { add_diag(r, Mx[tri(r(), r())]); });
       }
       if (trace * tinv * rcond < T(1)) {
         truncates = false;
@@ -1275,7 +1372,8 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= cvec[i()]; });  // osc.py:291-292
   sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297 (kNoTs: not stored)
   if constexpr (!Rows::kNoTs) {
-    if (P.use_g) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gscale, gz[i()], u[i()]); });  // osc.py:300-301
+    const T gsc = P.use_g ? gscale : T(0);  // osc.py:300-301 (uniform: a zero gain instead of N double selects)
+    sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = Rm<T>::fma(gsc, gz[i()], u[i()]); });
   }
   if constexpr (FEAT >= 1) {
     if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += un[i()] - a2[i()]; });
@@ -1312,6 +1410,8 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   // SIMD -; one backward sweep (rne_backward) then projects the sums onto the joint axes.  (Until round 2 the
   // recursion ran as a pass of its own with a second forward kinematics: +128 instructions per row.)
   constexpr bool TWO_PASS = USE_C && !MAT && A::kOrtho && (ABRK_C_TWO_PASS != 0);
+  // the frame rotation of an orthogonal chain is a product of exact rotations: one power step in quat_from_R
+  constexpr int kQSteps = A::kOrthoFrames ? 1 : 3;
   Joints<A, T> jt;
   Dyn<A, T, MAT ? CMODE_MAT : (USE_C && !TWO_PASS) ? CMODE_VEC : CMODE_NONE> d;
   T cvm[(MAT && USE_C) ? N : 1];  // C dq from the matrix
@@ -1399,33 +1499,45 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
   } else {
     {
       // the six rows go to the row store (the LDS slab on the GPU - free again: rne_backward has read the wrenches)
+      // ctrlr_dof (rows) and the frame's joint count (columns) are uniform over the launch: scalar branches decide what
+      // is stored (vector selects `on ? val : 0` cost two v_cndmask per entry, twice: 116 of them on the UR5, 5 % of
+      // the first pass).  Only a kernel that also emits J (Mode F) needs the column mask on Jv / Jw themselves.
+      constexpr bool kEmits = !std::is_same<typename std::decay<Emit>::type, NoEmit>::value;
       T Jv[N][3], Jw[N][3];
-      jacobian(jt, p, m, Jv, Jw);
+      if constexpr (kEmits) jacobian(jt, p, m, Jv, Jw);
+      else jacobian(jt, p, N, Jv, Jw);
       emit(p, Jv, Jw, d, jt, m);
+      const bool cut_cols = !kEmits && m != N;
       sfor<6>([&](auto r) ABRK_LAMBDA {
-        const bool on = P.dof[r()] != 0;
         T row[N];
-        sfor<N>([&](auto i) ABRK_LAMBDA {
-          const T val = (r() < 3) ? Jv[i()][r() % 3] : Jw[i()][r() % 3];
-          row[i()] = on ? val : T(0);
-        });
-        scr.put_row(r, row);
+        if (P.dof[r()] != 0) {
+          sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = (r() < 3) ? Jv[i()][r() % 3] : Jw[i()][r() % 3]; });
+          if (cut_cols) {  // a frame below the last joint: columns m.. are zero
+            ABRK_UNIFORM_BLOCK();
+            sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = i() < m ? row[i()] : T(0); });
+          }
+          scr.put_row(r, row);
+        } else {
+          sfor<N>([&](auto i) ABRK_LAMBDA { row[i()] = T(0); });
+          scr.put_row(r, row);
+          ABRK_UNIFORM_BLOCK();  // after the stores: the two arms share no tail the optimiser could merge into selects
+        }
       });
       scr.seal();
     }
     ABRK_SCHED_FENCE();
     late();
     if constexpr (MAT && USE_C)
-      osc_law6<N, T, true, FEAT>(P, d.Ms, d.gz, T(9.81), cvm, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+      osc_law6<N, T, true, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), cvm, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
                                  have_ext, une, u, ts, scr.defer_ptr());
     else if constexpr (TWO_PASS)
-      osc_law6<N, T, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+      osc_law6<N, T, true, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), cv2, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
                                  have_ext, une, u, ts, scr.defer_ptr());
     else if constexpr (USE_C)
-      osc_law6<N, T, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+      osc_law6<N, T, true, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), d.cv, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
                                  have_ext, une, u, ts, scr.defer_ptr());
     else
-      osc_law6<N, T, false, FEAT>(P, d.Ms, d.gz, T(9.81), d.gz, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
+      osc_law6<N, T, false, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), d.gz, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
                                   have_ext, une, u, ts, scr.defer_ptr());
   }
 }

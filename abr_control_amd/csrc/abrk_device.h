@@ -45,6 +45,12 @@
 #else
 #define ABRK_MARK(name) ((void)0)
 #endif
+// Inside a block guarded by a condition that is UNIFORM over the launch (a controller parameter): keeps the block a real
+// branch.  Left alone the compiler if-converts such blocks into vector selects - two v_cndmask per double, each as
+// expensive as an FMA on gfx950 (tools/microbench/valu_rates.hip) - or, asked for 0 / 1 factors instead, parks the
+// factors in scalar registers across the six-row kernel's persistent loop, which runs out of them (v_readlane per use).
+// A scalar branch costs the vector pipeline nothing.
+#define ABRK_UNIFORM_BLOCK() asm volatile("")
 #ifndef ABRK_SINCOS_AHEAD
 #define ABRK_SINCOS_AHEAD 1
 #endif
@@ -309,6 +315,8 @@ struct StaticArm {
     return true;
   }
   static constexpr bool kOrtho = compute_ortho();
+  // every frame rotation the chain can report (links, joints, EE) is a product of exact rotations
+  static constexpr bool kOrthoFrames = kOrtho && (!kHasEE || aff_is_orthogonal(Tab::E));
   // every static block rotates about z only: all joint axes are the world z axis and the z row of every
   // linear Jacobian is identically zero (twojoint, threejoint, onejoint)
   static constexpr bool aff_is_planar(const double* X) {
@@ -341,6 +349,7 @@ struct RtArm {
   static constexpr int N = NJ;
   static constexpr bool kStatic = false;
   static constexpr bool kOrtho = false;  // always differentiate the general affine chain
+  static constexpr bool kOrthoFrames = false;
   static constexpr bool kPlanar = false;
   static constexpr bool ortho_joint(int) { return false; }
   int NL;
@@ -1082,10 +1091,12 @@ ABRK_INL void jacobian(const Joints<A, T>& jt, const T (&p)[3], int m, T (&Jv)[A
     T dlt[3] = {p[0] - jt.o[i()][0], p[1] - jt.o[i()][1], p[2] - jt.o[i()][2]};
     T e[3];
     wapply<i()>(jt, dlt, e);
-    bool on = i() < m;
+    // m is uniform over the launch: a 0 / 1 factor from a scalar select (one v_mul per entry) instead of a vector
+    // select per entry (two v_cndmask for a double); folds away where m is the compile-time N
+    const T on = i() < m ? T(1) : T(0);
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      Jv[i()][r()] = on ? e[r()] : T(0);
-      Jw[i()][r()] = on ? jt.z[i()][r()] : T(0);
+      Jv[i()][r()] = on * e[r()];
+      Jw[i()][r()] = on * jt.z[i()][r()];
     });
   });
 }
@@ -1111,10 +1122,10 @@ ABRK_INL void jacobian_dot(const Joints<A, T>& jt, const T (&dq)[A::N], const T 
     wapply<j>(jt, s, t1);
     omega_apply<j>(jt, tmp, dq, Jv[j], t2);
     omega_apply<j>(jt, tmp, dq, jt.z[j], t3);
-    bool on = j < m;
+    const T on = j < m ? T(1) : T(0);  // uniform: see jacobian()
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      dJv[j][r()] = on ? t1[r()] + t2[r()] : T(0);
-      dJw[j][r()] = on ? t3[r()] : T(0);
+      dJv[j][r()] = on * (t1[r()] + t2[r()]);
+      dJw[j][r()] = on * t3[r()];
     });
   });
 }

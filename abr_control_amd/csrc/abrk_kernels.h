@@ -201,6 +201,9 @@ struct LdsScratch : ScratchBase {
 #ifndef ABRK_KM6_GRID_CAP
 #define ABRK_KM6_GRID_CAP 4096  // first pass of the six-row law: a persistent grid of at most this many blocks (a multiple of kWlLists)
 #endif
+#ifndef ABRK_KM6_P1_LOOP
+#define ABRK_KM6_P1_LOOP 0  // measurement switch: 1 = the first pass as a persistent grid too (rounds 2-3)
+#endif
 constexpr int kWlLists = 256;
 constexpr long wl_capacity(long B) { return ((B + kBlock - 1) / kBlock / kWlLists + 1) * kBlock; }  // rows per sub-list
 constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(B); }
@@ -255,7 +258,15 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       go(scr);
     }
   };
-  if constexpr (KM == 6) {
+  if constexpr (KM == 6 && PASS == 1 && (ABRK_KM6_P1_LOOP == 0)) {
+    // first pass at two waves per SIMD: one row per lane, no loop.  The second wavefront of the SIMD hides a row's
+    // memory round trips, and outside a loop nothing is hoisted: in the persistent-loop form the compiler keeps the
+    // row program's literals and the controller's parameters in scalar registers across iterations, runs out of them
+    // (116 spilled to vector-register lanes: 190 v_readlane per row, each a vector-ALU slot) and holds 40 hoisted
+    // vector constants on top.
+    ABRK_ROW_INDEX
+    row(b, true);
+  } else if constexpr (KM == 6) {
     // one call site for the row program (it is inlined): modes 0 / 1 launch one lane per row and leave the loop after
     // their row, mode 2 strides a persistent grid over the worklist.  (Only the six-row kernels defer: with x,y,z
     // alone the two certificates leave < 0.01 % of the rows to the sweeps, and the loop form costs the three-row
@@ -558,7 +569,8 @@ struct Launch {
         // stale counters would let pass 1 append past its sub-lists: no launch without the memset
         if (hipError_t e = hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream); e != hipSuccess) return e;
         dim3 g1 = grid_for(la.B);
-        if (ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;  // a multiple of kWlLists
+        // (the persistent-grid form of the first pass: a multiple of kWlLists)
+        if (ABRK_KM6_P1_LOOP && ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;
         if (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0) && !a.ts) go_nots(g1);
         else go(ic<1>{}, g1, 1);
         go(ic<0>{}, dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list

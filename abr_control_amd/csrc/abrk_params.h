@@ -35,6 +35,12 @@ inline OscP<T> make_oscp(const abrk_osc_params& s, int n) {
   p.ki = T(s.ki);
   p.vmax0 = T(s.vmax[0]);
   p.vmax1 = T(s.vmax[1]);
+  if (s.use_vmax) {  // the kernels' own expressions, in their arithmetic type
+    p.sat_xyz = p.vmax0 / p.kp * p.kv;
+    p.sat_abg = p.vmax1 / p.ko * p.kv;
+    p.lamb_xyz = p.kp / p.kv;
+    p.lamb_abg = p.ko / p.kv;
+  }
   p.use_vmax = s.use_vmax;
   p.use_g = s.use_g;
   p.alg = s.orientation_algorithm;

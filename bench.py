@@ -244,8 +244,9 @@ class Runner:
             blocks = min(blocks, 256 * 32 * 4)
         elif self.kind == "obstacles":
             blocks = min(blocks, 4096)
-        elif self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name() and self.B >= 16384:
-            blocks = min(blocks, 4096)
+        elif (self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name() and self.B >= 16384
+              and os.environ.get("ABRK_BENCH_KM6_P1_LOOP")):
+            blocks = min(blocks, 4096)  # a library built with -DABRK_KM6_P1_LOOP=1 (the first pass as a persistent grid)
         return blocks * 64
 
     def step(self):

@@ -58,8 +58,8 @@ def _lib_for(arm=None, law=False):
         n = arm["n_joints"]
         part = "rt13" if n <= 3 else "rt45" if n <= 5 else "rt6" if n == 6 else "rt7"
     if part not in _libs:
-        if not os.path.exists(_so(part)):
-            build()
+        if not _libs:
+            build()  # once per process: rebuilds the parts that are older than hostsim.cpp or a kernel header
         _libs[part] = C.CDLL(_so(part))
     return _libs[part]
 
