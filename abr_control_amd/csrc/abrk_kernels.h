@@ -204,6 +204,11 @@ struct LdsScratch : ScratchBase {
 #ifndef ABRK_KM6_P1_LOOP
 #define ABRK_KM6_P1_LOOP 0  // measurement switch: 1 = the first pass as a persistent grid too (rounds 2-3)
 #endif
+// the first pass of the six-row law as one row per lane (no persistent grid): where it holds two waves per SIMD - a
+// one-wave first pass (general chains) keeps the loop, whose next row hides the stores of the last
+constexpr bool km6_first_pass_plain(int km, bool use_c, int feat, bool ortho, int pass, bool is_static) {
+  return km == 6 && pass == 1 && !ABRK_KM6_P1_LOOP && osc_min_waves(km, use_c, feat, ortho, pass, is_static) >= 2;
+}
 constexpr int kWlLists = 256;
 constexpr long wl_capacity(long B) { return ((B + kBlock - 1) / kBlock / kWlLists + 1) * kBlock; }  // rows per sub-list
 constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(B); }
@@ -258,7 +263,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       go(scr);
     }
   };
-  if constexpr (KM == 6 && PASS == 1 && (ABRK_KM6_P1_LOOP == 0)) {
+  if constexpr (km6_first_pass_plain(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic)) {
     // first pass at two waves per SIMD: one row per lane, no loop.  The second wavefront of the SIMD hides a row's
     // memory round trips, and outside a loop nothing is hoisted: in the persistent-loop form the compiler keeps the
     // row program's literals and the controller's parameters in scalar registers across iterations, runs out of them
@@ -296,7 +301,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 #define ABRK_VEL_WAVES ABRK_MIN_WAVES  // measurement switch: 2 caps the C / dJ variant at 256 registers (364-424 B of scratch)
 #endif
 template <class A, class T, int KM, bool USE_C, int FEAT, bool VEL = false>
-__global__ void __launch_bounds__(kBlock, VEL ? (ABRK_VEL_WAVES) : osc_min_waves(KM, USE_C, FEAT, A::kOrtho))
+__global__ void __launch_bounds__(kBlock, VEL ? (ABRK_VEL_WAVES) : osc_min_waves(KM, USE_C, FEAT, A::kOrtho, 0, A::kStatic))
 osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                 const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
                 const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, unsigned want, DynOutP<T> out) {
@@ -570,7 +575,8 @@ struct Launch {
         if (hipError_t e = hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream); e != hipSuccess) return e;
         dim3 g1 = grid_for(la.B);
         // (the persistent-grid form of the first pass: a multiple of kWlLists)
-        if (ABRK_KM6_P1_LOOP && ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;
+        constexpr bool plain = km6_first_pass_plain(KM, UC, FEAT, A::kOrtho, 1, A::kStatic);
+        if (!plain && ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;
         if (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0) && !a.ts) go_nots(g1);
         else go(ic<1>{}, g1, 1);
         go(ic<0>{}, dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
