@@ -122,7 +122,8 @@ ABRK_INL bool chol(const T (&S)[K * (K + 1) / 2], T (&L)[K * (K + 1) / 2], T (&i
 // cycles, four FMAs' worth), no pivot selects, and the inverse itself - which the null-space filter and the second
 // certificate of the pinv branch want anyway - instead of two triangular solves: ~40 issue slots for the x,y,z law
 // against ~95.  ok = positive definite (leading minors); the entries carry a relative error of cond(A) eps like the
-// factor's.  When !ok, Inv is the adjugate (finite, unused by the callers).
+// factor's while ONE eigenvalue is small, of cond^2 eps when two are: the caller gates on trace^K / det (osc_law).
+// When !ok, Inv is the adjugate (finite, unused by the callers).
 template <int K, class T>
 ABRK_INL bool spd_inverse_small(const T (&A)[K * (K + 1) / 2], T (&Inv)[K * (K + 1) / 2], T& det) {
   static_assert(K == 2 || K == 3, "closed forms for 2 x 2 and 3 x 3");
@@ -888,11 +889,27 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   ABRK_MARK("law3:cholA_cert");
   T LA[KM * (KM + 1) / 2], ila[KM], Mx[KM * (KM + 1) / 2];
   // x,y,z / x,y: Mx by cofactors (spd_inverse_small); otherwise through the Cholesky factor of Mx_inv
-  constexpr bool kClosed = FAST && (ABRK_SMALL_INVERSE != 0);
+  // (fp64 only: the cofactors carry a relative error of eps * trace^K / det - see below -, which single precision
+  //  cannot afford on the everyday rows)
+  constexpr bool kClosed = FAST && (ABRK_SMALL_INVERSE != 0) && sizeof(T) == 8;
   bool okA;
   T det = T(1);
   if constexpr (kClosed) {
     okA = spd_inverse_small<KM>(Am, Mx, det);
+    // Accuracy gate.  Cofactors are differences of products of entries of size |A|, so adj(A) and det carry an absolute
+    // error of eps |A|^(K-1) and eps |A|^K: relative to det that is eps * trace^K / det - as good as a factorisation
+    // (eps * cond) while one eigenvalue is small, eps * cond^2 when two are.  Up to trace^K / det = 1e6 (error <=
+    // 1e-9; none of 12 288 golden rows of the built-in arms is above 1e5, and whatever passes the first certificate is
+    // below 1e4) the cofactor result stands; beyond it - rows deep in the pinv branch, nearly all of which go on to the
+    // eigen-decomposition anyway - the Cholesky factor is taken after all (cold code).
+    T tk = trace;
+    sfor<KM - 1>([&](auto) ABRK_LAMBDA { tk *= trace; });
+    if (!(okA && det * T(1e6) >= tk)) {
+      okA = chol<KM>(Am, LA, ila);
+      det = T(1);
+      sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
+      chol_inverse<KM>(LA, ila, Mx);
+    }
   } else {
     okA = chol<KM>(Am, LA, ila);
     sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });

@@ -599,6 +599,90 @@ def check_six_row_use_C(backend, arm="ur5", B=400):
     return worst
 
 
+_NEAR_SINGULAR = {}
+
+
+def near_singular_postures(arm="ur5", B=600):
+    """B joint states of `arm` whose x,y,z task-space inertia is nearly singular, the ratio of its extreme singular
+    values spread evenly (in the exponent) over 1e-13 .. 3e-3: the iterates of a seeded Nelder-Mead descent on that ratio
+    from random postures (the oracle evaluates it).  Deterministic; cached per process."""
+    if (arm, B) in _NEAR_SINGULAR:
+        return _NEAR_SINGULAR[(arm, B)]
+    from scipy.optimize import minimize
+
+    from oracle.oracle import Oracle
+
+    o = Oracle(_abi.load_table(arm))
+    n = o.n
+
+    def ratio(q):
+        J = o.J("EE", q, None)[:3]
+        sv = np.linalg.svd(J @ np.linalg.inv(o.M(q)) @ J.T, compute_uv=False)
+        return sv.min() / sv.max()
+
+    rng = np.random.RandomState(23)
+    seen = []
+
+    def f(q):
+        r = ratio(q)
+        seen.append((r, q.copy()))
+        return np.log(r + 1e-300)
+
+    for _ in range(40):
+        minimize(f, rng.uniform(0, 6.28, n), method="Nelder-Mead", options=dict(maxiter=600, xatol=1e-12, fatol=1e-12))
+    r = np.array([x[0] for x in seen])
+    qs = np.array([x[1] for x in seen])
+    keep = (r < 3e-3) & (r > 1e-13)
+    r, qs = r[keep], qs[keep]
+    bins = np.clip(((np.log10(r) + 13) / (13 + np.log10(3e-3)) * 30).astype(int), 0, 29)
+    pick = []
+    for b in range(30):
+        idx = np.flatnonzero(bins == b)
+        pick += list(rng.choice(idx, min(len(idx), B // 30), replace=False))
+    q = qs[np.array(pick)]
+    _NEAR_SINGULAR[(arm, B)] = q
+    return q
+
+
+def check_near_singular_postures(backend, arm="ur5", B=600):
+    """the x,y,z law on postures that approach the arm's kinematic singularities (near_singular_postures): Mx_inv
+    there has one or two eigenvalues far below the others, i.e. exactly where the cofactor form of Mx loses accuracy
+    and osc_law falls back to its Cholesky factor (trace^3 / det > 1e6) - and where the truncating pinv takes over.
+    Against the oracle; rows within 1e-8 of a threshold of `_Mx` are excluded, and so are rows whose kept part of
+    Mx_inv is itself ill-conditioned beyond 1e7 (neither side is good to 1e-6 there).
+    -> (worst relative error, number of rows beyond the accuracy gate, number of truncating rows)"""
+    from oracle.oracle import Oracle
+
+    o = Oracle(_abi.load_table(arm))
+    n = o.n
+    q = near_singular_postures(arm, B)
+    B = q.shape[0]
+    rng = np.random.RandomState(29)
+    dq, t = rng.uniform(-2, 2, (B, n)), rng.uniform(-0.8, 0.8, (B, 6))
+    worst, beyond, trunc = 0.0, 0, 0
+    for kw in (dict(kp=200), dict(kp=120, kv=15, use_C=True, null_controllers=[make_damping(8)])):
+        p = P(n, **kw)
+        uo = o.osc_batch(p, q, dq, t, None, None, None)
+        u, _ = backend.osc(p, q, dq, t)
+        ok = np.ones(B, bool)
+        for b in range(B):
+            J = o.J("EE", q[b], None)[:3]
+            A = J @ np.linalg.inv(o.M(q[b])) @ J.T
+            sv = np.linalg.svd(A, compute_uv=False)
+            det = abs(np.linalg.det(A))
+            ratio = sv / sv.max()
+            near = abs(det - 1e-3) < 1e-8 or (det < 1.001e-3 and np.any(np.abs(ratio - 1e-4) < 1e-8))
+            kept = ratio[ratio > 1e-4] if det < 1e-3 else ratio
+            ok[b] = not near and kept.min() > 1e-7
+            beyond += int(np.trace(A) ** 3 > 1e6 * det)
+            trunc += int(det < 1e-3 and ratio.min() < 1e-4)
+        assert ok.sum() > B // 2, f"near-singular set filtered too hard ({ok.sum()}/{B})"
+        err = rel_err(np.asarray(u, float), uo)[ok].max()
+        assert err <= TOL_D, f"{arm} near-singular {kw}: {err:.3e}"
+        worst = max(worst, err)
+    return worst, beyond, trunc
+
+
 # ---------------------------------------------------------------------------- seeded fuzz: Sliding / Joint / dynamics
 def check_fuzz_other(backend_factory, seed, B=64):
     """Sliding (Cartesian with frames/offsets/velocity+acceleration targets, joint space), Joint, Damping,

@@ -236,6 +236,17 @@ def sym6_eig(A, method):
     return lam, V
 
 
+def spd_inverse_small(A):
+    """the device code's cofactor inverse of a symmetric 2 x 2 / 3 x 3 matrix (abrk_ctrl.h `spd_inverse_small`, the
+    task-space inertia of the x,y,z / x,y law): A [B,K,K] -> (inv [B,K,K], det [B], ok [B] bool)"""
+    A = _in(A, np.dtype(np.float64))
+    B, K = A.shape[0], A.shape[1]
+    inv, det, ok = np.full((B, K, K), np.nan), np.full(B, np.nan), np.zeros(B, np.int32)
+    rc = _lib_for(law=True).hostsim_spd_inverse_small(int(K), C.c_int64(B), _p(A), _p(inv), _p(det), _p(ok))
+    assert rc == 0, rc
+    return inv, det, ok.astype(bool)
+
+
 def sym3_eig(A, dtype=np.float64):
     """the device code's direct symmetric 3x3 eigen-solver (abrk_ctrl.h `sym3_eig`): -> (lam [B,3], V [B,3,3])"""
     dt = np.dtype(dtype)

@@ -316,6 +316,32 @@ extern "C" int hostsim_sym6_eig(int method, int64_t B, const double* A, double* 
   }
   return 0;
 }
+// the cofactor inverse of the x,y,z / x,y law (abrk_ctrl.h `spd_inverse_small`): A [B,K,K] symmetric -> inv [B,K,K],
+// det [B], ok [B]
+extern "C" int hostsim_spd_inverse_small(int K, int64_t B, const double* A, double* inv, double* det, int* ok) {
+  for (long b = 0; b < B; b++) {
+    if (K == 3) {
+      double S[6], I[6], d;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c <= r; c++) S[tri(r, c)] = A[b * 9 + r * 3 + c];
+      ok[b] = spd_inverse_small<3, double>(S, I, d) ? 1 : 0;
+      det[b] = d;
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) inv[b * 9 + r * 3 + c] = I[tri(r > c ? r : c, r > c ? c : r)];
+    } else if (K == 2) {
+      double S[3], I[3], d;
+      for (int r = 0; r < 2; r++)
+        for (int c = 0; c <= r; c++) S[tri(r, c)] = A[b * 4 + r * 2 + c];
+      ok[b] = spd_inverse_small<2, double>(S, I, d) ? 1 : 0;
+      det[b] = d;
+      for (int r = 0; r < 2; r++)
+        for (int c = 0; c < 2; c++) inv[b * 4 + r * 2 + c] = I[tri(r > c ? r : c, r > c ? c : r)];
+    } else {
+      return -1;
+    }
+  }
+  return 0;
+}
 extern "C" int hostsim_sym3_eig(int dtype, int64_t B, const void* A, void* lam, void* V) {
   auto run = [&](auto tag) {
     using T = decltype(tag);

@@ -1762,3 +1762,11 @@ def test_gpu_concurrent_threads_own_streams():
     for th in ths:
         th.join()
     assert not errors, errors
+
+
+def test_gpu_three_row_law_near_singular_postures():
+    """the x,y,z law where Mx_inv is nearly singular (elbow stretched / folded to 1e-2 .. 1e-9 rad): the cofactor form
+    of Mx hands over to the Cholesky factor there (osc_law's accuracy gate) and the truncating pinv takes most rows"""
+    worst, beyond, trunc = cases.check_near_singular_postures(cases.GpuBackend("ur5"))
+    assert beyond > 100 and trunc > 100, (beyond, trunc)
+    assert worst < 1e-6

@@ -533,3 +533,47 @@ def test_rows_direct_sym3_eigensolver():
     lam32, V32 = hostsim.sym3_eig(A, dtype=np.float32)
     assert (np.abs(np.sort(lam32, axis=1) - ref).max(axis=1) / scale).max() < 2e-5
     assert np.abs(np.einsum("bij,bik->bjk", V32, V32) - np.eye(3)).max() < 1e-5
+
+
+def test_rows_cofactor_inverse_of_the_three_row_law():
+    """`spd_inverse_small` (abrk_ctrl.h): the x,y,z / x,y law takes Mx = (J M^-1 J^T)^-1 (osc.py:135-141) by cofactors
+    instead of a Cholesky factor.  Cofactors carry a relative error of eps * trace^K / det (eps * cond while one
+    eigenvalue is small, eps * cond^2 when two are), which is why osc_law only keeps the result up to trace^K / det =
+    1e6 and factorises beyond.  Against numpy.linalg.inv / det on graded SPD matrices: inside the gate the entries are
+    good to 8 eps trace^K / det of |A^-1| (<= 2e-9) and det to the same; indefinite, singular and NaN matrices are
+    refused (ok = False), which sends the row to the pinv branch."""
+    from tests import hostsim as hs
+
+    rng = np.random.RandomState(5)
+    for K in (3, 2):
+        mats = []
+        for logc in (0, 1, 2, 3, 4, 6) if K == 3 else (0, 2, 4, 6, 8, 10):
+            for _ in range(300):
+                Q, _r = np.linalg.qr(rng.randn(K, K))
+                lam = np.concatenate([[1.0], 10.0 ** (-logc * rng.uniform(0.3, 1.0, K - 1))]) * 10.0 ** rng.uniform(-3, 3)
+                mats.append((Q * lam) @ Q.T)
+        A = np.array([(m + m.T) / 2 for m in mats])
+        inv, det, ok = hs.spd_inverse_small(A)
+        assert ok.all()
+        ref, dref = np.linalg.inv(A), np.linalg.det(A)
+        amp = np.trace(A, axis1=1, axis2=2) ** K / dref  # the gate's quantity
+        gate = amp <= 1e6
+        assert gate.sum() > 600 and (~gate).sum() > 100  # both sides of the gate are exercised
+        err = np.abs(inv - ref).max(axis=(1, 2)) / np.abs(ref).max(axis=(1, 2))
+        bound = 8 * 2.3e-16 * amp + 1e-15
+        assert (err[gate] <= bound[gate]).all(), (K, (err[gate] / bound[gate]).max())
+        assert (np.abs(det / dref - 1)[gate] <= bound[gate]).all()
+        assert err[gate].max() < 2e-9
+        assert np.array_equal(inv, np.swapaxes(inv, 1, 2))  # symmetric by construction
+        bad = np.array([np.diag([1.0, -1.0, 2.0][:K]), np.zeros((K, K)), np.full((K, K), np.nan),
+                        np.ones((K, K)), -np.eye(K)])
+        _i, _d, okb = hs.spd_inverse_small(bad)
+        assert not okb.any()
+
+
+def test_rows_three_row_law_near_singular_postures():
+    """cases.check_near_singular_postures on the host build of the row programs: both sides of the cofactor / Cholesky
+    gate of osc_law and the truncating pinv behind it are taken"""
+    worst, beyond, trunc = cases.check_near_singular_postures(cases.HostsimBackend("ur5"))
+    assert beyond > 100 and trunc > 100, (beyond, trunc)
+    assert worst < 1e-6
