@@ -329,15 +329,23 @@ class Runner:
         if self.plan is not None and 8 <= steps < self.graph_steps:
             self.graph_steps = steps  # a short run is one graph of exactly K nodes
         graph = self.used_graph = self.plan is not None and self.graph_steps > 1 and steps >= self.graph_steps
+        # measurement switch (tools/gpu_latency_r3.sh): a short run as `head` plain launches followed by ONE graph of the
+        # remaining K - head nodes - does the GPU-side lead-in of a graph launch hide behind kernels already running?
+        head = int(os.environ.get("ABRK_BENCH_HEAD", "0")) if graph and steps == self.graph_steps else 0
+        head = min(head, max(steps - 2, 0))
         for _ in range(warmup):
             self.step()
         if graph:  # builds (captures + instantiates) the graph outside the timed region; untimed extra steps
-            self.plan.launch_graph(self.graph_steps)
+            self.plan.launch_graph(self.graph_steps - head)
         self.stream.sync()
         ev0, ev1 = a.Event(self.device), a.Event(self.device)
 
         def k_steps():
-            if graph:
+            if graph and head:
+                for _ in range(head):
+                    self.step()
+                self.plan.launch_graph(steps - head)
+            elif graph:
                 # K steps as ceil(K/G) hipGraph launches of G kernel nodes each (+ a remainder of plain launches)
                 for _ in range(steps // self.graph_steps):
                     self.plan.launch_graph(self.graph_steps)

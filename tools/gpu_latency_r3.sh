@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r3lat; mkdir -p $O
 run() { tag=$1; shift
-  for rep in 1 2 3; do env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-leg --no-strong-leg --no-extras > $O/${tag}_$rep.json 2>/dev/null; done
+  for rep in 1 2 3; do env "$@" python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline-leg --no-strong-leg --no-extras --no-streams-leg > $O/${tag}_$rep.json 2>/dev/null; done
   python - "$tag" <<'PY'
 import json, sys
 tag = sys.argv[1]
@@ -15,3 +15,7 @@ run blocking_sync X=1
 run polling_sync ABRK_SYNC_SPIN=1
 run eager ABRK_BENCH_GRAPH=0
 run eager_polling ABRK_BENCH_GRAPH=0 ABRK_SYNC_SPIN=1
+run head1 ABRK_BENCH_HEAD=1
+run head2 ABRK_BENCH_HEAD=2
+run head3 ABRK_BENCH_HEAD=3
+run head5 ABRK_BENCH_HEAD=5
