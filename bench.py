@@ -333,6 +333,7 @@ class Runner:
         # remaining K - head nodes - does the GPU-side lead-in of a graph launch hide behind kernels already running?
         head = int(os.environ.get("ABRK_BENCH_HEAD", "0")) if graph and steps == self.graph_steps else 0
         head = min(head, max(steps - 2, 0))
+        repeat_c = self.plan is not None and os.environ.get("ABRK_BENCH_REPEAT_C") == "1"
         for _ in range(warmup):
             self.step()
         if graph:  # builds (captures + instantiates) the graph outside the timed region; untimed extra steps
@@ -341,7 +342,9 @@ class Runner:
         ev0, ev1 = a.Event(self.device), a.Event(self.device)
 
         def k_steps():
-            if graph and head:
+            if repeat_c:
+                self.plan.launch_repeat(steps)  # K plain launches enqueued by ONE C call (abrk_plan_launch_repeat)
+            elif graph and head:
                 for _ in range(head):
                     self.step()
                 self.plan.launch_graph(steps - head)
