@@ -1,7 +1,7 @@
 """Joint-space PD controller (abr_control/controllers/joint.py:8-131), angle states."""
 import numpy as np
 
-from .. import _abi, engine
+from .. import _abi
 from .controller import Controller
 
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from abr_control_amd import _abi, specialize
-from abr_control_amd._lib import AbrkError, check, lib
+from abr_control_amd._lib import check, lib
 from tests import compiled_arms
 
 

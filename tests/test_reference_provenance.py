@@ -7,7 +7,6 @@ Build container only (needs /root/reference, which does not exist on the GPU box
     (the fixtures every parity test is pinned to really are outputs of the reference).
 The arm regenerated is `onejoint` (the cheapest: ~1 min including the reference's SymPy code generation when its
 function cache is cold); set ABRK_PROVENANCE_ARMS="twojoint,ur5" to regenerate others (minutes each)."""
-import json
 import os
 import shutil
 import subprocess
