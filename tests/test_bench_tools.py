@@ -78,14 +78,14 @@ def test_summarize_profiles_keys_grid_stride_kernels_by_rows(tmp_path):
 
 
 def test_timing_plots_replica_settings_have_a_staged_reference_workload():
-    """tools/timing_plots_replica.py times the reference's published benchmark on both sides: every setting names a
+    """tests/timing_plots_replica.py times the reference's published benchmark on both sides: every setting names a
     workload oracle/time_reference.py knows (so that oracle/stage_reference.py staged its functions), for an arm this
     package ships, with the keyword arguments of examples/timing_plots.py:34-39"""
     import importlib.util
 
     from oracle import time_reference
 
-    spec = importlib.util.spec_from_file_location("tp_replica", os.path.join(REPO, "tools", "timing_plots_replica.py"))
+    spec = importlib.util.spec_from_file_location("tp_replica", os.path.join(REPO, "tests", "timing_plots_replica.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert [s[0] for s in mod.SETTINGS] == ["Two joint", "UR5", "Jaco2"]

@@ -17,7 +17,8 @@ Three figures per setting:
     per-state figure;
   * `reference`: the staged reference (oracle/_ref, oracle/time_reference.py) on one host core of this machine, timed by
     the same per-state loop.
-MEASUREMENT TOOLING; run on the GPU box (tools/gpu_timing_plots.sh).  Usage: timing_plots_replica.py [out.json]
+MEASUREMENT TOOLING of the test side (it lives under tests/ because it runs the staged reference through oracle/, which
+only tests/, smoke() and bench.py's cpu_baseline leg may touch); run on the GPU box (tools/gpu_timing_plots.sh).  Usage: timing_plots_replica.py [out.json]
 """
 import importlib
 import json
