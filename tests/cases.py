@@ -323,10 +323,22 @@ def check_case_against_golden(backend, case_id, g, dtype=np.float64, rows=None):
     if case["arm"] == "threejoint" and dtype == np.float64:
         tol = TOL_THREEJOINT
     if dtype != np.float64:
-        # fp32 arithmetic: conditioning of Mx_inv amplifies rounding; keep well-conditioned rows
+        # fp32 arithmetic: conditioning of Mx_inv amplifies rounding; keep well-conditioned rows.  Three task rows:
+        # cond < 1e3.  Six rows mix metres and radians - cond(Mx_inv) starts at ~1e3 - so the gate is 1e4 there (observed
+        # error <= 1.6e-8 cond on the golden sets), and every row up to cond 1e6 that does not truncate is held to
+        # 1e-7 cond on top, so that the ill-conditioned rows are not simply dropped.
         if f"{key}_sv" in g:
             sv = g[f"{key}_sv"][sl]
-            ok &= (sv.max(1) / np.maximum(sv.min(1), 1e-300)) < 1e3
+            cond = sv.max(1) / np.maximum(sv.min(1), 1e-300)
+            six = sv.shape[1] > 3
+            if six:
+                trunc32 = truncating_rows(g, key)[sl]
+                wide = ok & (cond < 1e6) & ~trunc32
+                assert wide.sum() >= 0.5 * len(cond), f"{case_id}: only {wide.sum()} of {len(cond)} rows compared"
+                bad = rD[wide] > np.maximum(tol, 1e-7 * cond[wide])
+                assert not bad.any(), f"{case_id} [{backend.name}]: fp32 error above 1e-7 cond on {bad.sum()} rows"
+            ok &= cond < (1e4 if six else 1e3)
+            assert ok.sum() >= 0.25 * len(cond), f"{case_id}: only {ok.sum()} of {len(cond)} well-conditioned rows"
     worst = rD[ok].max() if ok.any() else 0.0
     assert worst <= tol, f"{case_id} [{backend.name}]: max rel err vs Oracle-D {worst:.3e} > {tol}"
     if "ts" in extra and extra["ts"] is not None and f"{key}_tsD" in g and dtype == np.float64:

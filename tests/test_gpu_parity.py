@@ -72,6 +72,56 @@ def test_gpu_fp32_config5_full_size():
     assert cases.rel_err(u64[:4096], uo).max() <= 1e-6
 
 
+# float32 is the reference's own shipped precision for J, M, g, C, dJ, R (base_config.py:223,247,270,285,301,336): every
+# `float` instantiation a user reaches through Config(dtype=np.float32) meets the reference's outputs on the device
+FP32_CASES = ["twojoint:cfg1", "ur5:cfg2", "ur5:cfg4", "jaco2:cfg3", "ur5:osc6_alg0", "jaco2:osc6_alg1", "ur5:osc_null2",
+              "ur5:osc_xyz_tvel", "ur5:joint", "jaco2:damping", "ur5:sliding", "threejoint:cfg5"]
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("case_id", FP32_CASES)
+def test_gpu_fp32_kernels_match_reference(case_id, variant):
+    """the fp32 OSC / Joint / Sliding kernels against the reference's fp64 formulas at TOL_F32 = 1e-4 on the rows whose
+    Mx_inv is well conditioned (cases.check_case_against_golden: cond < 1e3, six task rows < 1e4 + a cond-scaled bound)"""
+    arm = cases.CASES[case_id]["arm"]
+    r = cases.check_case_against_golden(cases.GpuBackend(arm, variant), case_id, golden(arm), dtype=np.float32)
+    assert r["worst_vs_D"] <= cases.TOL_F32
+
+
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("arm", DYN_ARMS)
+def test_gpu_fp32_dynamics_match_reference(arm, variant):
+    """every robot_config function of every frame in fp32 (2e-4 of the array's scale)"""
+    cases.check_dynamics_against_golden(cases.GpuBackend(arm, variant), arm, golden(arm), dtype=np.float32)
+
+
+def test_gpu_fp32_config2_full_size_vs_fp64_kernel():
+    """2^20 rows of BASELINE config 2's law: the float kernel against the double kernel (itself pinned to the reference)
+    on the rows whose 3 x 3 Mx_inv is well conditioned, and bounded by its conditioning on all others"""
+    be = cases.GpuBackend("ur5")
+    p = _abi.make_osc_params(6, kp=200)
+    B = 1 << 20
+    q, dq, t = draw(7, B, 6)
+    q32, dq32, t32 = (a.astype(np.float32) for a in (q, dq, t))
+    u32, _ = be.osc(p, q32, dq32, t32, dtype=np.float32)
+    # the same float32-representable states through the double kernel: what is compared is the arithmetic
+    u64, _ = be.osc(p, q32.astype(float), dq32.astype(float), t32.astype(float))
+    assert u32.dtype == np.float32 and np.all(np.isfinite(u32))
+    r = be.dynamics(q32.astype(float), None, "EE", None, ("J", "M"))
+    A = np.einsum("bij,bjk,blk->bil", r["J"][:, :3], np.linalg.inv(r["M"]), r["J"][:, :3])
+    sv = np.linalg.eigvalsh(A)
+    cond = sv[:, -1] / np.maximum(sv[:, 0], 1e-300)
+    det = np.abs(np.linalg.det(A))
+    err = cases.rel_err(u32.astype(float), u64)
+    well = cond < 1e3
+    assert well.mean() > 0.4
+    assert err[well].max() <= cases.TOL_F32, err[well].max()
+    # away from the two thresholds of _Mx (osc.py:138,145: the float kernel may take the other branch next to them)
+    clear = (np.abs(det - 1e-3) > 1e-4) & (np.abs(sv[:, 0] / sv[:, -1] - 1e-4) > 3e-5) & (cond < 1e6)
+    assert (err[clear] <= np.maximum(cases.TOL_F32, 1e-6 * cond[clear])).all(), \
+        (err[clear] / np.maximum(cases.TOL_F32, 1e-6 * cond[clear])).max()
+
+
 def test_gpu_config2_config4_full_size_vs_oracle():
     """BASELINE configs 2 (B=4096) and 4 (B=2^20 on one GPU): oracle on a sample + properties"""
     be, orc = cases.GpuBackend("ur5"), cases.OracleBackend("ur5")

@@ -53,6 +53,20 @@ def test_rows_fp32_other_kernels():
     cases.check_case_against_golden(be, "ur5:joint", g, dtype=np.float32)
 
 
+@pytest.mark.parametrize("case_id", ["twojoint:cfg1", "ur5:cfg4", "jaco2:cfg3", "ur5:osc6_alg0", "jaco2:osc6_alg1",
+                                     "ur5:osc_null2", "ur5:sliding", "jaco2:damping"])
+def test_rows_fp32_row_programs_match_reference(case_id):
+    """the float instantiations of the row programs (the -m gpu suite repeats this on the device, where sin / cos come
+    from the LDS table: test_gpu_fp32_kernels_match_reference)"""
+    arm = cases.CASES[case_id]["arm"]
+    cases.check_case_against_golden(cases.HostsimBackend(arm, "static"), case_id, golden(arm), dtype=np.float32)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2", "threejoint"])
+def test_rows_fp32_dynamics_match_reference(arm):
+    cases.check_dynamics_against_golden(cases.HostsimBackend(arm, "static"), arm, golden(arm), dtype=np.float32)
+
+
 def test_rows_twojoint_closed_forms():
     """reference's analytic known answers (arms/tests/dummy_base_arm.py) on its test grids"""
     k = golden("known_answers")
