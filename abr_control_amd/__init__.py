@@ -6,6 +6,6 @@ controllers; both evaluate one state or a batch of states with hand-written HIP 
 (abr_control_amd/csrc) through the C ABI of include/abrk.h.  No CPU fallback.
 """
 from . import arms, controllers  # noqa: F401
-from ._lib import AbrkError, DeviceArray, Event, Stream, device_count, device_name  # noqa: F401
+from ._lib import AbrkError, DeviceArray, Event, Stream, device_count, device_name, scratch_stats  # noqa: F401
 
 __version__ = "0.1.0"

@@ -48,6 +48,11 @@ class DynOut(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("Tx", "J", "M", "g", "C", "dJ", "R", "T", "Tinv", "quat")]
 
 
+class ScratchInfo(C.Structure):  # abrk_scratch_info
+    _fields_ = [(k, C.c_int64) for k in ("worklist_slots", "worklist_bytes", "inline_fallbacks", "evictions",
+                                          "device_free_bytes", "device_total_bytes")]
+
+
 class NullCtrl(C.Structure):
     _fields_ = [
         ("kind", C.c_int32),

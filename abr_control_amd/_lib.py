@@ -104,6 +104,7 @@ def lib():
         L.abrk_stream_create.argtypes = [C.c_int]
         L.abrk_stream_destroy.argtypes = [C.c_int, _vp]
         L.abrk_stream_sync.argtypes = [C.c_int, _vp]
+        L.abrk_scratch_stats.argtypes = [C.c_int, C.POINTER(_abi.ScratchInfo)]
         L.abrk_device_sync.argtypes = [C.c_int]
         L.abrk_event_create.restype = _vp
         L.abrk_event_create.argtypes = [C.c_int]
@@ -128,6 +129,13 @@ def device_name(device=0):
     buf = C.create_string_buffer(256)
     check(lib().abrk_device_name(device, buf, 256))
     return buf.value.decode()
+
+
+def scratch_stats(device=0):
+    """the library's own device scratch (abrk_scratch_stats): a dict of its counters"""
+    info = _abi.ScratchInfo()
+    check(lib().abrk_scratch_stats(device, C.byref(info)))
+    return {k: int(getattr(info, k)) for k, _ in _abi.ScratchInfo._fields_}
 
 
 NP_DTYPE = {_abi.F64: np.float64, _abi.F32: np.float32}

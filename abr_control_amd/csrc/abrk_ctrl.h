@@ -303,12 +303,64 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
 #ifndef ABRK_QL_BRANCHFREE
 #define ABRK_QL_BRANCHFREE 1
 #endif
-template <int K, class T>
-ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
+// a condition that holds on every lane of the wavefront alike (the wave-cooperative second pass: all lanes carry the
+// same matrix): as a scalar, so that the branch on it is a scalar branch
+ABRK_INL bool uni(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(c) != 0;  // v_cmp into a scalar pair, s_cmp, s_cbranch (a readfirstlane costs six more)
+#else
+  return c;
+#endif
+}
+// the rotation slots I, I - 1, .. L of one implicit-QL pass for the uniform (one matrix per wavefront) form of ql_core
+template <int K, class T, int NR, int L, int I>
+struct QlChain {
+  static ABRK_INL void run(T (&d)[K], T (&e)[K], T (&V)[NR][K], int m, T& sn, T& cs, T& pp, T& g, bool& stop) {
+#pragma clang fp contract(off)  // (see ql_core)
+    if constexpr (I >= L) {
+      if (uni(I < m)) {
+        const T f = sn * e[I], b = cs * e[I];
+        const T r2 = Rm<T>::fma(f, f, g * g);
+        if (uni(!(r2 > T(0)))) {  // tql2's recovery from underflow: the pass ends here
+          d[I + 1] -= pp;
+          stop = true;
+          return;
+        }
+        const T ir = Rm<T>::rsqrt(r2), r = r2 * ir;
+        e[I + 1] = r;
+        sn = f * ir;
+        cs = g * ir;
+        g = d[I + 1] - pp;
+        const T rr = Rm<T>::fma(d[I] - g, sn, T(2) * cs * b);
+        pp = sn * rr;
+        d[I + 1] = g + pp;
+        g = Rm<T>::fma(cs, rr, -b);
+        sfor<NR>([&](auto kk) ABRK_LAMBDA {
+          const T fz = V[kk()][I + 1];
+          V[kk()][I + 1] = Rm<T>::fma(sn, V[kk()][I], cs * fz);
+          V[kk()][I] = Rm<T>::fma(cs, V[kk()][I], -(sn * fz));
+        });
+      }
+      QlChain<K, T, NR, L, I - 1>::run(d, e, V, m, sn, cs, pp, g, stop);
+    }
+  }
+};
+// The solver proper: S = Z diag(lam) Z^T, applied to NR row vectors: V <- V Z.  IDENT: V comes in as the identity
+// (NR = K; its row 0 is e_0 and no reflector touches it) - V goes out as Z, the eigenvectors in its columns.  Otherwise
+// the NR rows are any vectors x^T and go out as x^T Z = (Z^T x)^T: what the wave-cooperative second pass of the six-row
+// law wants (each lane carries ONE vector and all lanes the same matrix).  UNI: every lane of the wavefront runs this
+// on the SAME matrix, so data-dependent branches are uniform - the rotation slots are real (scalar) branches and only
+// the rotations that exist are executed; without it (one matrix per lane) the predicated forms below.
+template <int K, class T, int NR, bool IDENT, bool UNI>
+ABRK_INL void ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K]) {
+  // No contraction of a * b + c beyond the fmas that are written out: the predicated one-matrix-per-lane form and the
+  // uniform one-matrix-per-wavefront form are different instantiations, and the finish kernel picks between them by the
+  // length of a sub-list - the result of a row must not depend on which one ran (bit for bit: a batch and its chunks).
+#pragma clang fp contract(off)
   static_assert(K >= 3, "two rows: one Jacobi rotation is exact");
+  static_assert(!IDENT || NR == K, "the identity has K rows");
   T a[K * (K + 1) / 2];  // packed lower triangle (the reduction works on a copy)
   sfor<K*(K + 1) / 2>([&](auto e) ABRK_LAMBDA { a[e()] = S[e()]; });
-  sfor<K>([&](auto i) ABRK_LAMBDA { sfor<K>([&](auto j) ABRK_LAMBDA { V[i()][j()] = (i() == j()) ? T(1) : T(0); }); });
   T d[K], e[K];
   sfor<K>([&](auto i) ABRK_LAMBDA { e[i()] = T(0); });
   // ---- Householder: A <- H_k A H_k, H_k = I - beta v v^T acting on rows / columns k+1 .. K-1;  V <- V H_k
@@ -319,7 +371,9 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
     sfor<M - 1>([&](auto j) ABRK_LAMBDA { sigma2 = Rm<T>::fma(a[tri(m0 + 1 + j(), k)], a[tri(m0 + 1 + j(), k)], sigma2); });
     T alpha = x0;  // the new sub-diagonal entry
     // nothing below the sub-diagonal (to rounding): the column is already tridiagonal
-    if (sigma2 > Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * (x0 * x0 + sigma2) && sigma2 > Rm<T>::tiny()) {
+    bool reflect = sigma2 > Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * Rm<T>::eps() * (x0 * x0 + sigma2) && sigma2 > Rm<T>::tiny();
+    if constexpr (UNI) reflect = uni(reflect);
+    if (reflect) {
       const T n2 = Rm<T>::fma(x0, x0, sigma2);
       const T nrm = n2 * Rm<T>::rsqrt(n2);
       alpha = x0 >= T(0) ? -nrm : nrm;
@@ -339,12 +393,12 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
       sfor<M>([&](auto i) ABRK_LAMBDA { pv[i()] = Rm<T>::fma(-kk, v[i()], pv[i()]); });  // q = p - (beta/2)(p.v) v
       sfor<M>([&](auto i) ABRK_LAMBDA {
         sfor<i() + 1>([&](auto j) ABRK_LAMBDA {
-          a[tri(m0 + i(), m0 + j())] = a[tri(m0 + i(), m0 + j())] - v[i()] * pv[j()] - pv[i()] * v[j()];
+          a[tri(m0 + i(), m0 + j())] = Rm<T>::fma(-pv[i()], v[j()], Rm<T>::fma(-v[i()], pv[j()], a[tri(m0 + i(), m0 + j())]));
         });
       });
-      // V <- V H (row 0 of V is e_0 throughout: the reflectors never touch index 0)
-      sfor<K - 1>([&](auto rr) ABRK_LAMBDA {
-        constexpr int r = rr() + 1;
+      // V <- V H (IDENT: row 0 of V is e_0 throughout: the reflectors never touch index 0)
+      sfor<NR - (IDENT ? 1 : 0)>([&](auto rr) ABRK_LAMBDA {
+        constexpr int r = rr() + (IDENT ? 1 : 0);
         T sdot = T(-0.0);
         sfor<M>([&](auto j) ABRK_LAMBDA { sdot = Rm<T>::fma(V[r][m0 + j()], v[j()], sdot); });
         sdot *= beta;
@@ -372,7 +426,7 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
           m = small ? j : m;
           dm = small ? d[j] : dm;
         });
-        if (m == l) break;
+        if (UNI ? uni(m == l) : (m == l)) break;
         T g = (d[l + 1] - d[l]) * T(0.5) * Rm<T>::rcp(e[l] == T(0) ? T(1) : e[l]);
         {
           const T r2 = Rm<T>::fma(g, g, T(1));
@@ -382,6 +436,11 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
         }
         T sn = T(1), cs = T(1), pp = T(0);
         bool stop = false;  // a zero rotation radius ends the pass early (tql2's recovery from underflow)
+        if constexpr (UNI) {
+          // one matrix per wavefront: the slots that exist, behind scalar branches (QlChain: the rare zero radius
+          // LEAVES the chain instead of joining the next slot - no merge, no register copies on the rotation path)
+          QlChain<K, T, NR, l, K - 2>::run(d, e, V, m, sn, cs, pp, g, stop);
+        } else {
 #if ABRK_QL_BRANCHFREE
         // Every slot K-2 .. l is executed by every lane, inactive ones (i >= m, or after a stop) as the identity
         // rotation: the pass is ONE basic block, so the six independent eigenvector updates of a slot overlap with the
@@ -407,7 +466,7 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
           cs = go ? cs_n : cs;
           pp = go ? pp_n : pp;
           const T se = go ? sn_n : T(0), ce = go ? cs_n : T(1);
-          sfor<K>([&](auto kk) ABRK_LAMBDA {
+          sfor<NR>([&](auto kk) ABRK_LAMBDA {
             const T fz = V[kk()][i + 1];
             V[kk()][i + 1] = Rm<T>::fma(se, V[kk()][i], ce * fz);
             V[kk()][i] = Rm<T>::fma(ce, V[kk()][i], -(se * fz));
@@ -432,7 +491,7 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
               pp = sn * rr;
               d[i + 1] = g + pp;
               g = Rm<T>::fma(cs, rr, -b);
-              sfor<K>([&](auto kk) ABRK_LAMBDA {
+              sfor<NR>([&](auto kk) ABRK_LAMBDA {
                 const T fz = V[kk()][i + 1];
                 V[kk()][i + 1] = Rm<T>::fma(sn, V[kk()][i], cs * fz);
                 V[kk()][i] = Rm<T>::fma(cs, V[kk()][i], -(sn * fz));
@@ -441,13 +500,14 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
           }
         });
 #endif
+        }
         // e[m] = 0 in either case (as value selects: an `if (m == j) e[j] = 0` chain becomes ONE store through a
         // selected pointer, which sends e[] to scratch memory)
         sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
           constexpr int j = l + jj();
           e[j] = (m == j) ? T(0) : e[j];
         });
-        if (!stop) {
+        if (UNI ? uni(!stop) : !stop) {
           d[l] -= pp;
           e[l] = g;
         }
@@ -455,6 +515,11 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
     }
   });
   sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = d[i()]; });
+}
+template <int K, class T>
+ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
+  sfor<K>([&](auto i) ABRK_LAMBDA { sfor<K>([&](auto j) ABRK_LAMBDA { V[i()][j()] = (i() == j()) ? T(1) : T(0); }); });
+  ql_core<K, T, K, true, false>(S, V, lam);
 }
 
 #ifndef ABRK_EIG_QL
@@ -1088,6 +1153,63 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   }
 }
 
+// LEN values (LEN even) to a 2-element-aligned address as two-element pieces (16-byte stores in fp64)
+template <int LEN, class T>
+ABRK_INL void store_pairs(T* dst, const T (&v)[LEN]) {
+  static_assert(LEN % 2 == 0, "pairs");
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  V2* d2 = reinterpret_cast<V2*>(dst);
+  sfor<LEN / 2>([&](auto k) ABRK_LAMBDA { d2[k()] = V2{v[2 * k()], v[2 * k() + 1]}; });
+}
+// weights of numpy.linalg.pinv(Mx_inv, rcond) on the eigenvalues (osc.py:145): 1 / lam where |lam| > rcond max|lam|
+template <int K, class T>
+ABRK_INL void pinv_weights(const T (&lam)[K], T rcond, T (&wv)[K]) {
+#pragma clang fp contract(off)
+  T smax = T(0);
+  sfor<K>([&](auto r) ABRK_LAMBDA { smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()])); });
+  const T cut = rcond * smax;
+  sfor<K>([&](auto r) ABRK_LAMBDA {
+    const bool keep = Rm<T>::fabs(lam[r()]) > cut;
+    wv[r()] = keep ? rcp(keep ? lam[r()] : T(1)) : T(0);
+  });
+}
+// ---- second pass of the six-row law on a hand-over record (the first pass left it: osc_law6's deferral branch).
+// With Mx_inv = Z diag(lam) Z^T the pseudo-inverse is Z W Z^T, and what the law needs of it are J^T Mx u_task and
+// J^T Mx (J v): with G = Z^T [J | u_task | J v] - the SAME orthogonal transformation applied to every column -
+//   (J^T Mx x)_c = sum_i G[i][c] W_i G[i][x],
+// so Z is never formed: the solver (ql_core) carries the columns along, one per lane in the wave-cooperative kernel
+// (abrk_law.hip osc6_finish_kernel: NV = 1, all lanes of the wavefront decompose the same matrix, each transforms its
+// own column; lanes N / N + 1 hand their transformed column to the others at the end) or all of them on one lane (the
+// host check build: NV = N + 2).  `col`: index of the first column held.  -> a1[k] = (J^T Mx u_task)_(col+k),
+// a2[k] = (J^T Mx J v)_(col+k) given the transformed u_task / J v columns gu, gw.
+template <int N, class T, int NV, bool UNI>
+ABRK_INL void osc6_rec_transform(const T* __restrict__ rec, int col, T (&G)[NV][6], T (&wv)[6]) {
+  constexpr int XS = rec_xs(N);
+  T S[21], lam[6];
+  sfor<21>([&](auto e) ABRK_LAMBDA { S[e()] = rec[e()]; });
+  sfor<NV>([&](auto k) ABRK_LAMBDA {
+    sfor<6>([&](auto r) ABRK_LAMBDA { G[k()][r()] = rec[rec_off_x() + r() * XS + col + k()]; });
+  });
+  ql_core<6, T, NV, false, UNI>(S, G, lam);
+  pinv_weights<6>(lam, T(1e-3) * T(0.1), wv);
+}
+// the whole second pass of one row on one lane (host check build; the GPU spreads the columns over lanes)
+template <int N, class T>
+ABRK_INL void osc6_finish_row(const T* __restrict__ rec, bool nulls, T (&u)[N], T (&ts)[N]) {
+#pragma clang fp contract(off)  // the same bits as the wave-cooperative form (abrk_kernels.h osc6_finish_kernel)
+  T G[N + 2][6], wv[6];
+  osc6_rec_transform<N, T, N + 2, false>(rec, 0, G, wv);
+  sfor<N>([&](auto c) ABRK_LAMBDA {
+    T a1 = T(-0.0), a2 = T(-0.0);
+    sfor<6>([&](auto i) ABRK_LAMBDA {
+      a1 = Rm<T>::fma(G[c()][i()], wv[i()] * G[N][i()], a1);
+      a2 = Rm<T>::fma(G[c()][i()], wv[i()] * G[N + 1][i()], a2);
+    });
+    ts[c()] = rec[rec_off_b1(N) + c()] - a1;
+    u[c()] = ts[c()] + rec[rec_off_b1(N) + N + c()] - (nulls ? a2 : T(0));
+  });
+}
+
 // ---- the same law for all six task rows (any ctrlr_dof, ref_frame, orientation control), restructured around its
 // register peak.  osc_law above keeps Jr (6 N values), Y = L^-1 J^T (6 N), M, its factor and two 6 x 6 factors alive
 // together: 390-490 registers, ONE wave per SIMD.  Here
@@ -1105,10 +1227,11 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
 #endif
 template <int N, class T, bool USE_C, int FEAT, class Rows, int QSTEPS = 3>
 ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
-                       const T (&cvec)[N], const Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
+                       const T (&cvec)[N], Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
                        const T (&dq)[N], const T (&tgt)[6], bool tv_given, const T (&tvin)[6], bool have_ierr,
                        T (&ierr)[6], bool have_ext, const T (&une)[N], T (&u)[N], T (&ts)[N], bool* defer = nullptr) {
   constexpr int KM = 6;
+  static_assert(rec_len(N) >= rec_off_b1(N) + 2 * N, "hand-over record layout");
   // ctrlr_dof is uniform over the launch.  With all six rows selected (the reference benchmark's UR5 setting) nothing
   // is masked; the masked forms sit in blocks of their own behind scalar branches (ABRK_UNIFORM_BLOCK) instead of
   // costing every launch two v_cndmask per `sel ? x : y`.
@@ -1304,7 +1427,42 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       }
     }
     if (truncates && (Rows::kDeferOnly || defer)) {
-      if (defer) *defer = true;  // worked off in the dense second pass; nothing of this row is written
+      if (defer) *defer = true;  // worked off in the second pass; u / the training signal of this row are not written yet
+      // the row joins its wavefront's sub-list; in hand-over mode it also leaves everything the second pass needs -
+      // Mx_inv, the task Jacobian rows, u_task and the two joint-space sums around J^T f - so that the pass runs the
+      // eigen-decomposition and nothing else (abrk_device.h rec_*; osc6_finish below reads it back)
+      if (T* rec = js.template claim<T>(rec_len(N))) {
+        constexpr int XS = rec_xs(N);
+        T sv[22];
+        sfor<21>([&](auto e) ABRK_LAMBDA { sv[e()] = Am[e()]; });
+        sfor<KM>([&](auto r) ABRK_LAMBDA { sv[tri(r(), r())] = sel[r()] ? Am[tri(r(), r())] : T(0); });
+        sv[21] = T(0);
+        store_pairs<22>(rec, sv);
+        sfor<KM>([&](auto r) ABRK_LAMBDA {
+          T xr[XS];
+          T row[N];
+          js.get_row(r, row);
+          T jv = T(-0.0);
+          sfor<N>([&](auto i) ABRK_LAMBDA { xr[i()] = row[i()]; });
+          if constexpr (FEAT >= 1) {
+            if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { jv += row[i()] * v[i()]; });
+          }
+          xr[N] = uts[r()];
+          xr[N + 1] = jv;
+          if constexpr (XS > N + 2) xr[XS - 1] = T(0);
+          store_pairs<XS>(rec + rec_off_x() + r() * XS, xr);
+        });
+        T bb[2 * N];
+        const T gsc = (!Rows::kNoTs && P.use_g) ? gscale : T(0);
+        sfor<N>([&](auto i) ABRK_LAMBDA {
+          bb[i()] = USE_C ? u0[i()] - cvec[i()] : u0[i()];
+          bb[N + i()] = gsc * gz[i()];
+        });
+        if constexpr (FEAT >= 1) {
+          if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { bb[N + i()] += un[i()]; });
+        }
+        store_pairs<2 * N>(rec + rec_off_b1(N), bb);
+      }
       return;
     }
     if constexpr (!Rows::kDeferOnly) if (truncates) {

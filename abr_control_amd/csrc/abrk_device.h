@@ -896,6 +896,26 @@ ABRK_INL void omega_advance(const Joints<A, T>& jt, const T (&dq)[A::N], Dyn<A, 
 // kernel allows it, the row program raises `deferred` instead of running the sweeps; the kernel then parks the row
 // index in a worklist that a second, densely packed pass works off (abrk_kernels.h osc_kernel, modes 1 / 2).  Lanes
 // diverge otherwise: one such row makes its whole wavefront run the sweeps.
+// Worklist of deferred rows: kWlLists sub-lists (wavefront w appends to sub-list w mod kWlLists), each with its own
+// counter on its own 64-byte line - one shared counter serialises at ~90 atomics per microsecond, which at 8 M rows
+// (125 k wavefronts with a deferred row) cost 1.4 ms, three times the arithmetic.
+// Layout (ints): counter of sub-list s at [16 s]; row indices of sub-list s at [16 kWlLists + s cap + k], cap = wl_capacity(B).
+constexpr int kWlLists = 256;
+constexpr int kWlBlock = 64;  // rows per first-pass workgroup (= abrk_kernels.h kBlock)
+constexpr long wl_capacity(long B) { return ((B + kWlBlock - 1) / kWlBlock / kWlLists + 1) * kWlBlock; }  // rows per sub-list
+constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(B); }
+// Hand-over record of a deferred row of the six-row law (osc_law6 writes it, osc6_finish reads it): everything the
+// truncating pseudo-inverse and the tail of the law need, so that the second pass does no kinematics -
+//   S   [22]          Mx_inv = J M^-1 J^T, packed lower (21 values), a masked task row as an isolated zero
+//   X   [6][xs(N)]    row r: the masked task Jacobian row J[r][0..N), then u_task[r], then (J v)[r] of the secondary
+//                     controllers (0 without them); xs(N) = N + 2 rounded up to even (16-byte row starts)
+//   b1  [N]           u0 - C dq: the training signal is b1 - J^T f
+//   b2  [N]           what follows the training signal: gravity (+ M v of the secondary controllers)
+constexpr int rec_xs(int n) { return (n + 3) & ~1; }
+constexpr int rec_off_x() { return 22; }
+constexpr int rec_off_b1(int n) { return 22 + 6 * rec_xs(n); }
+constexpr int rec_len(int n) { return (22 + 6 * rec_xs(n) + 2 * n + 1) & ~1; }
+
 struct ScratchBase {
   // true in the first pass of the six-row kernels (DeferOnly below): the row program is compiled WITHOUT the eigen-
   // decomposition - a row that needs it is always deferred - so its registers do not weigh on the two-wave budget
@@ -906,6 +926,28 @@ struct ScratchBase {
   static constexpr bool kNoTs = false;
   bool allow_defer = false, deferred = false;
   ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
+  // where a deferring row parks itself (set by the kernel; the host check build passes plain arrays): the worklist, this
+  // wavefront's sub-list, the row's index and - hand-over mode - the record store (rec_len(N) values per list slot)
+  int* wl = nullptr;
+  void* rec_base = nullptr;
+  long wl_cap = 0, row = 0;
+  int wl_sub = 0;
+  bool handed_over = false;
+  // appends the row to its sub-list; -> its hand-over record (nullptr: the second pass recomputes the row)
+  template <class T>
+  ABRK_INL T* claim(int len) {
+    if (!wl) return nullptr;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int k = atomicAdd(wl + 16 * wl_sub, 1);
+#else
+    const int k = wl[16 * wl_sub]++;
+#endif
+    const long slot = (long)wl_sub * wl_cap + k;
+    wl[16 * kWlLists + slot] = (int)row;
+    if (!rec_base) return nullptr;
+    handed_over = true;
+    return static_cast<T*>(rec_base) + slot * len;
+  }
 };
 template <class T, int N>
 struct RegScratch : ScratchBase {

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -321,8 +322,12 @@ extern "C" void* abrk_stream_create(int device) {
   }
   return s;
 }
+namespace {
+void wl_forget_stream(int device, hipStream_t stream);  // the six-row kernels' (device, stream) scratch: below
+}
 extern "C" int abrk_stream_destroy(int device, void* stream) {
   if (int rc = use_device(device)) return rc;
+  if (stream) wl_forget_stream(device, (hipStream_t)stream);
   HIPCHK(hipStreamDestroy((hipStream_t)stream));
   return 0;
 }
@@ -570,72 +575,203 @@ int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn, std::unique_lock<
   return st.finish();
 }
 
-// Worklist of the six-row OSC kernels (rows whose law needs the Jacobi sweeps are deferred to a dense second pass,
-// abrk_kernels.h): wl_ints(B) ~ B + 20 k ints of device scratch.  Immediate calls take it from a cache keyed by (device, stream) -
-// calls on one stream are ordered, so the buffer can be reused - PROVIDED the three launches that use it (memset of the
-// counters, pass 1, pass 2) enter the stream as a unit: several host threads may share a stream (every Python call
-// without an explicit stream is on the NULL stream, and ctypes releases the GIL), and memset A, pass-1 A, memset B,
-// pass-2 A would lose A's deferred rows (or overrun a list sized for one call).  So the caller keeps `hold` (g_wl_mu)
-// from here until its launches are enqueued (dispatch() releases it before any stream sync).  A grow frees the old
-// buffer only after draining the stream, which - every earlier user having enqueued under the same lock - covers all of
-// them.  A recorded plan owns its worklist.
+// Worklist of the six-row OSC kernels (rows whose law needs the truncating pseudo-inverse are deferred to a second pass,
+// abrk_kernels.h): wl_ints(B) ~ B + 20 k ints of device scratch and - hand-over mode, batches of up to
+// kHandoverMaxRows - a record of rec_len(n) values per list slot.  Immediate calls take both from a cache keyed by
+// (device, stream) - calls on one stream are ordered, so the buffers can be reused - PROVIDED the launches that use
+// them (counters' memset, pass 1, pass 2) enter the stream as a unit: several host threads may share a stream (every
+// Python call without an explicit stream is on the NULL stream, and ctypes releases the GIL), and memset A, pass-1 A,
+// memset B, pass-2 A would lose A's deferred rows (or overrun a list sized for one call).  So the caller keeps `hold` -
+// the SLOT's mutex: calls on other streams and other devices do not wait for it - from here until its launches are
+// enqueued (dispatch() releases it before any stream sync).  A grow frees the old buffers only after draining the
+// slot's own stream, which - every earlier user having enqueued under the same lock - covers all of them; only callers
+// of that one stream wait meanwhile.  The registry lock (g_wl_mu) is held for the look-up alone.  abrk_stream_destroy
+// hands a stream's slot back; streams the caller destroyed behind the library's back are evicted once the cache is
+// full (least recently used slot whose stream is idle or gone).  A recorded plan owns its worklist.
 struct WorklistSlot {
-  int device;
-  hipStream_t stream;
-  int* buf;
-  size_t cap;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int* buf = nullptr;      // counters + row indices
+  size_t cap = 0;          // bytes
+  void* rec = nullptr;     // hand-over records
+  size_t rec_cap = 0;      // bytes
+  bool dirty = true;       // counters may be non-zero (fresh buffer, or a call of the recompute form ran last)
+  uint64_t last_use = 0;
+  std::mutex mu;
 };
 std::mutex g_wl_mu;
-std::vector<WorklistSlot> g_wl_cache;
-// -> 0 and *out = the worklist (nullptr: run the sweeps inline), or an error code
-int worklist_for(int device, hipStream_t stream, int64_t B, int** out, std::unique_lock<std::mutex>& hold) {
-  *out = nullptr;
+std::vector<std::unique_ptr<WorklistSlot>> g_wl_cache;
+uint64_t g_wl_clock = 0;
+std::atomic<int64_t> g_wl_inline_fallbacks{0}, g_wl_evictions{0};
+constexpr size_t kWlCacheSlots = 64;
+// batches up to here hand the deferred rows' intermediate results over to the second pass (183 MB of records at most
+// for a six-joint arm in fp64); beyond, the second pass recomputes its rows (a record store in proportion to the batch
+// would cost gigabytes, and at those sizes the recomputation is 4 % of the call)
+constexpr int64_t kHandoverMaxRows = 262144;
+
+void wl_release(WorklistSlot& s) {  // caller holds s.mu (or owns the slot exclusively); the slot's stream is drained
+  (void)hipSetDevice(s.device);
+  if (s.buf) (void)hipFree(s.buf);
+  if (s.rec) (void)hipFree(s.rec);
+  s.buf = nullptr;
+  s.rec = nullptr;
+  s.cap = s.rec_cap = 0;
+  s.dirty = true;
+}
+// abrk_stream_destroy: the stream's slot leaves the cache (its launches are drained by the caller's hipStreamDestroy,
+// which waits for the stream's work; the buffers are freed after an explicit drain here)
+void wl_forget_stream(int device, hipStream_t stream) {
+  std::unique_ptr<WorklistSlot> mine;
+  {
+    std::lock_guard<std::mutex> lk(g_wl_mu);
+    for (size_t i = 0; i < g_wl_cache.size(); i++)
+      if (g_wl_cache[i]->device == device && g_wl_cache[i]->stream == stream) {
+        mine = std::move(g_wl_cache[i]);
+        g_wl_cache.erase(g_wl_cache.begin() + i);
+        break;
+      }
+  }
+  if (!mine) return;
+  std::lock_guard<std::mutex> sl(mine->mu);  // a caller that found the slot just before may still be enqueueing
+  (void)hipStreamSynchronize(stream);
+  wl_release(*mine);
+}
+bool handover_enabled() {
+  static const bool off = getenv("ABRK_NO_HANDOVER") != nullptr;  // measurement switch: the round-3 scheme
+  return !off;
+}
+// -> 0 and *wl = the worklist (nullptr: run the sweeps inline), *rec = the record store (nullptr: recompute form), or
+// an error code.  n / dtype: the arm's joint count and the arithmetic type (record size).
+int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, int** wl, void** rec,
+                 std::unique_lock<std::mutex>& hold) {
+  *wl = nullptr;
+  *rec = nullptr;
   static const bool off = getenv("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
-  // below ~16 k rows the second launch costs more than the divergence it removes (B = 4096: 32 -> 38 us per step)
   // (row indices are parked as 32-bit ints: batches beyond 2^31 rows - they fit the 288 GB for fp32 arms - run inline)
-  if (off || B < 16384 || B > 0x7fffffffLL) return 0;
+  if (off || B > 0x7fffffffLL) return 0;
+  const bool handover = handover_enabled() && B <= kHandoverMaxRows;
+  // the recompute form below ~16 k rows: the second launch costs more than the divergence it removes (round 2)
+  if (!handover && B < 16384) return 0;
   const size_t need = (size_t)wl_ints(B) * sizeof(int);
+  const size_t need_rec = handover ? (size_t)kWlLists * wl_capacity(B) * rec_len(n) * esz(dtype) : 0;
   if (Recorder* r = t_rec) {
-    void* p = nullptr;
+    void *p = nullptr, *q = nullptr;
     hipError_t e = hipMalloc(&p, need);
+    if (e == hipSuccess && need_rec) e = hipMalloc(&q, need_rec);
+    if (e == hipSuccess) e = hipMemset(p, 0, 16 * kWlLists * sizeof(int));  // hand-over: zero from here on (finish kernel)
     if (e != hipSuccess) {
       (void)hipGetLastError();
-      return fail(ABRK_ENOMEM, "worklist of the recorded six-row OSC call, hipMalloc(%zu): %s", need, hipGetErrorString(e));
+      if (p) (void)hipFree(p);
+      return fail(ABRK_ENOMEM, "worklist of the recorded six-row OSC call, hipMalloc(%zu + %zu): %s", need, need_rec,
+                  hipGetErrorString(e));
     }
     r->dev_bufs.push_back(p);
-    *out = (int*)p;
+    if (q) r->dev_bufs.push_back(q);
+    *wl = (int*)p;
+    *rec = q;
     return 0;
   }
-  hold = std::unique_lock<std::mutex>(g_wl_mu);
   WorklistSlot* s = nullptr;
-  for (auto& e : g_wl_cache)
-    if (e.device == device && e.stream == stream) s = &e;
-  if (!s) {
-    if (g_wl_cache.size() >= 64) {  // many short-lived streams: do not hoard scratch, run the sweeps inline
-      hold.unlock();
-      return 0;
+  std::unique_ptr<WorklistSlot> evicted;
+  {
+    std::lock_guard<std::mutex> lk(g_wl_mu);
+    for (auto& e : g_wl_cache)
+      if (e->device == device && e->stream == stream) s = e.get();
+    if (!s) {
+      if (g_wl_cache.size() >= kWlCacheSlots) {
+        // full: the least recently used slot whose stream has nothing in flight (or no longer exists) makes room
+        size_t pick = g_wl_cache.size();
+        for (size_t i = 0; i < g_wl_cache.size(); i++) {
+          WorklistSlot& c = *g_wl_cache[i];
+          if (pick < g_wl_cache.size() && c.last_use >= g_wl_cache[pick]->last_use) continue;
+          if (!c.mu.try_lock()) continue;  // somebody is enqueueing on it
+          (void)hipSetDevice(c.device);
+          const hipError_t q = c.stream ? hipStreamQuery(c.stream) : hipErrorNotReady;  // the NULL stream stays
+          (void)hipGetLastError();
+          c.mu.unlock();
+          if (q != hipErrorNotReady) pick = i;
+        }
+        (void)hipSetDevice(device);
+        if (pick == g_wl_cache.size()) {  // every cached stream is busy: inline sweeps for this call
+          g_wl_inline_fallbacks++;
+          return 0;
+        }
+        g_wl_evictions++;
+        evicted = std::move(g_wl_cache[pick]);
+        g_wl_cache.erase(g_wl_cache.begin() + pick);
+      }
+      g_wl_cache.emplace_back(new WorklistSlot);
+      s = g_wl_cache.back().get();
+      s->device = device;
+      s->stream = stream;
     }
-    g_wl_cache.push_back({device, stream, nullptr, 0});
-    s = &g_wl_cache.back();
+    s->last_use = ++g_wl_clock;
   }
-  if (s->cap < need) {
-    if (s->buf) {
-      (void)hipStreamSynchronize(stream);  // launches in flight may still use the old buffer (all enqueued: see above)
-      (void)hipFree(s->buf);
+  if (evicted) {
+    std::lock_guard<std::mutex> sl(evicted->mu);
+    wl_release(*evicted);
+    (void)hipSetDevice(device);
+  }
+  hold = std::unique_lock<std::mutex>(s->mu);
+  if (s->cap < need || s->rec_cap < need_rec) {
+    if (s->buf || s->rec) {
+      (void)hipStreamSynchronize(stream);  // launches in flight may still use the old buffers (all enqueued: see above)
+      wl_release(*s);
     }
-    s->buf = nullptr;
-    s->cap = 0;
-    void* p = nullptr;
-    if (hipMalloc(&p, need + need / 4) != hipSuccess) {
+    void *p = nullptr, *q = nullptr;
+    hipError_t e = hipMalloc(&p, need + need / 4);
+    if (e == hipSuccess && need_rec) e = hipMalloc(&q, need_rec + need_rec / 4);
+    if (e != hipSuccess) {
       (void)hipGetLastError();
+      if (p) (void)hipFree(p);
       hold.unlock();
+      g_wl_inline_fallbacks++;
       return 0;  // no scratch on an immediate call: inline sweeps (same results)
     }
     s->buf = (int*)p;
     s->cap = need + need / 4;
+    s->rec = q;
+    s->rec_cap = q ? need_rec + need_rec / 4 : 0;
+    s->dirty = true;
   }
-  *out = s->buf;
+  *wl = s->buf;
+  if (handover) {
+    // the finish kernel leaves the counters zero; a fresh buffer, or one the recompute form used last, is zeroed here
+    if (s->dirty) {
+      if (hipMemsetAsync(s->buf, 0, 16 * kWlLists * sizeof(int), stream) != hipSuccess) {
+        (void)hipGetLastError();
+        *wl = nullptr;
+        hold.unlock();
+        g_wl_inline_fallbacks++;
+        return 0;
+      }
+      s->dirty = false;
+    }
+    *rec = s->rec;
+  } else {
+    s->dirty = true;
+  }
   return 0;
+}
+
+// wavefronts per sub-list in the finish kernel: enough for ~8 % deferred rows in one wave-cooperative round
+// (random UR5 states with all six task rows: 4.6 %); ABRK_FINISH_WAVES / ABRK_FINISH_ROUNDS: measurement switches
+int finish_waves(int64_t B) {
+  static const int forced = [] {
+    const char* e = getenv("ABRK_FINISH_WAVES");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced >= 1 && forced <= kFinishMaxWaves) return forced;
+  const int64_t per_list = (B + wl_sublists((long)B) - 1) / wl_sublists((long)B);
+  const int64_t want = (per_list * 8 + 99) / 100;
+  return (int)(want < 4 ? 4 : want > kFinishMaxWaves ? kFinishMaxWaves : want);
+}
+int finish_coop_rounds() {
+  static const int v = [] {
+    const char* e = getenv("ABRK_FINISH_ROUNDS");
+    return e ? atoi(e) : 2;
+  }();
+  return v;
 }
 
 int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
@@ -647,6 +783,24 @@ int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
 }
 
 }  // namespace
+
+extern "C" int abrk_scratch_stats(int device, abrk_scratch_info* out) {
+  if (!out) return fail(ABRK_EINVAL, "out is NULL");
+  memset(out, 0, sizeof *out);
+  {
+    std::lock_guard<std::mutex> lk(g_wl_mu);
+    out->worklist_slots = (int64_t)g_wl_cache.size();
+    for (auto& e : g_wl_cache) out->worklist_bytes += (int64_t)(e->cap + e->rec_cap);  // (racy read of sizes: diagnostics)
+  }
+  out->inline_fallbacks = g_wl_inline_fallbacks.load();
+  out->evictions = g_wl_evictions.load();
+  if (int rc = use_device(device)) return rc;
+  size_t fr = 0, tot = 0;
+  HIPCHK(hipMemGetInfo(&fr, &tot));
+  out->device_free_bytes = (int64_t)fr;
+  out->device_total_bytes = (int64_t)tot;
+  return 0;
+}
 
 // ------------------------------------------------------------------------------- dynamics
 extern "C" int abrk_dynamics_batch(int arm_id, int dtype, int64_t B, const void* q, const void* dq, int frame,
@@ -771,15 +925,20 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
   std::unique_lock<std::mutex> wl_hold;  // the (device, stream) worklist stays ours until the launches are enqueued
   if (oa.fast == 0 && !want)
-    if (int rc = worklist_for(device, (hipStream_t)stream, B, &oa.wl, wl_hold)) return rc;
+    if (int rc = worklist_for(device, (hipStream_t)stream, B, n, dtype, &oa.wl, &oa.rec, wl_hold)) return rc;
   const OscP<double> p64 = make_oscp<double>(*P, n);
   const OscP<float> p32 = make_oscp<float>(*P, n);
   const ArmOps* ops = a->ops;
   const hipStream_t hs = (hipStream_t)stream;
+  // hand-over mode: the arm's first pass, then the arm-independent finish kernel on the records it left
+  FinishArgs fa{oa.wl, oa.rec, (P->n_null > 0 || u_null_ext) ? 1 : 0, finish_waves(B), finish_coop_rounds(), oa.u, oa.ts};
   return dispatch(st, a, dtype, [=](const void* rt) {
     OscArgs o = oa;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
-    return ops->osc(dtype, LaunchArgs{rt, (long)B, hs}, o);
+    const LaunchArgs la{rt, (long)B, hs};
+    const hipError_t e = ops->osc(dtype, la, o);
+    if (e != hipSuccess || !o.rec) return e;
+    return launch_osc6_finish(n, dtype, la, fa);
   }, &wl_hold);
 }
 

@@ -195,9 +195,8 @@ struct LdsScratch : ScratchBase {
   }
 };
 
-// Worklist of deferred rows: kWlLists sub-lists (wavefront w appends to sub-list w mod kWlLists), each with its own
-// counter on its own 64-byte line - one shared counter serialises at ~90 atomics per microsecond, which at 8 M rows
-// (125 k wavefronts with a deferred row) cost 1.4 ms, three times the arithmetic.
+// (the worklist of deferred rows and the hand-over record: abrk_device.h, next to ScratchBase)
+static_assert(kWlBlock == kBlock, "wl_capacity assumes one first-pass workgroup per kBlock rows");
 #ifndef ABRK_KM6_GRID_CAP
 #define ABRK_KM6_GRID_CAP 4096  // first pass of the six-row law: a persistent grid of at most this many blocks (a multiple of kWlLists)
 #endif
@@ -209,9 +208,6 @@ struct LdsScratch : ScratchBase {
 constexpr bool km6_first_pass_plain(int km, bool use_c, int feat, bool ortho, int pass, bool is_static) {
   return km == 6 && pass == 1 && !ABRK_KM6_P1_LOOP && osc_min_waves(km, use_c, feat, ortho, pass, is_static) >= 2;
 }
-constexpr int kWlLists = 256;
-constexpr long wl_capacity(long B) { return ((B + kBlock - 1) / kBlock / kWlLists + 1) * kBlock; }  // rows per sub-list
-constexpr long wl_ints(long B) { return 16L * kWlLists + kWlLists * wl_capacity(B); }
 // `mode`: 0 = every row start to finish; 1 = rows whose law needs the Jacobi eigen-decomposition (a truncating pinv that
 // neither certificate excludes) only leave their index in the worklist `wl`; 2 = work that list off, densely packed
 // (persistent grid: block b strides sub-list b mod kWlLists).  Lanes diverge, so in mode 0 one such row costs its whole wavefront
@@ -224,7 +220,8 @@ template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOT
 __global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
-           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl) {
+           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl,
+           T* __restrict__ rec) {
   constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
   // the slab: scratch of the Coriolis recursion (orthogonal chains) and / or the row store of the six-row law
   constexpr bool kLds = (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) || (KM == 6 && (ABRK_KM6_LDS != 0));
@@ -235,11 +232,14 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
   auto row = [&](long b, bool allow_defer) ABRK_LAMBDA {
     auto go = [&](auto& scr) ABRK_LAMBDA {
       scr.allow_defer = allow_defer;
-      osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
-      if (scr.deferred) {
-        const int sub = (int)(blockIdx.x % kWlLists);
-        wl[16 * kWlLists + sub * wl_capacity(B) + atomicAdd(wl + 16 * sub, 1)] = (int)b;
+      if (allow_defer) {  // where a deferring row parks itself (ScratchBase::claim, called by the law)
+        scr.wl = wl;
+        scr.rec_base = rec;
+        scr.wl_sub = (int)(blockIdx.x % kWlLists);
+        scr.wl_cap = wl_capacity(B);
+        scr.row = b;
       }
+      osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
     };
     if constexpr (kLds && NOTS) {
       static_assert(PASS == 1 && KM == 6 && FEAT == 0, "NOTS is instantiated for the first pass of the plain six-row law");
@@ -292,6 +292,86 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
     ABRK_ROW_INDEX
     row(b, false);
   }
+}
+
+// ---- second pass of the six-row law on hand-over records (osc_law6's deferral branch wrote them; abrk_device.h
+// rec_*; the arithmetic: abrk_ctrl.h osc6_rec_transform).  One workgroup per sub-list of the worklist, kFinishMaxWaves
+// wavefronts at most.  Two forms, chosen per sub-list by its length n:
+//   * wave-cooperative (n <= 2 x the workgroup's wavefronts): ONE deferred row per wavefront.  Every lane decomposes the
+//     row's 6 x 6 Mx_inv - redundantly, so nothing crosses lanes and every data-dependent branch of the QL iteration is
+//     uniform (only the rotations that exist are executed: ~35 of the 68 slots the predicated per-lane form walks) -
+//     and applies the transformations to ITS column of [J | u_task | J v]; lanes N and N + 1 then hand their column to
+//     the others (v_readlane) and lane c < N finishes joint c.  A lone lane's eigen-decomposition was the critical
+//     path of every small six-row step (4096 rows: 95 % of the 64 wavefronts have a truncating row, 21 us per step of
+//     which ~15 us are ONE lane's 4800 dependent instructions); here the per-lane work is the scalar recurrence plus
+//     one vector, and a 4096-row step's ~190 such rows run on 190 of the 1024 SIMDs at once.
+//   * one row per lane (longer sub-lists: arms whose Mx_inv always truncates, large shares of singular postures): the
+//     same arithmetic with all N + 2 columns on the lane - 64 rows per wavefront, issue-efficient where there are
+//     enough rows to fill wavefronts.
+// The workgroup re-zeroes its sub-list's counter: the next call's first pass appends from 0 without a memset node.
+constexpr int kFinishMaxWaves = 8;  // 512 threads: two wavefronts per SIMD, 256 registers for the one-row-per-lane form
+template <class T>
+__device__ __forceinline__ T lane_bcast(T v, int src) {
+  if constexpr (sizeof(T) == 8) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(x & 0xffffffffLL), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(x >> 32), src);
+    return __builtin_bit_cast(T, (long long)(((unsigned long long)hi << 32) | lo));
+  } else {
+    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+  }
+}
+template <int N, class T>
+__global__ void __launch_bounds__(kFinishMaxWaves * 64)
+osc6_finish_kernel(long B, int* __restrict__ wl, const T* __restrict__ recs, int nulls, int coop_rounds,
+                   T* __restrict__ ug, T* __restrict__ tsg) {
+  const int sub = (int)blockIdx.x;
+  const int waves = (int)(blockDim.x >> 6);
+  const int n = wl[16 * sub];
+  __syncthreads();
+  if (threadIdx.x == 0) wl[16 * sub] = 0;
+  if (n == 0) return;
+  const long cap = wl_capacity(B);
+  const int* rows = wl + 16 * kWlLists + (long)sub * cap;
+  const T* base = recs + (long)sub * cap * rec_len(N);
+  if (n <= coop_rounds * waves) {
+    const int lane = (int)(threadIdx.x & 63);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    for (int k = wave; k < n; k += waves) {
+      const T* rec = base + (long)k * rec_len(N);
+      const long b = rows[k];
+      const int c = lane < N + 2 ? lane : N + 1;  // (idle lanes shadow the last column)
+      {
+#pragma clang fp contract(off)  // the same bits as osc6_finish_row
+        T G[1][6], wv[6];
+        osc6_rec_transform<N, T, 1, true>(rec, c, G, wv);
+        T a1 = T(-0.0), a2 = T(-0.0);
+        sfor<6>([&](auto i) ABRK_LAMBDA {
+          const T gu = lane_bcast(G[0][i()], N), gw = lane_bcast(G[0][i()], N + 1);
+          a1 = Rm<T>::fma(G[0][i()], wv[i()] * gu, a1);
+          a2 = Rm<T>::fma(G[0][i()], wv[i()] * gw, a2);
+        });
+        if (lane < N) {
+          const T ts = rec[rec_off_b1(N) + lane] - a1;
+          ug[b * N + lane] = ts + rec[rec_off_b1(N) + N + lane] - (nulls ? a2 : T(0));
+          if (tsg) tsg[b * N + lane] = ts;
+        }
+      }
+    }
+  } else {
+    for (int k = (int)threadIdx.x; k < n; k += (int)blockDim.x) {
+      T u[N], ts[N];
+      osc6_finish_row<N, T>(base + (long)k * rec_len(N), nulls != 0, u, ts);
+      const long b = rows[k];
+      store_row<N>(ug, b, u);
+      if (tsg) store_row<N>(tsg, b, ts);
+    }
+  }
+}
+// sub-lists the first pass of a B-row launch appends to
+inline int wl_sublists(long B) {
+  const long blocks = (B + kBlock - 1) / kBlock;
+  return (int)(blocks < kWlLists ? blocks : kWlLists);
 }
 
 // Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
@@ -373,6 +453,14 @@ struct LaunchArgs {
   long B;
   hipStream_t stream;
 };
+struct FinishArgs {
+  int* wl;
+  const void* rec;
+  int nulls, waves, coop_rounds;
+  void *u, *ts;
+};
+// (abrk_law.hip; arm-independent: the record holds everything)
+hipError_t launch_osc6_finish(int n_joints, int dtype, const LaunchArgs& la, const FinishArgs& a);
 template <class A, class T, bool USE_C, int KM>
 __global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
 rollout_kernel(A arm, OscP<T> P, TwoLinkP<T> K, long B, int n_steps, int every, T* __restrict__ qg,
@@ -510,6 +598,9 @@ struct OscArgs {
   const void *q, *dq, *target, *tv, *une;
   void *ierr, *u, *ts;
   int* wl = nullptr;  // worklist of B + 1 ints: rows that need the Jacobi sweeps are deferred to a dense second pass
+  // hand-over records (rec_len(N) values per list slot): the first pass alone is launched, a deferred row leaves its
+  // record, and the CALLER enqueues launch_osc6_finish behind it; the counters of `wl` are zero on entry
+  void* rec = nullptr;
   unsigned want = 0;  // != 0: the fused Mode-F kernel also writes Tx / J / M / g / C / dJ (W_TX | ... | W_DJ)
   void* out[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -561,25 +652,27 @@ struct Launch {
     auto go = [&](auto pass, dim3 grid, int mode) {
       hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass()>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
                          *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
-                         (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl);
+                         (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl, (T*)a.rec);
     };
     auto go_nots = [&](dim3 grid) {  // first pass, plain law, no training signal asked for
       if constexpr (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0))
         hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, 1, true>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
                            *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
-                           (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)nullptr, 1, a.wl);
+                           (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)nullptr, 1, a.wl, (T*)a.rec);
     };
     if constexpr (KM == 6) {
       if (a.wl) {
-        // stale counters would let pass 1 append past its sub-lists: no launch without the memset
-        if (hipError_t e = hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream); e != hipSuccess) return e;
+        // stale counters would let pass 1 append past its sub-lists: no launch without the memset (hand-over mode: the
+        // finish kernel of the previous call left them zero, the host layer zeroed a fresh buffer)
+        if (!a.rec)
+          if (hipError_t e = hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream); e != hipSuccess) return e;
         dim3 g1 = grid_for(la.B);
         // (the persistent-grid form of the first pass: a multiple of kWlLists)
         constexpr bool plain = km6_first_pass_plain(KM, UC, FEAT, A::kOrtho, 1, A::kStatic);
         if (!plain && ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;
         if (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0) && !a.ts) go_nots(g1);
         else go(ic<1>{}, g1, 1);
-        go(ic<0>{}, dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
+        if (!a.rec) go(ic<0>{}, dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
         return hipSuccess;
       }
     }

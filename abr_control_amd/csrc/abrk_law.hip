@@ -20,6 +20,23 @@ hipError_t launch_osc_law(int n, int dtype, const LaunchArgs& la, const LawArgs&
   return hipErrorInvalidValue;
 }
 template <int N, class T>
+static hipError_t finish_launch(const LaunchArgs& la, const FinishArgs& a) {
+  hipLaunchKernelGGL((osc6_finish_kernel<N, T>), dim3((unsigned)wl_sublists(la.B)), dim3(64 * a.waves), 0, la.stream,
+                     la.B, a.wl, (const T*)a.rec, a.nulls, a.coop_rounds, (T*)a.u, (T*)a.ts);
+  return hipGetLastError();
+}
+hipError_t launch_osc6_finish(int n, int dtype, const LaunchArgs& la, const FinishArgs& a) {
+  if (a.waves < 1 || a.waves > kFinishMaxWaves) return hipErrorInvalidValue;
+#define ABRK_CASE(NN) \
+  case NN:            \
+    return dtype == 0 ? finish_launch<NN, double>(la, a) : finish_launch<NN, float>(la, a);
+  switch (n) {
+    ABRK_CASE(1) ABRK_CASE(2) ABRK_CASE(3) ABRK_CASE(4) ABRK_CASE(5) ABRK_CASE(6) ABRK_CASE(7)
+  }
+#undef ABRK_CASE
+  return hipErrorInvalidValue;
+}
+template <int N, class T>
 static hipError_t limits_launch(const LaunchArgs& la, const void* P, const void* q, void* u, int acc) {
   hipLaunchKernelGGL((limits_kernel<N, T>), grid_for(la.B), dim3(kBlock), 0, la.stream,
                      *static_cast<const LimitsP<T>*>(P), la.B, (const T*)q, (T*)u, acc);

@@ -171,7 +171,12 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
     else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
   };
   osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr);
-  if (scr.deferred) return;  // parked for the dense second pass: nothing of this row is written yet
+  if (scr.deferred) {
+    // parked for the second pass: u / the training signal are not written yet.  A handed-over row is finished there from
+    // its record, without its inputs: the integral state it advanced is stored here
+    if (scr.handed_over && have_ierr) store_row<6>(ierrg, b, ierr);
+    return;
+  }
   store_row<N>(ug, b, u);
   if (tsg) store_row<N>(tsg, b, ts);
   if (have_ierr) store_row<6>(ierrg, b, ierr);

@@ -1,13 +1,98 @@
 """Batch sharding across GPUs (one process per GPU).  Rows are independent, so a shard is
-a contiguous row range and NO collective sits on the data path;
-`torch.distributed` is only used by bench.py for the barrier / max-over-ranks timing."""
+a contiguous row range and NO collective sits on the data path; what the
+ranks of a bench run exchange - a barrier and the maximum of their timings - goes through
+HostGroup below: a few bytes over a local socket, no communication library."""
+import json
 import os
+import socket
+import struct
+import time
 
 
 def dist_env():
-    """(rank, local_rank, world_size) from the torch.distributed.run environment"""
+    """(rank, local_rank, world_size) as a launcher (`python -m torch.distributed.run`, mpirun wrappers, a shell
+    loop) exports them: RANK, LOCAL_RANK, WORLD_SIZE"""
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)),
             int(os.environ.get("WORLD_SIZE", 1)))
+
+
+class HostGroup:
+    """Barrier / max / gather between the ranks of ONE node (bench.py --gpus N: one process per GPU): rank 0 listens on
+    a Unix socket in the abstract namespace, keyed by MASTER_PORT and the launcher's pid (the ranks are siblings - the
+    launcher's own rendezvous store may occupy MASTER_PORT itself, so no TCP port is taken); every operation is one
+    exchange of a small JSON value: each rank sends its value, rank 0 answers with the list of all of them."""
+
+    def __init__(self, rank, world, timeout=120.0, key=None):
+        self.rank, self.world = rank, world
+        key = key or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        name = "\0abrk_hostgroup_" + key
+        if rank == 0:
+            self.srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            self.srv.bind(name)
+            self.srv.listen(world)
+            self.srv.settimeout(timeout)
+            self.peers = [None] * world
+            for _ in range(world - 1):
+                c, _addr = self.srv.accept()
+                c.settimeout(timeout)
+                self.peers[struct.unpack("<i", self._recvn(c, 4))[0]] = c
+        else:
+            deadline = time.monotonic() + timeout
+            while True:
+                self.sock = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+                try:
+                    self.sock.connect(name)
+                    break
+                except OSError:  # rank 0 is not up yet
+                    self.sock.close()
+                    if time.monotonic() > deadline:
+                        raise
+                    time.sleep(0.02)
+            self.sock.settimeout(timeout)
+            self.sock.sendall(struct.pack("<i", rank))
+
+    @staticmethod
+    def _recvn(c, n):
+        buf = b""
+        while len(buf) < n:
+            part = c.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("a rank of the host group went away")
+            buf += part
+        return buf
+
+    @classmethod
+    def _send(cls, c, obj):
+        raw = json.dumps(obj).encode()
+        c.sendall(struct.pack("<q", len(raw)) + raw)
+
+    @classmethod
+    def _recv(cls, c):
+        return json.loads(cls._recvn(c, struct.unpack("<q", cls._recvn(c, 8))[0]))
+
+    def exchange(self, value=None):
+        """-> [value of rank 0, ..., value of rank world-1] on every rank; returns once every rank has called it"""
+        if self.world == 1:
+            return [value]
+        if self.rank == 0:
+            vals = [value] + [self._recv(self.peers[r]) for r in range(1, self.world)]
+            for r in range(1, self.world):
+                self._send(self.peers[r], vals)
+            return vals
+        self._send(self.sock, value)
+        return self._recv(self.sock)
+
+    def barrier(self):
+        self.exchange(None)
+
+    def max(self, x):
+        return max(self.exchange(float(x)))
+
+    def close(self):
+        self.barrier()
+        if self.world > 1:
+            for c in (self.peers[1:] + [self.srv]) if self.rank == 0 else [self.sock]:
+                c.close()
 
 
 def shard_range(B, rank, world):
@@ -56,7 +141,10 @@ class MultiDevice:
 
         if isinstance(ctrlr, OSC):
             return self._generate_osc(ctrlr, q, dq, *args, **kwargs)
-        if not hasattr(ctrlr, "_joint_generate"):
+        from .controllers import Damping, Joint, RestingConfig, Sliding
+
+        # (every Controller inherits _joint_generate: the test is the class, not the attribute)
+        if not isinstance(ctrlr, (Sliding, Joint, Damping, RestingConfig)):
             raise TypeError(f"MultiDevice.generate: {type(ctrlr).__name__} has no sharded entry point")
         from ._lib import DeviceArray
 

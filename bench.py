@@ -39,7 +39,9 @@ FP64_VALU_PEAK_TF = 78.6   # = 1/2 of the 157.3 TF fp32 vector peak
 ISSUE_PEAK_NOMINAL = {"f64": 1024 * 16 * 2.4e9, "f32": 1024 * 32 * 2.4e9}
 # committed rocprofv3 evidence.  (Earlier rounds are not consulted: kernel names changed - a template parameter was added -
 # and round 2's traffic.json keyed the grid-stride kernels by grid threads instead of rows.)
-PROFILE_DIRS = ("round3",)
+PROFILE_DIRS = ("round4", "round3")
+# the reference's own Cython path timed on a GPU box's host (cpu_baseline fallback where no staged reference travels)
+BASELINE_DIRS = ("round4", "round3", "round2")
 
 WORKLOADS = {
     # name: (arm, batch per GPU, dtype, kind, params kwargs, algorithmic flops per eval)
@@ -68,6 +70,9 @@ WORKLOADS = {
     "ik": ("ur5", 4096, "f64", "ik", dict(method=3, n_timesteps=200), 2500),
     # position + orientation control (all six task rows, orientation algorithm 0): the masked six-row kernel
     "osc6": ("ur5", 4096, "f64", "osc", dict(kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6), 6000),
+    # the reference benchmark's Jaco2 setting (examples/timing_plots.py:37: ctrlr_dof = [True] * 5 + [False]): five of the
+    # six task rows on the general (non-orthogonal) chain - the masked six-row kernels of a one-wave-per-SIMD arm
+    "osc5_j2": ("jaco2", 4096, "f64", "osc", dict(kp=200, ctrlr_dof=[1] * 5 + [0]), 7000),
     # Sliding on the six-joint Jaco2 (general affine chain, full Christoffel matrix + dJ): the heaviest kernel of the set
     "sliding_j2": ("jaco2", 65536, "f64", "sliding", dict(), 12000),
     # the remaining secondary controllers as their own kernels (u [B,n] each)
@@ -216,8 +221,10 @@ class Runner:
             dof = list(p.ctrlr_dof)
             fast = dof == [1, 1, 1, 0, 0, 0] and p.ref_frame == 2 * self.n + 1
             b = lambda v: "true" if v else "false"
-            # six task rows from 16 k rows on: first pass (PASS = 1, the dominant kernel) + a dense second pass (PASS = 0)
-            six_two_pass = (not fast) and self.B >= 16384
+            # six task rows: first pass (PASS = 1, the dominant kernel) + a second pass for the rows whose pseudo-inverse
+            # truncates - up to 262144 rows the finish kernel on hand-over records (osc6_finish_kernel), beyond that the
+            # complete row program once more (PASS = 0); ABRK_NO_HANDOVER=1: the round-3 scheme (inline below 16 k rows)
+            six_two_pass = (not fast) and (self.B >= 16384 or not os.environ.get("ABRK_NO_HANDOVER"))
             km = 3 if fast else (2 if dof == [1, 1, 0, 0, 0, 0] and self.n <= 3 and p.ref_frame == 2 * self.n + 1 else 6)
             # ... and, the bench never asking for the training signal, the plain law's first pass is the NOTS variant
             nots = six_two_pass and not p.n_null and not os.environ.get("ABRK_BENCH_TS")
@@ -661,7 +668,7 @@ def cpu_baseline(workload, budget_s=12.0):
             rj = None
             print(f"cpu_baseline: the staged reference did not run here: {e}", file=sys.stderr)
         if rj is None:
-            for rnd in PROFILE_DIRS:
+            for rnd in BASELINE_DIRS:
                 try:
                     rj = json.load(open(os.path.join(REPO, "profiles", rnd, "reference_cython_baseline.json")))
                     rj["measured_on"] += " [committed figures: no staged reference on this machine]"
@@ -718,24 +725,14 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                          "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    dist = None
+    # coordination only (barrier + max of the timings + one gather of per-GPU figures): a few bytes over a local socket
+    # (abr_control_amd.sharding.HostGroup) - no communication library, nothing on the data path
+    group = None
     if world > 1:
-        import torch
-        import torch.distributed as dist
+        from abr_control_amd.sharding import HostGroup
 
-        # coordination only (barrier + max of timings): CPU tensors over gloo, no RCCL on the data path
-        # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the ONE
-        # JSON line - file descriptor 1 points at stderr while the process group comes up
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-            dist.barrier()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
+        group = HostGroup(rank, world)
+        group.barrier()
 
     import abr_control_amd as a
 
@@ -747,7 +744,7 @@ def main():
     B = args.batch or B0
     run = Runner(args.workload, B, device, stream)
 
-    barrier = (lambda: dist.barrier()) if dist else None
+    barrier = group.barrier if group else None
     wall, ms = run.timed(args.steps, args.warmup, barrier)
     # the same step when the fixed cost of a (graph) launch is amortised: 2000 steps, HIP events (not `value`)
     ms_long = None
@@ -756,10 +753,8 @@ def main():
         run.graph_steps = int(os.environ.get("ABRK_BENCH_GRAPH", "100"))
         _, ms_long = run.timed(2000, 0)
         run.graph_steps = gs
-    if dist:
-        tt = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt[0])
+    if group:
+        wall = group.max(wall)
     value = world * run.evals_per_launch * args.steps / wall
 
     out = None
@@ -790,10 +785,8 @@ def main():
         r4 = Runner("cfg4", hi - lo, device, stream, global_rows=(lo, G))
         k4 = max(min(args.steps, 400), 8)
         wall4, ms4 = r4.timed(k4, min(args.warmup, 50), barrier)
-        if dist:
-            tt = torch.tensor([wall4], dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            wall4 = float(tt[0])
+        if group:
+            wall4 = group.max(wall4)
         if args.dump_shard_u:  # test hook: this rank's shard of u (tests compare with the unsharded call, bit for bit)
             import hashlib
 
@@ -819,9 +812,8 @@ def main():
         mine = roofline_leg(bigr, f"{args.workload} batch={rb} on every GPU at once (barrier-aligned)",
                             args.roofline_steps, args.sustain_seconds, barrier)
         del bigr
-        gathered = [None] * world
-        dist.all_gather_object(gathered, {"rank": rank, "device": device, "us_per_launch": mine["us_per_launch"],
-                                          "achieved": mine["achieved"], "frac": mine["frac"]})
+        gathered = group.exchange({"rank": rank, "device": device, "us_per_launch": mine["us_per_launch"],
+                                   "achieved": mine["achieved"], "frac": mine["frac"]})
         if rank == 0:
             out["roofline_per_gpu"] = gathered
     # HBM-sized leg for the roofline (rank 0 only; the figure is per GPU)
@@ -882,6 +874,13 @@ def main():
             extra = Runner(w, rbx, device, stream)
             out["also"][w] = roofline_leg(extra, f"{w} batch={extra.B}", args.roofline_steps, args.sustain_seconds)
             del extra
+            if w in ("osc6", "osc5_j2", "cfg3", "cfg4"):  # and the step at the workload's own (config-sized) batch
+                small = Runner(w, WORKLOADS[w][1], device, stream)
+                _, ms_s = small.timed(400, 50)
+                st = roofline(small, ms_s, f"{w} batch={small.B} (cache-resident, launch-bound)")
+                out["also"][w]["config_sized_step"] = {"batch": small.B, "us_per_step": st["us_per_launch"],
+                                                       "evals_per_s": st["evals_per_s"], "kernel": st["kernel"]}
+                del small
     if rank == 0 and args.workload == "cfg2" and not args.no_roofline_leg and not args.no_streams_leg:
         out["concurrent_streams"] = [concurrent_streams_rate("cfg2", B, device, s, args.steps) for s in (2, 4, 8, 16)]
     if rank == 0 and args.workload == "cfg2":
@@ -891,9 +890,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    if group:
+        group.close()
 
 
 if __name__ == "__main__":

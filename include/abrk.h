@@ -418,6 +418,20 @@ int abrk_event_destroy(int device, void* ev);
 int abrk_event_record(int device, void* ev, void* stream);
 int abrk_event_elapsed_ms(int device, void* start, void* stop, float* ms); /* syncs stop */
 
+/* Diagnostics of the library's own device scratch (what the tests and a long-running host watch): the six-row OSC law
+ * (any ctrlr_dof beyond x,y,z; osc.py:134-147 - its truncating pinv) parks the rows that need the eigen-decomposition in
+ * a per-(device, stream) worklist; abrk_stream_destroy hands a stream's slot back.  Counters are process-wide and
+ * monotonic. */
+typedef struct abrk_scratch_info {
+  int64_t worklist_slots;      /* (device, stream) pairs that currently hold six-row scratch, all devices */
+  int64_t worklist_bytes;      /* device memory they hold */
+  int64_t inline_fallbacks;    /* six-row calls that ran one-pass because no scratch could be had */
+  int64_t evictions;           /* slots of idle / vanished streams that were recycled */
+  int64_t device_free_bytes;   /* hipMemGetInfo of `device` */
+  int64_t device_total_bytes;
+} abrk_scratch_info;
+int abrk_scratch_stats(int device, abrk_scratch_info* out);
+
 const char* abrk_last_error(void);
 int abrk_version(void);
 

@@ -186,7 +186,9 @@ class OracleBackend:
 class HostsimBackend:
     """the GPU row programs compiled for the CPU (tests/hostsim) - static or runtime-table arm"""
 
-    def __init__(self, arm, variant="static"):
+    def __init__(self, arm, variant="static", handover=False):
+        """handover: six-row laws run in the two-pass form libabrk launches up to 262144 rows (first pass without the
+        eigen-decomposition, deferred rows finished from their hand-over records); `deferred` counts those rows"""
         from tests import hostsim
 
         self.h = hostsim
@@ -196,9 +198,16 @@ class HostsimBackend:
             self.tab = _abi.load_table(arm)
         self.n = self.tab["n_joints"]
         self.arm = arm if variant == "static" else self.tab
-        self.name = f"hostsim-{variant}"
+        self.name = f"hostsim-{variant}" + ("-handover" if handover else "")
+        self.handover = handover
+        self.deferred = 0
 
     def osc(self, params, q, dq, t, tv=None, ie=None, une=None, dtype=np.float64):
+        if self.handover:
+            u, ts, nd = self.h.osc_generate(self.arm, params, q, dq, t, tv, ie, une, training_signal=True, dtype=dtype,
+                                            handover=True)
+            self.deferred += max(nd, 0)
+            return u, ts
         return self.h.osc_generate(self.arm, params, q, dq, t, tv, ie, une, training_signal=True, dtype=dtype)
 
     def sliding(self, params, q, dq, t, tv=None, ta=None, dtype=np.float64):
@@ -693,6 +702,63 @@ def check_near_singular_postures(backend, arm="ur5", B=600):
         assert err <= TOL_D, f"{arm} near-singular {kw}: {err:.3e}"
         worst = max(worst, err)
     return worst, beyond, trunc
+
+
+def check_six_row_near_singular(backend, arm="ur5", B=600, reference=None):
+    """all six task rows on postures next to the arm's kinematic singularities (near_singular_postures): most of them
+    take the truncating pinv(rcond=1e-4) of osc.py:145, i.e. the path the six-row kernels defer to their second pass.
+    Plain law, Coriolis term + fused secondary controllers, and every optional input (target velocity, integral
+    state over two steps, external null-space signal) against the oracle; `reference` (a second backend, e.g. the
+    inline form of the same row programs) must agree to 1e-9 where given.
+    -> (worst relative error vs the oracle, truncating rows compared)"""
+    from oracle.oracle import Oracle
+
+    o = Oracle(_abi.load_table(arm))
+    n = o.n
+    q = near_singular_postures(arm, B)
+    B = q.shape[0]
+    rng = np.random.RandomState(31)
+    dq, t = rng.uniform(-2, 2, (B, n)), rng.uniform(-0.8, 0.8, (B, 6))
+    tv, une = rng.uniform(-0.5, 0.5, (B, 6)), rng.uniform(-2, 2, (B, n))
+    ok = np.ones(B, bool)
+    trunc = np.zeros(B, bool)
+    for b in range(B):
+        J = o.J("EE", q[b], None)
+        A = J @ np.linalg.inv(o.M(q[b])) @ J.T
+        sv = np.linalg.svd(A, compute_uv=False)
+        det = abs(np.linalg.det(A))
+        ratio = sv / sv.max()
+        near = abs(det - 1e-3) < 1e-8 or (det < 1.001e-3 and np.any(np.abs(ratio - 1e-4) < 1e-8))
+        kept = ratio[ratio > 1e-4] if det < 1e-3 else ratio
+        ok[b] = not near and kept.min() > 1e-7
+        trunc[b] = det < 1e-3 and ratio.min() < 1e-4
+    assert (ok & trunc).sum() > B // 4, f"too few truncating rows ({(ok & trunc).sum()}/{B})"
+    worst = 0.0
+    variants = (dict(kw=dict(kp=200, ko=150, kv=25, ctrlr_dof=SIX)),
+                dict(kw=dict(kp=120, ko=90, kv=15, ctrlr_dof=SIX, use_C=True, orientation_algorithm=1,
+                             null_controllers=[make_damping(8), make_resting([None, 0.8, -1.6, None, 1.5, None][:n] +
+                                                                                [None] * max(0, n - 6), kp=40, kv=8)])),
+                dict(kw=dict(kp=100, ko=60, kv=12, ki=0.2, ctrlr_dof=SIX, vmax=[0.5, 1.0], use_g=False), tv=True, ext=True,
+                     steps=2))
+    for v in variants:
+        p = P(n, **v["kw"])
+        steps = v.get("steps", 1)
+        ie_o = np.zeros((B, 6)) if p.ki != 0 else None
+        ie = np.zeros((B, 6)) if p.ki != 0 else None
+        ie_r = np.zeros((B, 6)) if p.ki != 0 else None
+        for _ in range(steps):
+            uo = o.osc_batch(p, q, dq, t, tv if v.get("tv") else None, ie_o, une if v.get("ext") else None)
+            u, _ts = backend.osc(p, q, dq, t, tv if v.get("tv") else None, ie=ie, une=une if v.get("ext") else None)
+            err = rel_err(np.asarray(u, float), uo)[ok].max()
+            assert err <= TOL_D, f"{arm} six rows near-singular {v['kw']} [{backend.name}]: {err:.3e}"
+            worst = max(worst, err)
+            if reference is not None:
+                ur, _ = reference.osc(p, q, dq, t, tv if v.get("tv") else None, ie=ie_r, une=une if v.get("ext") else None)
+                d = rel_err(np.asarray(u, float), np.asarray(ur, float))[ok].max()
+                assert d <= 1e-9, f"{arm} six rows near-singular {v['kw']}: {backend.name} vs {reference.name} {d:.3e}"
+        if ie is not None:
+            assert np.allclose(ie, ie_o, rtol=1e-9, atol=1e-12)
+    return worst, int((ok & trunc).sum())
 
 
 # ---------------------------------------------------------------------------- seeded fuzz: Sliding / Joint / dynamics

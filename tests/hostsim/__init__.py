@@ -100,7 +100,9 @@ def dynamics(arm, q, dq=None, frame=None, x_off=None, want=("M",), dtype=np.floa
 
 
 def osc_generate(arm, params, q, dq, target, target_velocity=None, integrated_error=None, u_null_ext=None,
-                 training_signal=False, dtype=np.float64):
+                 training_signal=False, dtype=np.float64, handover=False):
+    """handover=True (six task rows only): the two-pass form libabrk launches up to 262144 rows - first pass without
+    the eigen-decomposition, deferred rows finished from their hand-over records; -> (..., rows deferred)"""
     name, desc, n = _arm(arm)
     dt = np.dtype(dtype)
     q, dq, target = _in(q, dt), _in(dq, dt), _in(target, dt)
@@ -110,6 +112,17 @@ def osc_generate(arm, params, q, dq, target, target_velocity=None, integrated_er
     ts = np.full((B, n), np.nan, dt) if training_signal else None
     if integrated_error is not None:
         assert integrated_error.dtype == dt and integrated_error.flags.c_contiguous
+    if handover:
+        nd = C.c_int64(0)
+        rc = _lib_for(arm).hostsim_osc_handover(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q),
+                                                _p(dq), _p(target), _p(tv), _p(integrated_error), _p(une), _p(u),
+                                                _p(ts), C.byref(nd))
+        if rc == -1:  # not a six-row law: there is no second pass to emulate
+            nd.value = -1
+            rc = _lib_for(arm).hostsim_osc(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq),
+                                           _p(target), _p(tv), _p(integrated_error), _p(une), _p(u), _p(ts))
+        assert rc == 0, rc
+        return (u, ts, nd.value) if training_signal else (u, nd.value)
     rc = _lib_for(arm).hostsim_osc(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(dq), _p(target),
                            _p(tv), _p(integrated_error), _p(une), _p(u), _p(ts))
     assert rc == 0, rc

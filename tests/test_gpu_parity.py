@@ -1607,6 +1607,119 @@ def test_gpu_six_row_deferred_pass_equals_inline_sweeps(variant):
     assert np.array_equal(big_ts, chunks_ts, equal_nan=True)  # with it: the same arithmetic, bit for bit
 
 
+@pytest.mark.parametrize("arm,variant", [("ur5", "static"), ("ur5", "rt"), ("jaco2", "static")])
+def test_gpu_six_row_handover_near_singular_postures(arm, variant):
+    """batches of up to 262144 rows run the six-row law as first pass + finish kernel on hand-over records (a deferring
+    row leaves Mx_inv, its task Jacobian rows, u_task and the joint-space sums; osc6_finish_kernel - one deferred row
+    per wavefront, each lane one column - completes it): hundreds of truncating rows (postures next to the kinematic
+    singularities), plain law / Coriolis + two fused secondary controllers / target velocity + integral state over two
+    steps + external null-space signal, against the oracle"""
+    be = cases.GpuBackend(arm, variant)
+    worst, n_trunc = cases.check_six_row_near_singular(be, arm, B=600)
+    assert n_trunc > 120 and worst <= cases.TOL_D
+
+
+_FORMS_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from abr_control_amd import _abi
+from tests import cases
+d = np.load(sys.argv[2])
+be = cases.GpuBackend(str(d["arm"]))
+out = {}
+for i, kw in enumerate((dict(kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6),
+                        dict(kp=100, ko=60, kv=12, ctrlr_dof=[1, 0, 1, 1, 1, 0], orientation_algorithm=1, use_C=True,
+                             null_controllers=[_abi.make_damping(5)]))):
+    for dt in (np.float64, np.float32):
+        u, ts = be.osc(_abi.make_osc_params(6, **kw), d["q"].astype(dt), d["dq"].astype(dt), d["t"].astype(dt), dtype=dt)
+        out[f"u{i}_{np.dtype(dt).name}"], out[f"ts{i}_{np.dtype(dt).name}"] = u, ts
+np.savez(sys.argv[3], **out)
+"""
+
+
+def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
+    """the finish kernel picks per sub-list between one deferred row per WAVEFRONT (short lists) and one per LANE (long
+    ones): a row's result must not depend on which ran - the two are different instantiations of the same solver with
+    contraction pinned off.  The same batch with every sub-list forced through each form (measurement switch
+    ABRK_FINISH_ROUNDS), fp64 and fp32: equal bit for bit, and equal to the default mix"""
+    import subprocess
+    import sys
+
+    from tests.conftest import REPO
+
+    qs = cases.near_singular_postures("ur5", 600)
+    rng = np.random.RandomState(5)
+    q = np.concatenate([qs, rng.uniform(0, 2 * np.pi, (3000 - len(qs), 6))])
+    dq, t = rng.uniform(0, 5, (len(q), 6)), rng.uniform(-1, 1, (len(q), 6))
+    np.savez(tmp_path / "in.npz", arm="ur5", q=q, dq=dq, t=t)
+    (tmp_path / "run.py").write_text(_FORMS_SCRIPT)
+    res = {}
+    for name, rounds in (("lane", "0"), ("wave", "100000"), ("default", None)):
+        env = dict(os.environ)
+        env.pop("ABRK_FINISH_ROUNDS", None)
+        if rounds is not None:
+            env["ABRK_FINISH_ROUNDS"] = rounds
+        r = subprocess.run([sys.executable, str(tmp_path / "run.py"), REPO, str(tmp_path / "in.npz"),
+                            str(tmp_path / f"{name}.npz")], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = np.load(tmp_path / f"{name}.npz")
+    for k in res["lane"].files:
+        assert np.array_equal(res["lane"][k], res["wave"][k], equal_nan=True), k
+        assert np.array_equal(res["lane"][k], res["default"][k], equal_nan=True), k
+    # ... and the truncating rows are there and right
+    uo, _ = cases.OracleBackend("ur5").osc(_abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6), q[600:1100],
+                                           dq[600:1100], t[600:1100])
+    assert np.median(cases.rel_err(res["wave"]["u0_float64"][600:1100], uo)) < 1e-10
+
+
+def test_gpu_six_row_many_short_lived_streams():
+    """the six-row kernels keep their worklist and hand-over records per (device, stream): a stream that is destroyed
+    through the library hands its slot back (device memory stays flat over 200 create - use - destroy cycles), streams
+    that stay alive beyond the cache's 64 slots recycle the least recently used idle slot, and no call ever falls back
+    to the one-pass form for want of scratch"""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+
+    be = cases.GpuBackend("ur5")
+    p = _abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6)
+    B = 2048
+    q, dq, t = draw(11, B, 6)
+    qd, dqd, td = _dev(q, dq, t)
+    ref, _ = be.osc(p, q, dq, t)
+    base = a.scratch_stats(0)
+    free = []
+    for i in range(200):
+        s = a.Stream(0)
+        u = a.DeviceArray((B, 6))
+        engine.osc_generate(be.arm_id, 6, p, qd, dqd, td, u=u, stream=s)
+        s.sync()
+        if i % 20 == 0:
+            assert np.array_equal(u.numpy(), ref)
+        del s, u
+        if i >= 4:
+            free.append(a.scratch_stats(0)["device_free_bytes"])
+    st = a.scratch_stats(0)
+    assert st["inline_fallbacks"] == base["inline_fallbacks"]
+    assert st["worklist_slots"] <= base["worklist_slots"] + 1
+    assert max(free) - min(free) <= 64 << 20, (min(free), max(free))
+    # 80 streams alive at once: more than the cache holds - the idle ones make room, nothing runs one-pass
+    keep = [a.Stream(0) for _ in range(80)]
+    outs = []
+    for s in keep:
+        u = a.DeviceArray((B, 6))
+        engine.osc_generate(be.arm_id, 6, p, qd, dqd, td, u=u, stream=s)
+        s.sync()  # (an idle stream's slot may be recycled; one with work in flight is never touched)
+        outs.append(u)
+    for u in outs:
+        assert np.array_equal(u.numpy(), ref)
+    st2 = a.scratch_stats(0)
+    assert st2["inline_fallbacks"] == base["inline_fallbacks"]
+    assert st2["evictions"] > st["evictions"] and st2["worklist_slots"] <= 64
+    del keep, outs
+    assert a.scratch_stats(0)["worklist_slots"] <= base["worklist_slots"] + 1
+
+
 def test_gpu_table_sincos_negative_and_large_angles():
     """the OSC / Sliding kernels take sin/cos through the 128-entry LDS table (abrk_sincos_table.h): negative angles,
     angles up to the routine's range (|q| < 1e5; beyond it the library path), fp64 and fp32, builtin and user arms,

@@ -67,6 +67,49 @@ def test_rows_fp32_dynamics_match_reference(arm):
     cases.check_dynamics_against_golden(cases.HostsimBackend(arm, "static"), arm, golden(arm), dtype=np.float32)
 
 
+SIX_ROW_CASES = ["ur5:osc6_alg0", "ur5:osc6_alg1", "ur5:osc6_vmax", "ur5:osc_abg", "ur5:osc_xz_b", "ur5:osc_link5",
+                 "jaco2:osc5", "jaco2:osc6_alg1", "threejoint:osc_xyg_alg0", "threejoint:osc_xyg_alg1"]
+
+
+@pytest.mark.parametrize("case_id", SIX_ROW_CASES)
+def test_rows_six_row_handover_form_matches_reference(case_id):
+    """the two-pass form of the six-row law (first pass without the eigen-decomposition; a deferring row leaves Mx_inv,
+    its task Jacobian rows, u_task and the joint-space sums in a record, osc6_finish_row completes it from there) against
+    the reference's outputs - every truncating golden row goes through the record"""
+    arm = cases.CASES[case_id]["arm"]
+    g = golden(arm)
+    be = cases.HostsimBackend(arm, "static", handover=True)
+    r = cases.check_case_against_golden(be, case_id, g)
+    assert be.deferred >= r["n_trunc_compared"], (be.deferred, r)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2"])
+def test_rows_six_row_handover_form_near_singular_postures(arm):
+    """hundreds of truncating rows (postures next to the kinematic singularities) through the hand-over records: plain
+    law, Coriolis + two fused secondary controllers, target velocity + integral state + external null-space signal -
+    against the oracle and against the one-pass form of the same row programs"""
+    be = cases.HostsimBackend(arm, "static", handover=True)
+    worst, n_trunc = cases.check_six_row_near_singular(be, arm, B=300, reference=cases.HostsimBackend(arm, "static"))
+    assert be.deferred >= n_trunc
+    assert worst <= cases.TOL_D
+
+
+def test_rows_six_row_handover_form_fuzz_on_user_arms():
+    """random 1..7-joint user arms (runtime-table row programs), any ctrlr_dof mask / frame / optional input: the
+    two-pass form against the oracle"""
+    ran = 0
+    for fc in cases.fuzz_osc_cases(41, 14):
+        be = []
+
+        def factory(tab):
+            be.append(cases.HostsimBackend(tab, handover=True))
+            return be[-1]
+
+        cases.check_fuzz_case(factory, fc, B=64)
+        ran += be[-1].deferred
+    assert ran > 0, "no fuzz row went through the hand-over records"
+
+
 def test_rows_twojoint_closed_forms():
     """reference's analytic known answers (arms/tests/dummy_base_arm.py) on its test grids"""
     k = golden("known_answers")

@@ -70,3 +70,48 @@ def test_two_rank_gloo_shards_reassemble(tmp_path):
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "OK True 1001" in outs[0]
+
+
+GROUP_WORKER = r'''
+import sys, time
+sys.path.insert(0, sys.argv[1])
+from abr_control_amd.sharding import HostGroup, dist_env
+rank, local_rank, world = dist_env()
+if rank == 1:
+    time.sleep(0.3)  # rank 0 is listening long before: connect retries are for the opposite order, rank 2 below
+g = HostGroup(rank, world, timeout=30)
+g.barrier()
+t0 = time.perf_counter()
+if rank == 0:
+    time.sleep(0.2)
+g.barrier()  # nobody leaves before the slowest rank arrived
+waited = time.perf_counter() - t0
+assert waited >= 0.19, waited
+assert g.max(float(rank) + 0.5) == world - 0.5
+got = g.exchange({"rank": rank, "u": [rank] * 3})
+assert [x["rank"] for x in got] == list(range(world)) and got[-1]["u"] == [world - 1] * 3
+g.close()
+print("OK", rank)
+'''
+
+
+def test_three_rank_host_group_barrier_max_gather():
+    """bench.py's rank coordination (abr_control_amd.sharding.HostGroup): barrier, max-over-ranks, gather - three
+    processes over a local socket, no communication library"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in (2, 1, 0):  # rank 0 last: the others retry until it listens
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", GROUP_WORKER, REPO], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+        if rank == 2:
+            import time
+
+            time.sleep(0.2)
+    outs = [p.communicate(timeout=120) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+        assert o.startswith("OK")
