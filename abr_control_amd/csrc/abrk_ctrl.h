@@ -312,21 +312,21 @@ ABRK_INL bool uni(bool c) {
   return c;
 #endif
 }
-// the rotation slots I, I - 1, .. L of one implicit-QL pass for the uniform (one matrix per wavefront) form of ql_core
+// the rotation slots I, I - 1, .. L of one implicit-QL pass for the uniform (one matrix per wavefront) form of ql_core.
+// `m` is a scalar (the slots that exist are behind scalar compares, off the vector pipeline); a rotation radius that
+// underflows (tql2's recovery path: never on matrices of sane scale) only raises `bad` - the caller then repeats the
+// decomposition with the predicated form - so that no data-dependent branch sits on the recurrence.
 template <int K, class T, int NR, int L, int I>
 struct QlChain {
-  static ABRK_INL void run(T (&d)[K], T (&e)[K], T (&V)[NR][K], int m, T& sn, T& cs, T& pp, T& g, bool& stop) {
+  static ABRK_INL void run(T (&d)[K], T (&e)[K], T (&V)[NR][K], int m, T& sn, T& cs, T& pp, T& g, bool& bad) {
 #pragma clang fp contract(off)  // (see ql_core)
     if constexpr (I >= L) {
-      if (uni(I < m)) {
+      if (I < m) {
         const T f = sn * e[I], b = cs * e[I];
         const T r2 = Rm<T>::fma(f, f, g * g);
-        if (uni(!(r2 > T(0)))) {  // tql2's recovery from underflow: the pass ends here
-          d[I + 1] -= pp;
-          stop = true;
-          return;
-        }
-        const T ir = Rm<T>::rsqrt(r2), r = r2 * ir;
+        bad = bad || !(r2 > Rm<T>::tiny());
+        const T r2g = Rm<T>::fmax(r2, Rm<T>::tiny());
+        const T ir = Rm<T>::rsqrt(r2g), r = r2g * ir;
         e[I + 1] = r;
         sn = f * ir;
         cs = g * ir;
@@ -341,18 +341,27 @@ struct QlChain {
           V[kk()][I] = Rm<T>::fma(cs, V[kk()][I], -(sn * fz));
         });
       }
-      QlChain<K, T, NR, L, I - 1>::run(d, e, V, m, sn, cs, pp, g, stop);
+      QlChain<K, T, NR, L, I - 1>::run(d, e, V, m, sn, cs, pp, g, bad);
     }
   }
 };
+// an int that is equal on every lane, as a scalar
+ABRK_INL int uni_int(int v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_readfirstlane(v);
+#else
+  return v;
+#endif
+}
 // The solver proper: S = Z diag(lam) Z^T, applied to NR row vectors: V <- V Z.  IDENT: V comes in as the identity
 // (NR = K; its row 0 is e_0 and no reflector touches it) - V goes out as Z, the eigenvectors in its columns.  Otherwise
 // the NR rows are any vectors x^T and go out as x^T Z = (Z^T x)^T: what the wave-cooperative second pass of the six-row
 // law wants (each lane carries ONE vector and all lanes the same matrix).  UNI: every lane of the wavefront runs this
 // on the SAME matrix, so data-dependent branches are uniform - the rotation slots are real (scalar) branches and only
 // the rotations that exist are executed; without it (one matrix per lane) the predicated forms below.
+// -> false (UNI only): a rotation radius underflowed and the result is not to be used - repeat with UNI = false.
 template <int K, class T, int NR, bool IDENT, bool UNI>
-ABRK_INL void ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K]) {
+ABRK_INL bool ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K]) {
   // No contraction of a * b + c beyond the fmas that are written out: the predicated one-matrix-per-lane form and the
   // uniform one-matrix-per-wavefront form are different instantiations, and the finish kernel picks between them by the
   // length of a sub-list - the result of a row must not depend on which one ran (bit for bit: a batch and its chunks).
@@ -362,6 +371,7 @@ ABRK_INL void ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K])
   T a[K * (K + 1) / 2];  // packed lower triangle (the reduction works on a copy)
   sfor<K*(K + 1) / 2>([&](auto e) ABRK_LAMBDA { a[e()] = S[e()]; });
   T d[K], e[K];
+  bool bad = false;
   sfor<K>([&](auto i) ABRK_LAMBDA { e[i()] = T(0); });
   // ---- Householder: A <- H_k A H_k, H_k = I - beta v v^T acting on rows / columns k+1 .. K-1;  V <- V H_k
   sfor<K - 2>([&](auto kc) ABRK_LAMBDA {
@@ -426,7 +436,8 @@ ABRK_INL void ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K])
           m = small ? j : m;
           dm = small ? d[j] : dm;
         });
-        if (UNI ? uni(m == l) : (m == l)) break;
+        if constexpr (UNI) m = uni_int(m);
+        if (m == l) break;
         T g = (d[l + 1] - d[l]) * T(0.5) * Rm<T>::rcp(e[l] == T(0) ? T(1) : e[l]);
         {
           const T r2 = Rm<T>::fma(g, g, T(1));
@@ -437,9 +448,8 @@ ABRK_INL void ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K])
         T sn = T(1), cs = T(1), pp = T(0);
         bool stop = false;  // a zero rotation radius ends the pass early (tql2's recovery from underflow)
         if constexpr (UNI) {
-          // one matrix per wavefront: the slots that exist, behind scalar branches (QlChain: the rare zero radius
-          // LEAVES the chain instead of joining the next slot - no merge, no register copies on the rotation path)
-          QlChain<K, T, NR, l, K - 2>::run(d, e, V, m, sn, cs, pp, g, stop);
+          // one matrix per wavefront: the slots that exist, behind scalar compares (QlChain)
+          QlChain<K, T, NR, l, K - 2>::run(d, e, V, m, sn, cs, pp, g, bad);
         } else {
 #if ABRK_QL_BRANCHFREE
         // Every slot K-2 .. l is executed by every lane, inactive ones (i >= m, or after a stop) as the identity
@@ -507,7 +517,7 @@ ABRK_INL void ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K])
           constexpr int j = l + jj();
           e[j] = (m == j) ? T(0) : e[j];
         });
-        if (UNI ? uni(!stop) : !stop) {
+        if (UNI || !stop) {
           d[l] -= pp;
           e[l] = g;
         }
@@ -515,6 +525,7 @@ ABRK_INL void ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K])
     }
   });
   sfor<K>([&](auto i) ABRK_LAMBDA { lam[i()] = d[i()]; });
+  return UNI ? !uni(bad) : true;
 }
 template <int K, class T>
 ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
@@ -1190,7 +1201,14 @@ ABRK_INL void osc6_rec_transform(const T* __restrict__ rec, int col, T (&G)[NV][
   sfor<NV>([&](auto k) ABRK_LAMBDA {
     sfor<6>([&](auto r) ABRK_LAMBDA { G[k()][r()] = rec[rec_off_x() + r() * XS + col + k()]; });
   });
-  ql_core<6, T, NV, false, UNI>(S, G, lam);
+  if (!ql_core<6, T, NV, false, UNI>(S, G, lam)) {
+    if constexpr (UNI) {  // (cold: a rotation radius underflowed - the predicated form has tql2's recovery path)
+      sfor<NV>([&](auto k) ABRK_LAMBDA {
+        sfor<6>([&](auto r) ABRK_LAMBDA { G[k()][r()] = rec[rec_off_x() + r() * XS + col + k()]; });
+      });
+      ql_core<6, T, NV, false, false>(S, G, lam);
+    }
+  }
   pinv_weights<6>(lam, T(1e-3) * T(0.1), wv);
 }
 // the whole second pass of one row on one lane (host check build; the GPU spreads the columns over lanes)
@@ -1431,7 +1449,8 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       // the row joins its wavefront's sub-list; in hand-over mode it also leaves everything the second pass needs -
       // Mx_inv, the task Jacobian rows, u_task and the two joint-space sums around J^T f - so that the pass runs the
       // eigen-decomposition and nothing else (abrk_device.h rec_*; osc6_finish below reads it back)
-      if (T* rec = js.template claim<T>(rec_len(N))) {
+      if (js.claim()) {
+        T* rec = js.template record<T>(rec_len(N));
         constexpr int XS = rec_xs(N);
         T sv[22];
         sfor<21>([&](auto e) ABRK_LAMBDA { sv[e()] = Am[e()]; });

@@ -926,28 +926,37 @@ struct ScratchBase {
   static constexpr bool kNoTs = false;
   bool allow_defer = false, deferred = false;
   ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
-  // where a deferring row parks itself (set by the kernel; the host check build passes plain arrays): the worklist, this
-  // wavefront's sub-list, the row's index and - hand-over mode - the record store (rec_len(N) values per list slot)
+  // where a deferring row parks itself (set by the kernel; the host check build passes plain arrays).
+  //   hand-over mode (rec_base != nullptr; batches up to 262144 rows): the row's record is rec_base[row] - no list, no
+  //     atomic; the kernel notes WHICH rows deferred as one 64-bit mask per 64-row chunk (osc_kernel: a ballot after the
+  //     row program), and the finish kernel compacts the masks;
+  //   recompute mode: the row's index joins sub-list wl_sub of the worklist `wl` (an atomic slot) and the second pass
+  //     runs the complete row program on it.
   int* wl = nullptr;
   void* rec_base = nullptr;
   long wl_cap = 0, row = 0;
   int wl_sub = 0;
   bool handed_over = false;
-  // appends the row to its sub-list; -> its hand-over record (nullptr: the second pass recomputes the row)
-  template <class T>
-  ABRK_INL T* claim(int len) {
-    if (!wl) return nullptr;
+  bool handover = false;  // hand-over mode (rec_base is valid)
+  // -> true: hand-over mode, the row's record is record<T>(len); false: recompute mode, the row was appended to its
+  // sub-list.  (A flag, not a null test of the pointer: `rec_base` is a generic pointer here, and the gfx950 backend of
+  // ROCm 7.2 fails on the aperture test a generic null check can fold into - "V_CMP_NE_U32 0, $src_shared_base".)
+  ABRK_INL bool claim() {
+    if (handover) {
+      handed_over = true;
+      return true;
+    }
+    if (wl_cap == 0) return false;
 #if defined(__HIP_DEVICE_COMPILE__)
     const int k = atomicAdd(wl + 16 * wl_sub, 1);
 #else
     const int k = wl[16 * wl_sub]++;
 #endif
-    const long slot = (long)wl_sub * wl_cap + k;
-    wl[16 * kWlLists + slot] = (int)row;
-    if (!rec_base) return nullptr;
-    handed_over = true;
-    return static_cast<T*>(rec_base) + slot * len;
+    wl[16 * kWlLists + (long)wl_sub * wl_cap + k] = (int)row;
+    return false;
   }
+  template <class T>
+  ABRK_INL T* record(int len) const { return static_cast<T*>(rec_base) + row * len; }
 };
 template <class T, int N>
 struct RegScratch : ScratchBase {

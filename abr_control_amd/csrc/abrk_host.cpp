@@ -595,7 +595,6 @@ struct WorklistSlot {
   size_t cap = 0;          // bytes
   void* rec = nullptr;     // hand-over records
   size_t rec_cap = 0;      // bytes
-  bool dirty = true;       // counters may be non-zero (fresh buffer, or a call of the recompute form ran last)
   uint64_t last_use = 0;
   std::mutex mu;
 };
@@ -604,10 +603,9 @@ std::vector<std::unique_ptr<WorklistSlot>> g_wl_cache;
 uint64_t g_wl_clock = 0;
 std::atomic<int64_t> g_wl_inline_fallbacks{0}, g_wl_evictions{0};
 constexpr size_t kWlCacheSlots = 64;
-// batches up to here hand the deferred rows' intermediate results over to the second pass (183 MB of records at most
-// for a six-joint arm in fp64); beyond, the second pass recomputes its rows (a record store in proportion to the batch
-// would cost gigabytes, and at those sizes the recomputation is 4 % of the call)
-constexpr int64_t kHandoverMaxRows = 262144;
+// batches up to kHandoverMaxRows (abrk_kernels.h: 262144) hand the deferred rows' intermediate results over to the second
+// pass (172 MB of records at most for a six-joint arm in fp64); beyond, the second pass recomputes its rows (a record
+// store in proportion to the batch would cost gigabytes, and at those sizes the recomputation is 4 % of the call)
 
 void wl_release(WorklistSlot& s) {  // caller holds s.mu (or owns the slot exclusively); the slot's stream is drained
   (void)hipSetDevice(s.device);
@@ -616,7 +614,6 @@ void wl_release(WorklistSlot& s) {  // caller holds s.mu (or owns the slot exclu
   s.buf = nullptr;
   s.rec = nullptr;
   s.cap = s.rec_cap = 0;
-  s.dirty = true;
 }
 // abrk_stream_destroy: the stream's slot leaves the cache (its launches are drained by the caller's hipStreamDestroy,
 // which waits for the stream's work; the buffers are freed after an explicit drain here)
@@ -653,12 +650,12 @@ int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, in
   // the recompute form below ~16 k rows: the second launch costs more than the divergence it removes (round 2)
   if (!handover && B < 16384) return 0;
   const size_t need = (size_t)wl_ints(B) * sizeof(int);
-  const size_t need_rec = handover ? (size_t)kWlLists * wl_capacity(B) * rec_len(n) * esz(dtype) : 0;
+  // (hand-over mode keeps one 64-bit mask per 64-row chunk in `wl` - far less than the recompute form's lists)
+  const size_t need_rec = handover ? (size_t)B * rec_len(n) * esz(dtype) : 0;
   if (Recorder* r = t_rec) {
     void *p = nullptr, *q = nullptr;
     hipError_t e = hipMalloc(&p, need);
     if (e == hipSuccess && need_rec) e = hipMalloc(&q, need_rec);
-    if (e == hipSuccess) e = hipMemset(p, 0, 16 * kWlLists * sizeof(int));  // hand-over: zero from here on (finish kernel)
     if (e != hipSuccess) {
       (void)hipGetLastError();
       if (p) (void)hipFree(p);
@@ -732,46 +729,31 @@ int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, in
     s->cap = need + need / 4;
     s->rec = q;
     s->rec_cap = q ? need_rec + need_rec / 4 : 0;
-    s->dirty = true;
   }
   *wl = s->buf;
-  if (handover) {
-    // the finish kernel leaves the counters zero; a fresh buffer, or one the recompute form used last, is zeroed here
-    if (s->dirty) {
-      if (hipMemsetAsync(s->buf, 0, 16 * kWlLists * sizeof(int), stream) != hipSuccess) {
-        (void)hipGetLastError();
-        *wl = nullptr;
-        hold.unlock();
-        g_wl_inline_fallbacks++;
-        return 0;
-      }
-      s->dirty = false;
-    }
-    *rec = s->rec;
-  } else {
-    s->dirty = true;
-  }
+  if (handover) *rec = s->rec;
   return 0;
 }
 
-// wavefronts per sub-list in the finish kernel: enough for ~8 % deferred rows in one wave-cooperative round
-// (random UR5 states with all six task rows: 4.6 %); ABRK_FINISH_WAVES / ABRK_FINISH_ROUNDS: measurement switches
-int finish_waves(int64_t B) {
-  static const int forced = [] {
-    const char* e = getenv("ABRK_FINISH_WAVES");
-    return e ? atoi(e) : 0;
-  }();
-  if (forced >= 1 && forced <= kFinishMaxWaves) return forced;
-  const int64_t per_list = (B + wl_sublists((long)B) - 1) / wl_sublists((long)B);
-  const int64_t want = (per_list * 8 + 99) / 100;
-  return (int)(want < 4 ? 4 : want > kFinishMaxWaves ? kFinishMaxWaves : want);
+// finish kernel of the hand-over form: measurement switches (read once)
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+// deferred rows up to which a wavefront takes ONE row (above: one row per lane).  Four latency-bound wavefronts share a
+// SIMD without slowing each other much; beyond that the per-lane form's 64 rows per wavefront win.
+int finish_coop_max() {
+  static const int v = env_int("ABRK_FINISH_COOP_MAX", 4096);
+  return v;
 }
 int finish_coop_rounds() {
-  static const int v = [] {
-    const char* e = getenv("ABRK_FINISH_ROUNDS");
-    return e ? atoi(e) : 2;
-  }();
+  static const int v = env_int("ABRK_FINISH_ROUNDS", 2);
   return v;
+}
+int finish_grid_for(int64_t B) {
+  static const int forced = env_int("ABRK_FINISH_GRID", 0);
+  const int lo = (int)((B + (int64_t)kFinishMaxRounds * kFinishWaves * 64 - 1) / ((int64_t)kFinishMaxRounds * kFinishWaves * 64));
+  return forced >= lo ? forced : finish_grid((long)B);
 }
 
 int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
@@ -931,7 +913,8 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   const ArmOps* ops = a->ops;
   const hipStream_t hs = (hipStream_t)stream;
   // hand-over mode: the arm's first pass, then the arm-independent finish kernel on the records it left
-  FinishArgs fa{oa.wl, oa.rec, (P->n_null > 0 || u_null_ext) ? 1 : 0, finish_waves(B), finish_coop_rounds(), oa.u, oa.ts};
+  FinishArgs fa{oa.wl, oa.rec, (P->n_null > 0 || u_null_ext) ? 1 : 0, finish_grid_for(B), finish_coop_max(),
+                finish_coop_rounds(), oa.u, oa.ts};
   return dispatch(st, a, dtype, [=](const void* rt) {
     OscArgs o = oa;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;

@@ -2,6 +2,8 @@
 // launch table.  Each arm translation unit (abrk_arm_<name>.hip, abrk_arm_rt<N>.hip)
 // instantiates these for its arm policy and both arithmetic types.
 #pragma once
+#include <cstdlib>
+
 #include "abrk_rows.h"
 
 namespace abrk {
@@ -130,6 +132,19 @@ __device__ __forceinline__ void load_sincos_table(T* tab, int lane) {
   __syncthreads();
 }
 static_assert(kBlock == 64 && kSinCosN == 128, "two table entries per lane");
+// ... by a workgroup of any number of wavefronts (the x,y,z OSC kernels: 1 - 4, osc_waves below): one copy per workgroup
+template <class T>
+__device__ __forceinline__ void load_sincos_table_wg(T* tab) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef T t2 __attribute__((ext_vector_type(2)));
+  const d2* src = reinterpret_cast<const d2*>(&kSinCosTab[0][0]);
+  t2* dst = reinterpret_cast<t2*>(tab);
+  for (int i = (int)threadIdx.x; i < kSinCosN; i += (int)blockDim.x) {
+    const d2 a = src[i];
+    dst[i] = t2{(T)a.x, (T)a.y};
+  }
+  __syncthreads();
+}
 // scratch of kernels without a Coriolis recursion: nothing but the table pointer
 template <class T, int N>
 struct TabScratch : RegScratch<T, N> {
@@ -216,51 +231,94 @@ constexpr bool km6_first_pass_plain(int km, bool use_c, int feat, bool ortho, in
 // PASS (six-row kernels): 0 = the complete row program (modes 0 and 2: the sweeps are compiled in; one wave per SIMD),
 // 1 = the first pass (mode 1) - no eigen-decomposition in the code at all, two waves per SIMD.
 // NOTS (first pass of the plain six-row law only): the caller wants no training signal - see ScratchBase::kNoTs.
+// Workgroup shape of the OSC kernels.  Rows never share data, so a workgroup is just a dispatch unit: one wavefront for
+// the six-row kernels (their worklist / mask bookkeeping is per 64-row chunk) and for small batches (4096 rows = 64
+// wavefronts, one per CU); the x,y,z kernels of large launches take osc_waves(B) wavefronts per workgroup - single-
+// wavefront workgroups are dispatched at ~1.1 per ns chip-wide, which at 131072 rows (2048 of them: one residency round
+// of the chip, the 8-way shard of BASELINE config 4) is ~1.9 us of a 10.7 us step.  The LDS of a workgroup is dynamic:
+// [sin/cos table][slab of wavefront 0][slab of wavefront 1]...
+constexpr int kOscMaxWaves = 4;
+constexpr int osc_max_threads(int km) { return km <= 3 ? kOscMaxWaves * kBlock : kBlock; }
+template <class A, class T, int KM, bool USE_C>
+constexpr bool osc_uses_slab() {
+  return (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) || (KM == 6 && (ABRK_KM6_LDS != 0));
+}
+template <class A, class T, int KM, bool USE_C>
+constexpr size_t osc_lds_bytes(int waves) {
+  return ((ABRK_SINCOS_TABLE != 0) ? 2 * kSinCosN * sizeof(T) : 16) +
+         (osc_uses_slab<A, T, KM, USE_C>() ? (size_t)waves * slab_pairs<A::N>() * kBlock * 2 * sizeof(T) : 0);
+}
+inline int osc_waves(long B) {
+  static const int forced = [] {
+    const char* e = getenv("ABRK_OSC_WAVES");  // measurement switch
+    return e ? atoi(e) : 0;
+  }();
+  if (forced >= 1 && forced <= kOscMaxWaves) return forced;
+  return B >= 65536 ? kOscMaxWaves : 1;
+}
+extern __shared__ __attribute__((aligned(16))) unsigned char osc_smem[];
 template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOTS = false>
-__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic))
+__global__ void __launch_bounds__(osc_max_threads(KM), osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl,
            T* __restrict__ rec) {
   constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
   // the slab: scratch of the Coriolis recursion (orthogonal chains) and / or the row store of the six-row law
-  constexpr bool kLds = (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) || (KM == 6 && (ABRK_KM6_LDS != 0));
-  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
-  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);  // every lane takes part: before any exit
+  constexpr bool kLds = osc_uses_slab<A, T, KM, USE_C>();
   using V2 = typename LdsScratch<T, A::N>::V2;
-  __shared__ V2 slab[kLds ? slab_pairs<A::N>() * kBlock : 1];
+  T* const sctab = reinterpret_cast<T*>(osc_smem);
+  const int lane = (int)(threadIdx.x & (kBlock - 1));
+  V2* slab = reinterpret_cast<V2*>(osc_smem + (kTab ? 2 * kSinCosN * sizeof(T) : 16));
+  if constexpr (KM <= 3) {
+    if constexpr (kTab) load_sincos_table_wg(sctab);  // every lane takes part: before any exit
+    if constexpr (kLds) slab += __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kBlock)) * (slab_pairs<A::N>() * kBlock);
+  } else {
+    if constexpr (kTab) load_sincos_table(sctab, lane);
+  }
+  const bool handover = rec != nullptr;
   auto row = [&](long b, bool allow_defer) ABRK_LAMBDA {
     auto go = [&](auto& scr) ABRK_LAMBDA {
       scr.allow_defer = allow_defer;
       if (allow_defer) {  // where a deferring row parks itself (ScratchBase::claim, called by the law)
         scr.wl = wl;
         scr.rec_base = rec;
+        scr.handover = handover;
         scr.wl_sub = (int)(blockIdx.x % kWlLists);
         scr.wl_cap = wl_capacity(B);
         scr.row = b;
       }
       osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+      return scr.deferred;
     };
     if constexpr (kLds && NOTS) {
       static_assert(PASS == 1 && KM == 6 && FEAT == 0, "NOTS is instantiated for the first pass of the plain six-row law");
       NoTs<DeferOnly<LdsScratch<T, A::N>>> scr;
       scr.slab = slab;
-      scr.lane = (int)threadIdx.x;
+      scr.lane = lane;
       scr.sctab = sctab;
-      go(scr);
+      return go(scr);
     } else if constexpr (kLds) {
       std::conditional_t<PASS == 1, DeferOnly<LdsScratch<T, A::N>>, LdsScratch<T, A::N>> scr;
       scr.slab = slab;
-      scr.lane = (int)threadIdx.x;
+      scr.lane = lane;
       scr.sctab = sctab;
-      go(scr);
+      return go(scr);
     } else if constexpr (kTab) {
       std::conditional_t<PASS == 1, DeferOnly<TabScratch<T, A::N>>, TabScratch<T, A::N>> scr;
       scr.sctab = sctab;
-      go(scr);
+      return go(scr);
     } else {
       std::conditional_t<PASS == 1, DeferOnly<RegScratch<T, A::N>>, RegScratch<T, A::N>> scr;
-      go(scr);
+      return go(scr);
+    }
+  };
+  // hand-over mode: which rows of a 64-row chunk deferred, as one mask per chunk (every chunk writes its mask, so the
+  // array needs no clearing between calls); the finish kernel compacts the masks
+  auto note = [&](long b, bool deferred) ABRK_LAMBDA {
+    if (handover) {
+      const unsigned long long m = __ballot(deferred);
+      if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(wl)[b / kBlock] = m;
     }
   };
   if constexpr (km6_first_pass_plain(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic)) {
@@ -269,8 +327,10 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
     // row program's literals and the controller's parameters in scalar registers across iterations, runs out of them
     // (116 spilled to vector-register lanes: 190 v_readlane per row, each a vector-ALU slot) and holds 40 hoisted
     // vector constants on top.
-    ABRK_ROW_INDEX
-    row(b, true);
+    long b = (long)blockIdx.x * kBlock + threadIdx.x;
+    const bool in = b < B;
+    const bool deferred = in && row(b, true);
+    note((long)blockIdx.x * kBlock, deferred);
   } else if constexpr (KM == 6) {
     // one call site for the row program (it is inlined): modes 0 / 1 launch one lane per row and leave the loop after
     // their row, mode 2 strides a persistent grid over the worklist.  (Only the six-row kernels defer: with x,y,z
@@ -287,17 +347,25 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
     const long n = list ? (long)wl[16 * sub] : B;
     const long first = list ? (long)(blockIdx.x / kWlLists) * kBlock + threadIdx.x : (long)blockIdx.x * kBlock + threadIdx.x;
     const long step = list ? (long)(gridDim.x / kWlLists) * kBlock : (long)gridDim.x * kBlock;
-    for (long i = first; i < n; i += step) row(list ? (long)rows[i] : i, mode == 1);
+    for (long i = first; i < n; i += step) {
+      const bool deferred = row(list ? (long)rows[i] : i, mode == 1);
+      // (hand-over mode: the lanes still in the loop are a prefix of the chunk - lane 0 is among them or the chunk is
+      //  past the end - so one ballot is the chunk's mask)
+      if (mode == 1) note(i - threadIdx.x, deferred);
+    }
   } else {
-    ABRK_ROW_INDEX
+    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 1 - 4 wavefronts per workgroup (osc_waves)
+    if (b >= B) return;
     row(b, false);
   }
 }
 
-// ---- second pass of the six-row law on hand-over records (osc_law6's deferral branch wrote them; abrk_device.h
-// rec_*; the arithmetic: abrk_ctrl.h osc6_rec_transform).  One workgroup per sub-list of the worklist, kFinishMaxWaves
-// wavefronts at most.  Two forms, chosen per sub-list by its length n:
-//   * wave-cooperative (n <= 2 x the workgroup's wavefronts): ONE deferred row per wavefront.  Every lane decomposes the
+// ---- second pass of the six-row law on hand-over records (osc_law6's deferral branch wrote them, one per deferring
+// row, at rec[row]; abrk_device.h rec_*; the arithmetic: abrk_ctrl.h osc6_rec_transform).  Which rows deferred arrives
+// as one 64-bit mask per 64-row chunk (the first pass's ballot).  Every workgroup compacts ALL masks (<= 32 KB at
+// 262144 rows; a block-wide prefix sum of the popcounts) and takes the deferred rows whose global index falls on its
+// slots - the rows are spread evenly over the grid whatever wavefronts they came from.  Two forms, one per launch:
+//   * wave-cooperative (P <= coop_max rows, <= coop_rounds per slot): a slot is a WAVEFRONT.  Every lane decomposes the
 //     row's 6 x 6 Mx_inv - redundantly, so nothing crosses lanes and every data-dependent branch of the QL iteration is
 //     uniform (only the rotations that exist are executed: ~35 of the 68 slots the predicated per-lane form walks) -
 //     and applies the transformations to ITS column of [J | u_task | J v]; lanes N and N + 1 then hand their column to
@@ -305,11 +373,11 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 //     path of every small six-row step (4096 rows: 95 % of the 64 wavefronts have a truncating row, 21 us per step of
 //     which ~15 us are ONE lane's 4800 dependent instructions); here the per-lane work is the scalar recurrence plus
 //     one vector, and a 4096-row step's ~190 such rows run on 190 of the 1024 SIMDs at once.
-//   * one row per lane (longer sub-lists: arms whose Mx_inv always truncates, large shares of singular postures): the
-//     same arithmetic with all N + 2 columns on the lane - 64 rows per wavefront, issue-efficient where there are
-//     enough rows to fill wavefronts.
-// The workgroup re-zeroes its sub-list's counter: the next call's first pass appends from 0 without a memset node.
-constexpr int kFinishMaxWaves = 8;  // 512 threads: two wavefronts per SIMD, 256 registers for the one-row-per-lane form
+//   * one row per lane (more rows than that: arms whose Mx_inv always truncates, large batches): a slot is a LANE, the
+//     same arithmetic with all N + 2 columns on it - issue-efficient where there are enough rows to fill wavefronts.
+constexpr int kFinishWaves = 8;      // 512 threads: two wavefronts per SIMD, 256 registers for the one-row-per-lane form
+constexpr int kFinishMaxRounds = 4;  // rows per slot at most: the host sizes the grid for it (finish_grid)
+constexpr int kFinishMaskPer = 8;    // masks per thread: 512 x 8 x 64 = 262144 rows
 template <class T>
 __device__ __forceinline__ T lane_bcast(T v, int src) {
   if constexpr (sizeof(T) == 8) {
@@ -322,25 +390,63 @@ __device__ __forceinline__ T lane_bcast(T v, int src) {
   }
 }
 template <int N, class T>
-__global__ void __launch_bounds__(kFinishMaxWaves * 64)
-osc6_finish_kernel(long B, int* __restrict__ wl, const T* __restrict__ recs, int nulls, int coop_rounds,
-                   T* __restrict__ ug, T* __restrict__ tsg) {
-  const int sub = (int)blockIdx.x;
-  const int waves = (int)(blockDim.x >> 6);
-  const int n = wl[16 * sub];
+__global__ void __launch_bounds__(kFinishWaves * 64)
+osc6_finish_kernel(long B, const unsigned long long* __restrict__ masks, const T* __restrict__ recs, int nulls,
+                   int coop_max, int coop_rounds, T* __restrict__ ug, T* __restrict__ tsg) {
+  constexpr int kThreads = kFinishWaves * 64;
+  __shared__ int wave_tot[kFinishWaves];
+  __shared__ int mine[kFinishMaxRounds * kThreads];
+  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- every workgroup: the global index of each deferred row (thread t owns masks [t per, (t + 1) per))
+  const long nchunk = (B + kBlock - 1) / kBlock;
+  const int per = (int)((nchunk + kThreads - 1) / kThreads);
+  unsigned long long m[kFinishMaskPer];
+  int cnt = 0;
+  sfor<kFinishMaskPer>([&](auto k) ABRK_LAMBDA {
+    const long idx = (long)tid * per + k();
+    m[k()] = (k() < per && idx < nchunk) ? masks[idx] : 0ull;
+    cnt += __popcll(m[k()]);
+  });
+  int incl = cnt;
+  for (int d = 1; d < 64; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if (lane >= d) incl += v;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  if (threadIdx.x == 0) wl[16 * sub] = 0;
-  if (n == 0) return;
-  const long cap = wl_capacity(B);
-  const int* rows = wl + 16 * kWlLists + (long)sub * cap;
-  const T* base = recs + (long)sub * cap * rec_len(N);
-  if (n <= coop_rounds * waves) {
-    const int lane = (int)(threadIdx.x & 63);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    for (int k = wave; k < n; k += waves) {
-      const T* rec = base + (long)k * rec_len(N);
-      const long b = rows[k];
+  int before = 0, P = 0;
+  sfor<kFinishWaves>([&](auto w) ABRK_LAMBDA {
+    const int t = wave_tot[w()];
+    before += (w() < wave) ? t : 0;
+    P += t;
+  });
+  if (P == 0) return;
+  const bool coop = P <= coop_max && P <= coop_rounds * (int)gridDim.x * kFinishWaves;
+  const int SB = coop ? kFinishWaves : kThreads;  // slots of a workgroup (a slot: a wavefront / a lane)
+  const int S = (int)gridDim.x * SB;
+  {
+    int p = before + incl - cnt;
+    sfor<kFinishMaskPer>([&](auto k) ABRK_LAMBDA {
+      unsigned long long bits = m[k()];
+      while (bits) {
+        const int bit = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int s = p % S, r = p / S;
+        if (s / SB == (int)blockIdx.x && r < kFinishMaxRounds) mine[r * SB + s % SB] = (int)(((long)tid * per + k()) * kBlock + bit);
+        p++;
+      }
+    });
+  }
+  __syncthreads();
+  const int rounds = (P + S - 1) / S;
+  if (coop) {
+    for (int r = 0; r < rounds; r++) {
+      if (r * S + (int)blockIdx.x * SB + wave >= P) break;  // (uniform per wavefront)
+      const long b = mine[r * SB + wave];
+      const T* rec = recs + b * rec_len(N);
       const int c = lane < N + 2 ? lane : N + 1;  // (idle lanes shadow the last column)
+      // the two joint-space sums are asked for with the rest of the record: one memory round trip, not two
+      const T b1 = rec[rec_off_b1(N) + (lane < N ? lane : 0)], b2 = rec[rec_off_b1(N) + N + (lane < N ? lane : 0)];
       {
 #pragma clang fp contract(off)  // the same bits as osc6_finish_row
         T G[1][6], wv[6];
@@ -352,28 +458,34 @@ osc6_finish_kernel(long B, int* __restrict__ wl, const T* __restrict__ recs, int
           a2 = Rm<T>::fma(G[0][i()], wv[i()] * gw, a2);
         });
         if (lane < N) {
-          const T ts = rec[rec_off_b1(N) + lane] - a1;
-          ug[b * N + lane] = ts + rec[rec_off_b1(N) + N + lane] - (nulls ? a2 : T(0));
+          const T ts = b1 - a1;
+          ug[b * N + lane] = ts + b2 - (nulls ? a2 : T(0));
           if (tsg) tsg[b * N + lane] = ts;
         }
       }
     }
   } else {
-    for (int k = (int)threadIdx.x; k < n; k += (int)blockDim.x) {
+    for (int r = 0; r < rounds && r < kFinishMaxRounds; r++) {
+      if (r * S + (int)blockIdx.x * SB + tid >= P) break;
+      const long b = mine[r * SB + tid];
       T u[N], ts[N];
-      osc6_finish_row<N, T>(base + (long)k * rec_len(N), nulls != 0, u, ts);
-      const long b = rows[k];
+      osc6_finish_row<N, T>(recs + b * rec_len(N), nulls != 0, u, ts);
       store_row<N>(ug, b, u);
       if (tsg) store_row<N>(tsg, b, ts);
     }
   }
 }
-// sub-lists the first pass of a B-row launch appends to
-inline int wl_sublists(long B) {
-  const long blocks = (B + kBlock - 1) / kBlock;
-  return (int)(blocks < kWlLists ? blocks : kWlLists);
+// workgroups of the finish kernel for a B-row call: a wavefront per deferred row while ~7 % of the rows defer (random
+// UR5 states with all six task rows: 4.6 %), 4096 wavefronts at most (four per SIMD: they are latency-bound), and never
+// fewer than one lane per kFinishMaxRounds rows (every row may defer: arms whose Mx_inv always truncates)
+inline int finish_grid(long B) {
+  long g = (B * 7 / 100 + kFinishWaves - 1) / kFinishWaves;
+  const long lo = (B + (long)kFinishMaxRounds * kFinishWaves * 64 - 1) / ((long)kFinishMaxRounds * kFinishWaves * 64);
+  if (g > 512) g = 512;
+  if (g < lo) g = lo;
+  return (int)(g < 1 ? 1 : g);
 }
-
+constexpr long kHandoverMaxRows = (long)kFinishWaves * 64 * kFinishMaskPer * kBlock;  // 262144: the masks one workgroup compacts
 // Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
 // cooperative stores and (use_C) the scratch of the Coriolis recursion, which is dead by the time the first row is
 // parked.  FEAT is 0 (the plain law) or 2 (every optional input).
@@ -454,9 +566,9 @@ struct LaunchArgs {
   hipStream_t stream;
 };
 struct FinishArgs {
-  int* wl;
+  const void* masks;  // one 64-bit mask per 64-row chunk: the rows the first pass deferred
   const void* rec;
-  int nulls, waves, coop_rounds;
+  int nulls, grid, coop_max, coop_rounds;
   void *u, *ts;
 };
 // (abrk_law.hip; arm-independent: the record holds everything)
@@ -598,8 +710,8 @@ struct OscArgs {
   const void *q, *dq, *target, *tv, *une;
   void *ierr, *u, *ts;
   int* wl = nullptr;  // worklist of B + 1 ints: rows that need the Jacobi sweeps are deferred to a dense second pass
-  // hand-over records (rec_len(N) values per list slot): the first pass alone is launched, a deferred row leaves its
-  // record, and the CALLER enqueues launch_osc6_finish behind it; the counters of `wl` are zero on entry
+  // hand-over records (rec_len(N) values per ROW): the first pass alone is launched, a deferred row leaves its record,
+  // `wl` receives one 64-bit mask per 64-row chunk, and the CALLER enqueues launch_osc6_finish behind it
   void* rec = nullptr;
   unsigned want = 0;  // != 0: the fused Mode-F kernel also writes Tx / J / M / g / C / dJ (W_TX | ... | W_DJ)
   void* out[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -649,21 +761,29 @@ struct Launch {
   }
   template <int KM, bool UC, int FEAT>
   static hipError_t osc_launch(const LaunchArgs& la, const OscArgs& a) {
+    // workgroups of `waves` wavefronts (the x,y,z kernels of large launches; the six-row kernels: one), LDS to match
+    const int waves = KM <= 3 ? osc_waves(la.B) : 1;
+    const size_t lds = osc_lds_bytes<A, T, KM, UC>(waves);
     auto go = [&](auto pass, dim3 grid, int mode) {
-      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass()>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
+      if (lds > 65536) {  // beyond the default dynamic-LDS limit: raise it for this instantiation, once
+        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&osc_kernel<A, T, KM, UC, FEAT, pass()>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)once;
+      }
+      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass()>), grid, dim3(kBlock * waves), lds, la.stream, arm_of(la),
                          *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
                          (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl, (T*)a.rec);
     };
     auto go_nots = [&](dim3 grid) {  // first pass, plain law, no training signal asked for
       if constexpr (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0))
-        hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, 1, true>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
+        hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, 1, true>), grid, dim3(kBlock), lds, la.stream, arm_of(la),
                            *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
                            (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)nullptr, 1, a.wl, (T*)a.rec);
     };
     if constexpr (KM == 6) {
       if (a.wl) {
-        // stale counters would let pass 1 append past its sub-lists: no launch without the memset (hand-over mode: the
-        // finish kernel of the previous call left them zero, the host layer zeroed a fresh buffer)
+        // stale counters would let pass 1 append past its sub-lists: no launch without the memset (hand-over mode: no
+        // counters - every chunk writes its mask)
         if (!a.rec)
           if (hipError_t e = hipMemsetAsync(a.wl, 0, 16 * kWlLists * sizeof(int), la.stream); e != hipSuccess) return e;
         dim3 g1 = grid_for(la.B);
@@ -676,7 +796,7 @@ struct Launch {
         return hipSuccess;
       }
     }
-    go(ic<0>{}, grid_for(la.B), 0);
+    go(ic<0>{}, dim3((unsigned)((la.B + (long)kBlock * waves - 1) / ((long)kBlock * waves))), 0);
     return hipSuccess;
   }
   template <int KM, bool UC>

@@ -8,6 +8,9 @@
 #ifndef ABRK_LATE_TARGET
 #define ABRK_LATE_TARGET 0
 #endif
+#ifndef ABRK_KM6_EARLY
+#define ABRK_KM6_EARLY 0  // measurement switch: the six-row kernels request every input up front as well
+#endif
 
 namespace abrk {
 
@@ -154,7 +157,7 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
   // kinematics to keep that kernel's register peak down.
   // (the six-row kernels ask late as well: their law, not the kinematics, is the register peak)
-  constexpr bool EARLY = FEAT < 2 && KM <= 3;
+  constexpr bool EARLY = FEAT < 2 && (KM <= 3 || (ABRK_KM6_EARLY != 0));
   // (ABRK_LATE_TARGET = 1 requests the target after the kinematics in the use_C kernels; measured unnecessary once
   //  the link wrenches of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
   constexpr bool EARLY_T = EARLY && !(USE_C && ABRK_LATE_TARGET);

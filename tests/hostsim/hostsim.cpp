@@ -103,17 +103,18 @@ int run_osc_handover(const A& arm, int n, const abrk_osc_params* P, int64_t B, c
   if (P->ki == 0) ie = nullptr;
   const int feat = (tv || ie || une) ? 2 : (p.n_null > 0 ? 1 : 0);
   const bool nulls = p.n_null > 0 || une != nullptr;
-  std::vector<int> wl((size_t)wl_ints((long)B), 0);
-  std::vector<T> rec((size_t)kWlLists * wl_capacity((long)B) * rec_len(A::N), T(0));
+  // hand-over mode as on the device: the record of row b at rec[b]; which rows deferred is the kernel's business there
+  // (a ballot per 64-row chunk) and a plain flag array here
+  std::vector<T> rec((size_t)B * rec_len(A::N), T(0));
+  std::vector<char> flag((size_t)B, 0);
   auto first = [&](long b, auto& scr, auto uc, auto ft) {
     scr.allow_defer = true;
-    scr.wl = wl.data();
     scr.rec_base = rec.data();
-    scr.wl_sub = (int)((b / kWlBlock) % kWlLists);
-    scr.wl_cap = wl_capacity((long)B);
+    scr.handover = true;
     scr.row = b;
     osc_body<A, T, 6, uc(), ft()>(b, arm, p, (long)B, (const T*)q, (const T*)dq, (const T*)tg, (const T*)tv, (T*)ie,
                                   (const T*)une, (T*)u, (T*)ts, scr);
+    flag[b] = scr.deferred;
   };
   using std::integral_constant;
   for (long b = 0; b < B; b++) {
@@ -132,17 +133,13 @@ int run_osc_handover(const A& arm, int n, const abrk_osc_params* P, int64_t B, c
     else with_feat(integral_constant<bool, false>{});
   }
   int64_t total = 0;
-  for (int sub = 0; sub < kWlLists; sub++) {
-    const int cnt = wl[16 * sub];
-    total += cnt;
-    for (int k = 0; k < cnt; k++) {
-      const long slot = (long)sub * wl_capacity((long)B) + k;
-      const long b = wl[16 * kWlLists + slot];
-      T uu[A::N], tt[A::N];
-      osc6_finish_row<A::N, T>(rec.data() + slot * rec_len(A::N), nulls, uu, tt);
-      store_row<A::N>((T*)u, b, uu);
-      if (ts) store_row<A::N>((T*)ts, b, tt);
-    }
+  for (long b = 0; b < B; b++) {
+    if (!flag[b]) continue;
+    total++;
+    T uu[A::N], tt[A::N];
+    osc6_finish_row<A::N, T>(rec.data() + b * rec_len(A::N), nulls, uu, tt);
+    store_row<A::N>((T*)u, b, uu);
+    if (ts) store_row<A::N>((T*)ts, b, tt);
   }
   if (n_deferred) *n_deferred = total;
   return 0;

@@ -1639,10 +1639,10 @@ np.savez(sys.argv[3], **out)
 
 
 def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
-    """the finish kernel picks per sub-list between one deferred row per WAVEFRONT (short lists) and one per LANE (long
-    ones): a row's result must not depend on which ran - the two are different instantiations of the same solver with
-    contraction pinned off.  The same batch with every sub-list forced through each form (measurement switch
-    ABRK_FINISH_ROUNDS), fp64 and fp32: equal bit for bit, and equal to the default mix"""
+    """the finish kernel takes one deferred row per WAVEFRONT (few of them) or one per LANE (many): a row's result must
+    not depend on which ran - the two are different instantiations of the same solver with contraction pinned off.
+    The same batch forced through each form (measurement switches ABRK_FINISH_COOP_MAX / _ROUNDS / _GRID), fp64 and
+    fp32: equal bit for bit, and equal to what the default rule picks"""
     import subprocess
     import sys
 
@@ -1655,11 +1655,12 @@ def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
     np.savez(tmp_path / "in.npz", arm="ur5", q=q, dq=dq, t=t)
     (tmp_path / "run.py").write_text(_FORMS_SCRIPT)
     res = {}
-    for name, rounds in (("lane", "0"), ("wave", "100000"), ("default", None)):
-        env = dict(os.environ)
-        env.pop("ABRK_FINISH_ROUNDS", None)
-        if rounds is not None:
-            env["ABRK_FINISH_ROUNDS"] = rounds
+    forms = (("lane", dict(ABRK_FINISH_COOP_MAX="0")),
+             ("wave", dict(ABRK_FINISH_COOP_MAX="1000000", ABRK_FINISH_ROUNDS="4", ABRK_FINISH_GRID="256")),
+             ("default", {}))
+    for name, sw in forms:
+        env = {k: v for k, v in os.environ.items() if not k.startswith("ABRK_FINISH_")}
+        env.update(sw)
         r = subprocess.run([sys.executable, str(tmp_path / "run.py"), REPO, str(tmp_path / "in.npz"),
                             str(tmp_path / f"{name}.npz")], env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
@@ -1686,7 +1687,11 @@ def test_gpu_six_row_many_short_lived_streams():
     B = 2048
     q, dq, t = draw(11, B, 6)
     qd, dqd, td = _dev(q, dq, t)
-    ref, _ = be.osc(p, q, dq, t)
+    u0 = a.DeviceArray((B, 6))
+    engine.osc_generate(be.arm_id, 6, p, qd, dqd, td, u=u0)  # (no training signal asked for: the same first pass as below)
+    ref = u0.numpy()
+    uo, _ = cases.OracleBackend("ur5").osc(p, q[:256], dq[:256], t[:256])
+    assert np.median(cases.rel_err(ref[:256], uo)) < 1e-10
     base = a.scratch_stats(0)
     free = []
     for i in range(200):

@@ -15,11 +15,10 @@ import json,sys; d=json.loads(sys.stdin.read()); print('$lab', 'B=$b', d['roofli
 for b in 4096 16384 65536; do
   ab handover_$b $b A=1
   ab round3_$b $b ABRK_NO_HANDOVER=1
-  ab lane_$b $b ABRK_FINISH_ROUNDS=0
+  ab lane_$b $b ABRK_FINISH_COOP_MAX=0
 done
-ab waves2_4096 4096 ABRK_FINISH_WAVES=2
-ab waves8_4096 4096 ABRK_FINISH_WAVES=8
-ab rounds1_4096 4096 ABRK_FINISH_ROUNDS=1
+ab grid128_4096 4096 ABRK_FINISH_GRID=128
+ab coop8k_65536 65536 ABRK_FINISH_COOP_MAX=8192 ABRK_FINISH_GRID=1024
 ab handover_262144 262144 A=1
 ab round3_262144 262144 ABRK_NO_HANDOVER=1
 # Jaco2 five rows (timing_plots.py:37)
