@@ -602,10 +602,15 @@ std::mutex g_wl_mu;
 std::vector<std::unique_ptr<WorklistSlot>> g_wl_cache;
 uint64_t g_wl_clock = 0;
 std::atomic<int64_t> g_wl_inline_fallbacks{0}, g_wl_evictions{0};
+// batches up to here take the hand-over form of the six-row law (kHandoverMaxRows is what the finish kernel can scan).
+// Measured on one box (UR5, all six rows, us per step, hand-over / recompute form): 4096 rows 17.1 / 20.9 (the recompute
+// form runs one-pass below 16 k rows), 16 k 18.3 / 32.6, 32 k 23.0 / 33.8, 64 k 35.9 / 37.0, 128 k 47.2 / 38.8, 256 k 67.8 /
+// 48.6 - beyond 64 k rows the deferred rows fill wavefronts, and re-running the row program on coalesced inputs beats
+// reading 656-byte records one lane each.
+constexpr int64_t kHandoverRows = 65536;
 constexpr size_t kWlCacheSlots = 64;
-// batches up to kHandoverMaxRows (abrk_kernels.h: 262144) hand the deferred rows' intermediate results over to the second
-// pass (172 MB of records at most for a six-joint arm in fp64); beyond, the second pass recomputes its rows (a record
-// store in proportion to the batch would cost gigabytes, and at those sizes the recomputation is 4 % of the call)
+// batches up to kHandoverRows (below) hand the deferred rows' intermediate results over to the second pass (43 MB of
+// records for a six-joint arm in fp64); beyond, the second pass recomputes its rows
 
 void wl_release(WorklistSlot& s) {  // caller holds s.mu (or owns the slot exclusively); the slot's stream is drained
   (void)hipSetDevice(s.device);
@@ -646,7 +651,12 @@ int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, in
   static const bool off = getenv("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
   // (row indices are parked as 32-bit ints: batches beyond 2^31 rows - they fit the 288 GB for fp32 arms - run inline)
   if (off || B > 0x7fffffffLL) return 0;
-  const bool handover = handover_enabled() && B <= kHandoverMaxRows;
+  static const int64_t ho_max = [] {  // measurement switch: the largest batch that takes the hand-over form
+    const char* e = getenv("ABRK_HANDOVER_MAX");
+    const int64_t v = e ? atoll(e) : kHandoverRows;
+    return v < kHandoverMaxRows ? v : (int64_t)kHandoverMaxRows;
+  }();
+  const bool handover = handover_enabled() && B <= ho_max;
   // the recompute form below ~16 k rows: the second launch costs more than the divergence it removes (round 2)
   if (!handover && B < 16384) return 0;
   const size_t need = (size_t)wl_ints(B) * sizeof(int);
@@ -740,10 +750,11 @@ int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// deferred rows up to which a wavefront takes ONE row (above: one row per lane).  Four latency-bound wavefronts share a
-// SIMD without slowing each other much; beyond that the per-lane form's 64 rows per wavefront win.
+// deferred rows up to which a wavefront takes ONE row (above: one row per lane): while there is about one such wavefront
+// per SIMD (1024) the cooperative form is bound by a single instruction stream (~8 us); two on a SIMD halve each other's
+// issue rate, and from there the per-lane form's 64 rows per wavefront (~12 us whatever the count) wins.
 int finish_coop_max() {
-  static const int v = env_int("ABRK_FINISH_COOP_MAX", 4096);
+  static const int v = env_int("ABRK_FINISH_COOP_MAX", 1536);
   return v;
 }
 int finish_coop_rounds() {
@@ -752,8 +763,8 @@ int finish_coop_rounds() {
 }
 int finish_grid_for(int64_t B) {
   static const int forced = env_int("ABRK_FINISH_GRID", 0);
-  const int lo = (int)((B + (int64_t)kFinishMaxRounds * kFinishWaves * 64 - 1) / ((int64_t)kFinishMaxRounds * kFinishWaves * 64));
-  return forced >= lo ? forced : finish_grid((long)B);
+  const int lo = (int)((B + (int64_t)kFinishMaxRounds * kBlock - 1) / ((int64_t)kFinishMaxRounds * kBlock));
+  return forced >= lo ? forced : finish_grid((long)B, finish_coop_max() > 0 ? finish_coop_max() : 1);
 }
 
 int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {

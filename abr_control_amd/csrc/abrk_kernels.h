@@ -232,11 +232,10 @@ constexpr bool km6_first_pass_plain(int km, bool use_c, int feat, bool ortho, in
 // 1 = the first pass (mode 1) - no eigen-decomposition in the code at all, two waves per SIMD.
 // NOTS (first pass of the plain six-row law only): the caller wants no training signal - see ScratchBase::kNoTs.
 // Workgroup shape of the OSC kernels.  Rows never share data, so a workgroup is just a dispatch unit: one wavefront for
-// the six-row kernels (their worklist / mask bookkeeping is per 64-row chunk) and for small batches (4096 rows = 64
-// wavefronts, one per CU); the x,y,z kernels of large launches take osc_waves(B) wavefronts per workgroup - single-
-// wavefront workgroups are dispatched at ~1.1 per ns chip-wide, which at 131072 rows (2048 of them: one residency round
-// of the chip, the 8-way shard of BASELINE config 4) is ~1.9 us of a 10.7 us step.  The LDS of a workgroup is dynamic:
-// [sin/cos table][slab of wavefront 0][slab of wavefront 1]...
+// the six-row kernels (their worklist / mask bookkeeping is per 64-row chunk); the x,y,z kernels can take 1 - 4
+// wavefronts per workgroup (osc_waves; ABRK_OSC_WAVES) - built to test whether the dispatch of single-wavefront
+// workgroups (~1.1 per ns chip-wide) bounds the 131072-row shard of BASELINE config 4: it does not (osc_waves).  The LDS
+// of a workgroup is dynamic: [sin/cos table][slab of wavefront 0][slab of wavefront 1]...
 constexpr int kOscMaxWaves = 4;
 constexpr int osc_max_threads(int km) { return km <= 3 ? kOscMaxWaves * kBlock : kBlock; }
 template <class A, class T, int KM, bool USE_C>
@@ -254,7 +253,11 @@ inline int osc_waves(long B) {
     return e ? atoi(e) : 0;
   }();
   if (forced >= 1 && forced <= kOscMaxWaves) return forced;
-  return B >= 65536 ? kOscMaxWaves : 1;
+  // Measured (round 4, UR5 + g + C, us per step with 1 / 2 / 4 wavefronts per workgroup): 131072 rows 10.53 / 10.22 /
+  // 10.43, 262144 rows 18.4 / 19.5 / 18.7, 2^20 rows 58.8 / 60.6 / 58.7, 8 M rows 495.9 / 494.9 / 496.8: no effect - the
+  // shard-sized step is one residency round of 2048 wavefronts at ~1650 issue slots each, not dispatch.  One it stays.
+  (void)B;
+  return 1;
 }
 extern __shared__ __attribute__((aligned(16))) unsigned char osc_smem[];
 template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOTS = false>
@@ -365,7 +368,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 // as one 64-bit mask per 64-row chunk (the first pass's ballot).  Every workgroup compacts ALL masks (<= 32 KB at
 // 262144 rows; a block-wide prefix sum of the popcounts) and takes the deferred rows whose global index falls on its
 // slots - the rows are spread evenly over the grid whatever wavefronts they came from.  Two forms, one per launch:
-//   * wave-cooperative (P <= coop_max rows, <= coop_rounds per slot): a slot is a WAVEFRONT.  Every lane decomposes the
+//   * wave-cooperative (P <= coop_max rows, <= coop_rounds per slot): a slot is a WAVEFRONT (= a workgroup).  Every lane decomposes the
 //     row's 6 x 6 Mx_inv - redundantly, so nothing crosses lanes and every data-dependent branch of the QL iteration is
 //     uniform (only the rotations that exist are executed: ~35 of the 68 slots the predicated per-lane form walks) -
 //     and applies the transformations to ITS column of [J | u_task | J v]; lanes N and N + 1 then hand their column to
@@ -375,9 +378,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 //     one vector, and a 4096-row step's ~190 such rows run on 190 of the 1024 SIMDs at once.
 //   * one row per lane (more rows than that: arms whose Mx_inv always truncates, large batches): a slot is a LANE, the
 //     same arithmetic with all N + 2 columns on it - issue-efficient where there are enough rows to fill wavefronts.
-constexpr int kFinishWaves = 8;      // 512 threads: two wavefronts per SIMD, 256 registers for the one-row-per-lane form
 constexpr int kFinishMaxRounds = 4;  // rows per slot at most: the host sizes the grid for it (finish_grid)
-constexpr int kFinishMaskPer = 8;    // masks per thread: 512 x 8 x 64 = 262144 rows
 template <class T>
 __device__ __forceinline__ T lane_bcast(T v, int src) {
   if constexpr (sizeof(T) == 8) {
@@ -389,60 +390,68 @@ __device__ __forceinline__ T lane_bcast(T v, int src) {
     return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
   }
 }
+// Workgroups are single wavefronts: the wave-cooperative form is bound by ONE wavefront's instruction stream, and two
+// of them on a SIMD halve each other's issue rate (measured with 512-thread workgroups: eight working wavefronts per
+// CU, 14.4 us for 190 rows; the dispatcher spreads single-wavefront workgroups over the CUs).  Every wavefront scans
+// all masks itself (lane t owns masks [t per, (t + 1) per); a wavefront-level prefix sum, no barrier).
 template <int N, class T>
-__global__ void __launch_bounds__(kFinishWaves * 64)
+__global__ void __launch_bounds__(kBlock)
 osc6_finish_kernel(long B, const unsigned long long* __restrict__ masks, const T* __restrict__ recs, int nulls,
                    int coop_max, int coop_rounds, T* __restrict__ ug, T* __restrict__ tsg) {
-  constexpr int kThreads = kFinishWaves * 64;
-  __shared__ int wave_tot[kFinishWaves];
-  __shared__ int mine[kFinishMaxRounds * kThreads];
-  const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // ---- every workgroup: the global index of each deferred row (thread t owns masks [t per, (t + 1) per))
+  __shared__ int mine[kFinishMaxRounds * kBlock];
+  const int lane = (int)threadIdx.x;
+  // ---- the global index of each deferred row
   const long nchunk = (B + kBlock - 1) / kBlock;
-  const int per = (int)((nchunk + kThreads - 1) / kThreads);
-  unsigned long long m[kFinishMaskPer];
+  const int per = (int)((nchunk + kBlock - 1) / kBlock);
+  const long m0 = (long)lane * per;
   int cnt = 0;
-  sfor<kFinishMaskPer>([&](auto k) ABRK_LAMBDA {
-    const long idx = (long)tid * per + k();
-    m[k()] = (k() < per && idx < nchunk) ? masks[idx] : 0ull;
-    cnt += __popcll(m[k()]);
-  });
+  for (int k = 0; k < per; k++) cnt += (m0 + k < nchunk) ? __popcll(masks[m0 + k]) : 0;
   int incl = cnt;
-  for (int d = 1; d < 64; d <<= 1) {
+  for (int d = 1; d < kBlock; d <<= 1) {
     const int v = __shfl_up(incl, d);
     if (lane >= d) incl += v;
   }
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  int before = 0, P = 0;
-  sfor<kFinishWaves>([&](auto w) ABRK_LAMBDA {
-    const int t = wave_tot[w()];
-    before += (w() < wave) ? t : 0;
-    P += t;
-  });
+  const int P = __builtin_amdgcn_readlane(incl, kBlock - 1);
   if (P == 0) return;
-  const bool coop = P <= coop_max && P <= coop_rounds * (int)gridDim.x * kFinishWaves;
-  const int SB = coop ? kFinishWaves : kThreads;  // slots of a workgroup (a slot: a wavefront / a lane)
+  const bool coop = P <= coop_max && P <= coop_rounds * (int)gridDim.x;
+  const int SB = coop ? 1 : kBlock;  // slots of a workgroup (a slot: the wavefront / a lane)
   const int S = (int)gridDim.x * SB;
+  const int rounds = (P + S - 1) / S;
+  if ((int)blockIdx.x * SB >= P) return;  // no row falls on this workgroup's slots
+  // the rows on this workgroup's slots: round r covers the global indices [lo, hi); a lane whose deferred rows
+  // [pre, pre + cnt) meet that range walks ITS masks once more (L2-resident) and delivers exactly those rows
   {
-    int p = before + incl - cnt;
-    sfor<kFinishMaskPer>([&](auto k) ABRK_LAMBDA {
-      unsigned long long bits = m[k()];
-      while (bits) {
-        const int bit = __builtin_ctzll(bits);
-        bits &= bits - 1;
-        const int s = p % S, r = p / S;
-        if (s / SB == (int)blockIdx.x && r < kFinishMaxRounds) mine[r * SB + s % SB] = (int)(((long)tid * per + k()) * kBlock + bit);
-        p++;
+    const int pre = incl - cnt;
+    for (int r = 0; r < rounds && r < kFinishMaxRounds; r++) {
+      const int lo = r * S + (int)blockIdx.x * SB;
+      int hi = lo + SB;
+      hi = hi < P ? hi : P;
+      int a = pre > lo ? pre : lo;
+      const int b = pre + cnt < hi ? pre + cnt : hi;
+      if (a < b) {
+        int p = pre;
+        for (int k = 0; k < per && p < b; k++) {
+          unsigned long long bits = masks[m0 + k];  // (cnt > 0: every index of this lane below nchunk that matters)
+          const int c = __popcll(bits);
+          if (p + c <= a) {  // the whole mask lies before the range
+            p += c;
+            continue;
+          }
+          while (bits && p < b) {
+            const int bit = __builtin_ctzll(bits);
+            bits &= bits - 1;
+            if (p >= a) mine[r * SB + (p - lo)] = (int)((m0 + k) * kBlock + bit);
+            p++;
+          }
+        }
       }
-    });
+    }
   }
   __syncthreads();
-  const int rounds = (P + S - 1) / S;
   if (coop) {
-    for (int r = 0; r < rounds; r++) {
-      if (r * S + (int)blockIdx.x * SB + wave >= P) break;  // (uniform per wavefront)
-      const long b = mine[r * SB + wave];
+    for (int r = 0; r < rounds && r < kFinishMaxRounds; r++) {
+      if (r * S + (int)blockIdx.x >= P) break;
+      const long b = mine[r];
       const T* rec = recs + b * rec_len(N);
       const int c = lane < N + 2 ? lane : N + 1;  // (idle lanes shadow the last column)
       // the two joint-space sums are asked for with the rest of the record: one memory round trip, not two
@@ -466,8 +475,8 @@ osc6_finish_kernel(long B, const unsigned long long* __restrict__ masks, const T
     }
   } else {
     for (int r = 0; r < rounds && r < kFinishMaxRounds; r++) {
-      if (r * S + (int)blockIdx.x * SB + tid >= P) break;
-      const long b = mine[r * SB + tid];
+      if (r * S + (int)blockIdx.x * SB + lane >= P) break;
+      const long b = mine[r * SB + lane];
       T u[N], ts[N];
       osc6_finish_row<N, T>(recs + b * rec_len(N), nulls != 0, u, ts);
       store_row<N>(ug, b, u);
@@ -475,17 +484,18 @@ osc6_finish_kernel(long B, const unsigned long long* __restrict__ masks, const T
     }
   }
 }
-// workgroups of the finish kernel for a B-row call: a wavefront per deferred row while ~7 % of the rows defer (random
-// UR5 states with all six task rows: 4.6 %), 4096 wavefronts at most (four per SIMD: they are latency-bound), and never
+// workgroups (= wavefronts) of the finish kernel for a B-row call: one per deferred row while ~7 % of the rows defer
+// (random UR5 states with all six task rows: 4.6 %), as many as the wave-cooperative form can use at most, and never
 // fewer than one lane per kFinishMaxRounds rows (every row may defer: arms whose Mx_inv always truncates)
-inline int finish_grid(long B) {
-  long g = (B * 7 / 100 + kFinishWaves - 1) / kFinishWaves;
-  const long lo = (B + (long)kFinishMaxRounds * kFinishWaves * 64 - 1) / ((long)kFinishMaxRounds * kFinishWaves * 64);
-  if (g > 512) g = 512;
+inline int finish_grid(long B, int coop_max) {
+  long g = (B * 7 + 99) / 100;
+  const long lo = (B + (long)kFinishMaxRounds * kBlock - 1) / ((long)kFinishMaxRounds * kBlock);
+  if (g > coop_max) g = coop_max;  // (beyond coop_max deferred rows the per-lane form runs: 64 rows per workgroup)
   if (g < lo) g = lo;
   return (int)(g < 1 ? 1 : g);
 }
-constexpr long kHandoverMaxRows = (long)kFinishWaves * 64 * kFinishMaskPer * kBlock;  // 262144: the masks one workgroup compacts
+constexpr long kHandoverMaxRows = 262144;  // 4096 masks: 64 per lane of a scanning wavefront
+
 // Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
 // cooperative stores and (use_C) the scratch of the Coriolis recursion, which is dead by the time the first row is
 // parked.  FEAT is 0 (the plain law) or 2 (every optional input).

@@ -21,7 +21,7 @@ hipError_t launch_osc_law(int n, int dtype, const LaunchArgs& la, const LawArgs&
 }
 template <int N, class T>
 static hipError_t finish_launch(const LaunchArgs& la, const FinishArgs& a) {
-  hipLaunchKernelGGL((osc6_finish_kernel<N, T>), dim3((unsigned)a.grid), dim3(64 * kFinishWaves), 0, la.stream, la.B,
+  hipLaunchKernelGGL((osc6_finish_kernel<N, T>), dim3((unsigned)a.grid), dim3(kBlock), 0, la.stream, la.B,
                      (const unsigned long long*)a.masks, (const T*)a.rec, a.nulls, a.coop_max, a.coop_rounds, (T*)a.u,
                      (T*)a.ts);
   return hipGetLastError();
