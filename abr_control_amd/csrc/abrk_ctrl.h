@@ -1243,6 +1243,13 @@ ABRK_INL void osc6_finish_row(const T* __restrict__ rec, bool nulls, T (&u)[N], 
 #ifndef ABRK_LAW6_YB
 #define ABRK_LAW6_YB 3  // rows of Y held at a time (2 was measured: 12 instead of 9 solves cost more than 16 B of scratch)
 #endif
+// ... in the first pass (compiled without the eigen-decomposition: 202 - 210 registers on the UR5, room to spare under the
+// 256 of two waves per SIMD) all six rows at once: 6 forward solves instead of 9, 224 - 246 registers, still no scratch.
+// Same box, 8 M UR5 rows: 762 / 763 us against 786 / 794 us with three rows (and 815 / 817 with two); the 4096-row step
+// 16.9 - 17.0 against 17.1 - 17.4 us.
+#ifndef ABRK_LAW6_YB_FIRST
+#define ABRK_LAW6_YB_FIRST 6
+#endif
 template <int N, class T, bool USE_C, int FEAT, class Rows, int QSTEPS = 3>
 ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
                        const T (&cvec)[N], Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
@@ -1373,7 +1380,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     // more row at a time (recomputed when its own block comes up).  Three rows per block cost 9 forward solves for the
     // six rows, two rows 12 (measured with the training signal among the outputs, where u0 AND the gravity sums stay
     // live across the law: 957 us against 937 us at 8 M UR5 rows - the 16 B of scratch it saves do not pay for 3 solves)
-    constexpr int YB = ABRK_LAW6_YB;
+    constexpr int YB = Rows::kDeferOnly ? ABRK_LAW6_YB_FIRST : ABRK_LAW6_YB;
     static_assert(KM % YB == 0, "block size divides the six rows");
     sfor<KM / YB>([&](auto bi) ABRK_LAMBDA {
       constexpr int r0 = bi() * YB;

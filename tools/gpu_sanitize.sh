@@ -15,7 +15,8 @@ test_gpu_sharded_sliding_joint_dynamics_equal_unsharded_bitwise or test_gpu_reco
 run() {  # name, runtime .so, environment
   local name=$1 rt=$2; shift 2
   if [ ! -f abr_control_amd/libabrk_$name.so ]; then echo "$name: libabrk_$name.so not built" | tee -a "$OUT/summary.txt"; return; fi
-  env "$@" LD_PRELOAD=$RT/$rt ABRK_LIB_PATH=$PWD/abr_control_amd/libabrk_$name.so \
+  case "$rt" in /*) ;; *) rt=$RT/$rt;; esac
+  env "$@" LD_PRELOAD=$rt ABRK_LIB_PATH=$PWD/abr_control_amd/libabrk_$name.so \
     timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -p no:cacheprovider -k "$TESTS" > "$OUT/$name.log" 2>&1
   local rc=$?
   local reports
@@ -24,7 +25,10 @@ run() {  # name, runtime .so, environment
 }
 # ASan: the HIP runtime's own allocations are not ours to check (detect_leaks=0); ROCr maps its apertures where ASan's
 # shadow gap sits (protect_shadow_gap=0)
-run asan libclang_rt.asan-x86_64.so ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0
+# (gcc's runtime, not ROCm's compiler-rt: the latter intercepts HSA allocations for device-side ASan and aborts hipInit
+#  on an xnack- GPU - csrc/Makefile)
+GCCASAN=$(readlink -f "$(gcc -print-file-name=libasan.so)")
+run asan "$GCCASAN" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0
 # TSan: only the instrumented module (libabrk's host layer) is judged; the interpreter and the HIP runtime are not built for it
 run tsan libclang_rt.tsan-x86_64.so TSAN_OPTIONS=ignore_noninstrumented_modules=1:halt_on_error=0:report_signal_unsafe=0
 run ubsan libclang_rt.ubsan_standalone-x86_64.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0
