@@ -1411,7 +1411,11 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
   bool mx_explicit = FEAT != 0, f_ready = false;
   T f[KM], f2[FEAT >= 1 ? KM : 1];
-  if constexpr (FEAT != 0) chol_inverse<KM>(LA, ila, Mx);
+  // (only where the factor exists: after a non-positive pivot LA / ila hold non-finite values, which -ffinite-math-only
+  //  makes unspecified to compute with; every reader of Mx below sits behind okA or overwrites it)
+  if constexpr (FEAT != 0) {
+    if (okA) chol_inverse<KM>(LA, ila, Mx);
+  }
   const T thr = T(1e-3), rcond = T(1e-3) * T(0.1);
   if (!(okA && det >= thr)) {
     // pinv branch (osc.py:142-145); the two certificates of osc_law
@@ -2227,6 +2231,251 @@ ABRK_INL void obstacles_row(const A& arm, const ObsP<T>& P, const T (&q)[A::N], 
     T x = u[i()] * P.gain;
     u[i()] = x < -P.maximum ? -P.maximum : (x > P.maximum ? P.maximum : x);
   });
+}
+
+// ---- AvoidObstacles with the heavy pairs redistributed over the wavefront (orthogonal chains of three joints and more).
+// obstacles_row runs every (obstacle, segment) slot on every lane that is near ITS obstacle - and makes the other 63
+// wait: with three obstacles a random UR5 state has 2.0 near pairs on the segments that need the general 3 x 3 path
+// (ii >= 2: ~900 instructions each), but the wavefront walks 8.4 of its 12 such slots.  Split in three:
+//   phase A (one row per lane): kinematics, M and its factor, every near test, the cheap rank-1 / rank-2 pairs of the
+//     first two segments; the row's factor and frames go to a record, its near heavy pairs to a bit mask;
+//   pairs (one PAIR per lane, whoever's row it is): the wavefront's pairs are numbered through (a prefix sum of the
+//     popcounts), lane j of round r takes pair 64 r + j, reads the owning row's record and leaves the pair's
+//     contribution to u;
+//   the owner adds its pairs' contributions in slot order, then gain and clip.
+// The records live in LDS on the GPU (obstacles_lds_kernel: [field][lane], 66 values per row for six joints = 33 KiB per
+// wavefront), in plain arrays in the host check build.  Same arithmetic per pair as obstacles_row; only the order in
+// which a row's contributions are summed differs (light pairs first, then heavy ones by obstacle and segment).
+template <int N>
+constexpr int obs_rec_len() { return N * (N + 1) / 2 + N + 3 * N + 3 * N + 3; }  // L, il, o, z, pe
+template <int N>
+constexpr int obs_heavy_segments() { return N > 2 ? N - 2 : 0; }
+// record field offsets
+template <int N>
+struct ObsRec {
+  static constexpr int L = 0, IL = N * (N + 1) / 2, O = IL + N, Z = O + 3 * N, PE = Z + 3 * N;
+};
+
+// phase A.  `put(field, value)` stores a record field; -> the mask of near heavy slots (slot = ob * (N - 2) + ii - 2)
+template <class A, class T, class Put>
+ABRK_INL unsigned long long obstacles_phase_a(const A& arm, const ObsP<T>& P, const T (&q)[A::N], T (&u)[A::N], Put&& put) {
+  constexpr int N = A::N;
+  static_assert(A::kOrtho && N >= 3, "orthogonal chains with heavy segments");
+  using R = ObsRec<N>;
+  Joints<A, T> jt;
+  Dyn<A, T, CMODE_NONE> d;
+  T XR[9], xo[3], pe[3];
+  NoCap nc;
+  T zero[N];
+  sfor<N>([&](auto i) ABRK_LAMBDA { zero[i()] = T(0); });
+  kin_dyn(arm, q, zero, jt, d, XR, xo, nc);
+  mulBE_pt<A, T>(arm, XR, xo, pe);
+  T L[N * (N + 1) / 2], il[N];
+  chol<N>(d.Ms, L, il);
+  sfor<N*(N + 1) / 2>([&](auto e) ABRK_LAMBDA { put(R::L + e(), L[e()]); });
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    put(R::IL + i(), il[i()]);
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      put(R::O + 3 * i() + r(), jt.o[i()][r()]);
+      put(R::Z + 3 * i() + r(), jt.z[i()][r()]);
+    });
+  });
+  sfor<3>([&](auto r) ABRK_LAMBDA { put(R::PE + r(), pe[r()]); });
+  sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = T(0); });
+  const T lo = P.threshold / T(50), ithr = T(1) / P.threshold;
+  T noise = T(0);
+  sfor<N>([&](auto i) ABRK_LAMBDA { noise += il[i()] * il[i()]; });
+  noise *= sizeof(T) == 8 ? T(1e-24) : T(1e-10);
+  T w00 = T(0), w01 = T(0), w11 = T(0);
+  {
+    T e[N], y0[N], y1[N];
+    sfor<N>([&](auto i) ABRK_LAMBDA { e[i()] = i() == 0 ? T(1) : T(0); });
+    chol_fwd<N>(L, il, e, y0);
+    sfor<N>([&](auto i) ABRK_LAMBDA { w00 += y0[i()] * y0[i()]; });
+    sfor<N>([&](auto i) ABRK_LAMBDA { e[i()] = i() == 1 ? T(1) : T(0); });
+    chol_fwd<N>(L, il, e, y1);
+    sfor<N>([&](auto i) ABRK_LAMBDA {
+      w01 += y0[i()] * y1[i()];
+      w11 += y1[i()] * y1[i()];
+    });
+  }
+  unsigned long long heavy = 0ull;
+  for (int ob = 0; ob < P.n; ob++) {
+    const T v[3] = {P.obs[ob][0], P.obs[ob][1], P.obs[ob][2]};
+    const T radius = P.obs[ob][3];
+    sfor<N>([&](auto iic) ABRK_LAMBDA {
+      constexpr int ii = iic();
+      T p1[3], p2[3], vl[3], vo[3];
+      sfor<3>([&](auto r) ABRK_LAMBDA {
+        p1[r()] = jt.o[ii][r()];
+        if constexpr (ii == N - 1) p2[r()] = pe[r()];
+        else p2[r()] = jt.o[ii + 1 < N ? ii + 1 : ii][r()];
+        vl[r()] = p2[r()] - p1[r()];
+        vo[r()] = v[r()] - p1[r()];
+      });
+      const T len2 = dot3(vl, vl);
+      if (len2 > T(0)) {
+        T pr = dot3(vo, vl) * rcp(len2);
+        pr = pr < T(0) ? T(0) : (pr > T(1) ? T(1) : pr);
+        T cl[3], dv[3];
+        sfor<3>([&](auto r) ABRK_LAMBDA {
+          cl[r()] = pr == T(1) ? p2[r()] : p1[r()] + pr * vl[r()];
+          dv[r()] = v[r()] - cl[r()];
+        });
+        const T d2 = dot3(dv, dv);
+        const T dist = d2 > T(0) ? d2 * Rm<T>::rsqrt(d2 > T(0) ? d2 : T(1)) : T(0);
+        const T rho = Rm<T>::fmax(dist - radius, lo);
+        if (rho < P.threshold) {
+          if constexpr (ii >= 2) {
+            heavy |= 1ull << (ob * (N - 2) + (ii - 2));
+          } else {
+            const T irho = rcp(rho);
+            const T k = T(0.02) * (irho - ithr) * irho * irho * Rm<T>::rsqrt(rho);
+            T F[3] = {k * dv[0], k * dv[1], k * dv[2]};
+            T Jp[2][3];
+            sfor<2>([&](auto i) ABRK_LAMBDA {
+              if constexpr (i() <= ii) {
+                T dl[3] = {cl[0] - jt.o[i()][0], cl[1] - jt.o[i()][1], cl[2] - jt.o[i()][2]};
+                wapply<i()>(jt, dl, Jp[i()]);
+              } else {
+                Jp[i()][0] = Jp[i()][1] = Jp[i()][2] = T(0);
+              }
+            });
+            const T floor = noise * len2;
+            bool done = false;
+            if constexpr (ii == 0) {
+              const T tr = w00 * dot3(Jp[0], Jp[0]);
+              if (tr > floor) u[0] -= dot3(Jp[0], F) * rcp(tr);
+              done = true;
+            } else {
+              const T g00 = dot3(Jp[0], Jp[0]);
+              const T ig0 = Rm<T>::rsqrt(Rm<T>::fmax(g00, Rm<T>::tiny()));
+              const T q0[3] = {Jp[0][0] * ig0, Jp[0][1] * ig0, Jp[0][2] * ig0};
+              const T r01 = dot3(q0, Jp[1]);
+              const T pp1[3] = {Jp[1][0] - r01 * q0[0], Jp[1][1] - r01 * q0[1], Jp[1][2] - r01 * q0[2]};
+              const T h11 = dot3(pp1, pp1), g11 = dot3(Jp[1], Jp[1]);
+              if (g00 > T(0) && h11 > (sizeof(T) == 8 ? T(1e-20) : T(1e-8)) * g11) {
+                const T ih = Rm<T>::rsqrt(h11);
+                const T q1[3] = {pp1[0] * ih, pp1[1] * ih, pp1[2] * ih};
+                const T r00 = g00 * ig0, r11 = h11 * ih;
+                const T a0 = r00 * w00 + r01 * w01, a1 = r00 * w01 + r01 * w11;
+                const T s00 = a0 * r00 + a1 * r01, s01 = a1 * r11, s11 = r11 * w11 * r11;
+                const T tr = s00 + s11;
+                if (tr > floor) {
+                  const T t = jacobi_tan(s11 - s00, T(2) * s01);
+                  const T c = Rm<T>::rsqrt(t * t + T(1)), sn = t * c;
+                  const T l0 = s00 - t * s01, l1 = s11 + t * s01;
+                  const T lmax = Rm<T>::fmax(l0, l1), cut = T(0.01) * lmax;
+                  const T i0 = l0 > cut ? rcp(l0 > cut ? l0 : T(1)) : T(0), i1 = l1 > cut ? rcp(l1 > cut ? l1 : T(1)) : T(0);
+                  const T b0 = dot3(q0, F), b1 = dot3(q1, F);
+                  const T z0 = (c * b0 - sn * b1) * i0, z1 = (sn * b0 + c * b1) * i1;
+                  const T x0 = c * z0 + sn * z1, x1 = -sn * z0 + c * z1;
+                  u[0] -= r00 * x0;
+                  u[1] -= r01 * x0 + r11 * x1;
+                }
+                done = true;
+              }
+            }
+            if (!done) {  // degenerate first two columns: the general path, here (rare)
+              T JpN[N][3], Mx[6], f[3];
+              sfor<N>([&](auto i) ABRK_LAMBDA {
+                sfor<3>([&](auto r) ABRK_LAMBDA { JpN[i()][r()] = i() < 2 ? Jp[i() < 2 ? i() : 0][r()] : T(0); });
+              });
+              point_inertia<N, T, false>(L, il, JpN, T(0), T(0.01), floor, Mx);
+              symv<3>(Mx, F, f);
+              sfor<2>([&](auto i) ABRK_LAMBDA {
+                if constexpr (i() <= ii) u[i()] -= Jp[i()][0] * f[0] + Jp[i()][1] * f[1] + Jp[i()][2] * f[2];
+              });
+            }
+          }
+        }
+      }
+    });
+  }
+  return heavy;
+}
+
+// one heavy pair: slot = ob * (N - 2) + ii - 2 of the row whose record `get(field)` reads -> its contribution c to u
+// (already negated: u += c)
+template <int N, class T, class Get>
+ABRK_INL void obstacles_pair(const ObsP<T>& P, int slot, Get&& get, T (&c)[N]) {
+  using R = ObsRec<N>;
+  constexpr int NH = N - 2;
+  const int ob = slot / NH, ii = 2 + slot % NH;
+  T L[N * (N + 1) / 2], il[N], o[N][3], z[N][3];
+  sfor<N*(N + 1) / 2>([&](auto e) ABRK_LAMBDA { L[e()] = get(R::L + e()); });
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    il[i()] = get(R::IL + i());
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      o[i()][r()] = get(R::O + 3 * i() + r());
+      z[i()][r()] = get(R::Z + 3 * i() + r());
+    });
+  });
+  // the segment's end points by their run-time index: straight from the record (o_ii; o_ii+1, or the EE after the last)
+  T p1[3], p2[3], vl[3], vo[3], v[3];
+  const int f2 = ii == N - 1 ? R::PE : R::O + 3 * (ii + 1);
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    p1[r()] = get(R::O + 3 * ii + r());
+    p2[r()] = get(f2 + r());
+    v[r()] = P.obs[ob][r()];
+    vl[r()] = p2[r()] - p1[r()];
+    vo[r()] = v[r()] - p1[r()];
+  });
+  const T radius = P.obs[ob][3];
+  const T lo = P.threshold / T(50), ithr = T(1) / P.threshold;
+  const T len2 = dot3(vl, vl);
+  T pr = dot3(vo, vl) * rcp(len2);
+  pr = pr < T(0) ? T(0) : (pr > T(1) ? T(1) : pr);
+  T cl[3], dv[3];
+  sfor<3>([&](auto r) ABRK_LAMBDA {
+    cl[r()] = pr == T(1) ? p2[r()] : p1[r()] + pr * vl[r()];
+    dv[r()] = v[r()] - cl[r()];
+  });
+  const T d2 = dot3(dv, dv);
+  const T dist = d2 > T(0) ? d2 * Rm<T>::rsqrt(d2 > T(0) ? d2 : T(1)) : T(0);
+  const T rho = Rm<T>::fmax(dist - radius, lo);
+  const T irho = rcp(rho);
+  const T k = T(0.02) * (irho - ithr) * irho * irho * Rm<T>::rsqrt(rho);
+  T F[3] = {k * dv[0], k * dv[1], k * dv[2]};
+  T Jp[N][3];
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    T dl[3] = {cl[0] - o[i()][0], cl[1] - o[i()][1], cl[2] - o[i()][2]}, w[3];
+    cross3(z[i()], dl, w);
+    const bool on = i() <= ii;
+    sfor<3>([&](auto r) ABRK_LAMBDA { Jp[i()][r()] = on ? w[r()] : T(0); });
+  });
+  T noise = T(0);
+  sfor<N>([&](auto i) ABRK_LAMBDA { noise += il[i()] * il[i()]; });
+  noise *= sizeof(T) == 8 ? T(1e-24) : T(1e-10);
+  T Mx[6], f[3];
+  point_inertia<N, T, false>(L, il, Jp, T(0), T(0.01), noise * len2, Mx);
+  symv<3>(Mx, F, f);
+  sfor<N>([&](auto i) ABRK_LAMBDA { c[i()] = -(Jp[i()][0] * f[0] + Jp[i()][1] * f[1] + Jp[i()][2] * f[2]); });
+}
+
+// np.clip(u * gain) (avoid_obstacles.py:121)
+template <int N, class T>
+ABRK_INL void obstacles_finish(const ObsP<T>& P, T (&u)[N]) {
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    T x = u[i()] * P.gain;
+    u[i()] = x < -P.maximum ? -P.maximum : (x > P.maximum ? P.maximum : x);
+  });
+}
+// the three steps on one row, pair by pair (host check build; what obstacles_lds_kernel does with the pairs spread over
+// the wavefront)
+template <class A, class T>
+ABRK_INL void obstacles_row_split(const A& arm, const ObsP<T>& P, const T (&q)[A::N], T (&u)[A::N]) {
+  constexpr int N = A::N;
+  T rec[obs_rec_len<N>()];
+  unsigned long long heavy = obstacles_phase_a<A, T>(arm, P, q, u, [&](int f, T v) ABRK_LAMBDA { rec[f] = v; });
+  while (heavy) {
+    const int slot = __builtin_ctzll(heavy);
+    heavy &= heavy - 1;
+    T c[N];
+    obstacles_pair<N, T>(P, slot, [&](int f) ABRK_LAMBDA { return rec[f]; }, c);
+    sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += c[i()]; });
+  }
+  obstacles_finish<N, T>(P, u);
 }
 
 // ---------------------------------------------------------------- Joint / Damping / RestingConfig, one row

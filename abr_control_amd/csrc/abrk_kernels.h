@@ -636,6 +636,79 @@ obstacles_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restri
     obstacles_body<A, T>(b, arm, P, qg, ug, acc);
 }
 constexpr long kObstaclesMaxBlocks = 4096;
+// AvoidObstacles with the heavy (obstacle, segment) pairs of a wavefront's 64 rows redistributed over its lanes through
+// LDS (abrk_ctrl.h obstacles_phase_a / obstacles_pair): orthogonal chains of three joints and more, up to 64 heavy slots
+// (obstacles x (N - 2) segments).  LDS per wavefront: the rows' records [field][lane] (66 values per row for six joints:
+// 33 KiB in fp64), the pair list and one round of contributions - 40 KiB, four wavefronts per CU.
+constexpr int kObsPairCap = 2048;  // pairs of a wavefront that are redistributed; a lane beyond works its own off
+template <class A, class T>
+constexpr bool obstacles_use_lds() { return A::kOrtho && A::N >= 3; }
+template <class A, class T>
+__global__ void __launch_bounds__(kBlock, ABRK_OBS_WAVES)
+obstacles_lds_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
+  constexpr int N = A::N, RL = obs_rec_len<N>();
+  __shared__ T rec[RL * kBlock];
+  __shared__ unsigned short pairs[kObsPairCap];
+  __shared__ T contrib[kBlock * N];
+  const int lane = (int)threadIdx.x;
+  for (long b0 = (long)blockIdx.x * kBlock; b0 < B; b0 += (long)gridDim.x * kBlock) {
+    const long b = b0 + lane;
+    const bool in = b < B;
+    T u[N];
+    unsigned long long heavy = 0ull;
+    if (in) {
+      T q[N];
+      load_row<N>(qg, b, q);
+      heavy = obstacles_phase_a<A, T>(arm, P, q, u, [&](int f, T v) ABRK_LAMBDA { rec[f * kBlock + lane] = v; });
+    }
+    // number the wavefront's pairs: lane l owns [pre, pre + cnt), in slot order
+    const int cnt = __popcll(heavy);
+    int incl = cnt;
+    for (int d = 1; d < kBlock; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if (lane >= d) incl += v;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, kBlock - 1);
+    const int pre = incl - cnt;
+    const int shared = total < kObsPairCap ? total : kObsPairCap;  // pairs [0, shared) are redistributed
+    {
+      int p = pre;
+      unsigned long long bits = heavy;
+      while (bits && p < kObsPairCap) {
+        const int slot = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        pairs[p++] = (unsigned short)(lane | (slot << 6));
+      }
+      // (what does not fit the list - a wavefront with more than 32 heavy pairs per row on average - stays with its row)
+      while (bits) {
+        const int slot = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        T c[N];
+        obstacles_pair<N, T>(P, slot, [&](int f) ABRK_LAMBDA { return rec[f * kBlock + lane]; }, c);
+        sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += c[i()]; });
+      }
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < shared; r0 += kBlock) {
+      const int p = r0 + lane;
+      if (p < shared) {
+        const int e = pairs[p], src = e & (kBlock - 1), slot = e >> 6;
+        T c[N];
+        obstacles_pair<N, T>(P, slot, [&](int f) ABRK_LAMBDA { return rec[f * kBlock + src]; }, c);
+        sfor<N>([&](auto i) ABRK_LAMBDA { contrib[lane * N + i()] = c[i()]; });
+      }
+      __syncthreads();
+      // every owner adds its pairs of this round, in slot order
+      const int lo = pre > r0 ? pre : r0, hi = (pre + cnt < r0 + kBlock ? pre + cnt : r0 + kBlock) < shared ? (pre + cnt < r0 + kBlock ? pre + cnt : r0 + kBlock) : shared;
+      for (int pp = lo; pp < hi; pp++) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += contrib[(pp - r0) * N + i()]; });
+      __syncthreads();
+    }
+    if (in) {
+      obstacles_finish<N, T>(P, u);
+      put_row<N>(ug, b, u, acc);
+    }
+  }
+}
 
 template <int N, class T>
 __global__ void __launch_bounds__(kBlock)
@@ -940,9 +1013,18 @@ struct OpsFor {
   template <class A, class T>
   static hipError_t obstacles_t(const LaunchArgs& la, const ObstaclesArgs& a) {
     const long blocks = (la.B + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL((obstacles_kernel<A, T>), dim3((unsigned)(blocks < kObstaclesMaxBlocks ? blocks : kObstaclesMaxBlocks)),
-                       dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la),
-                       *static_cast<const ObsP<T>*>(a.P), la.B, (const T*)a.q, (T*)a.u, a.acc);
+    const dim3 grid((unsigned)(blocks < kObstaclesMaxBlocks ? blocks : kObstaclesMaxBlocks));
+    const ObsP<T>& P = *static_cast<const ObsP<T>*>(a.P);
+    if constexpr (obstacles_use_lds<A, T>()) {
+      static const bool off = getenv("ABRK_OBS_PLAIN") != nullptr;  // measurement switch: the one-pass kernel
+      if (!off && P.n * (A::N - 2) <= 64) {
+        hipLaunchKernelGGL((obstacles_lds_kernel<A, T>), grid, dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la), P, la.B,
+                           (const T*)a.q, (T*)a.u, a.acc);
+        return hipGetLastError();
+      }
+    }
+    hipLaunchKernelGGL((obstacles_kernel<A, T>), grid, dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la), P, la.B,
+                       (const T*)a.q, (T*)a.u, a.acc);
     return hipGetLastError();
   }
   static hipError_t obstacles(int dt, const LaunchArgs& la, const ObstaclesArgs& a) {

@@ -405,6 +405,19 @@ ABRK_INL void obstacles_body(long b, const A& arm, const ObsP<T>& P, const T* __
   put_row<N>(ug, b, u, acc);
 }
 
+// the same through the split row program (phase A, pairs, finish - abrk_ctrl.h obstacles_row_split): what the host check
+// build runs where the GPU runs obstacles_lds_kernel
+template <class A, class T>
+ABRK_INL void obstacles_split_body(long b, const A& arm, const ObsP<T>& P, const T* __restrict__ qg, T* __restrict__ ug,
+                                   int acc) {
+  constexpr int N = A::N;
+  T q[N], u[N];
+  load_row<N>(qg, b, q);
+  if constexpr (A::kOrtho && N >= 3) obstacles_row_split<A, T>(arm, P, q, u);
+  else obstacles_row<A, T>(arm, P, q, u);
+  put_row<N>(ug, b, u, acc);
+}
+
 // ---- closed loop: n_steps x { OSC.generate ; ArmSim._step } with the state kept in registers
 // (examples/PyGame/force_osc_xy.py:57-78).  Two-joint arms only.
 template <class A, class T, bool USE_C, int KM>

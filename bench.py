@@ -240,6 +240,8 @@ class Runner:
             return f"limits_kernel<{self.n}, {t}>"
         if k == "rollout":
             return f"rollout_kernel<{arm}, {t}, {'true' if self.params.use_C else 'false'}>"
+        if k == "obstacles" and self.arm in ("ur5", "threejoint") and not os.environ.get("ABRK_OBS_PLAIN"):
+            return f"obstacles_lds_kernel<{arm}, {t}>"  # orthogonal chains: heavy pairs redistributed through LDS
         return f"{k}_kernel<{arm}, {t}>"
 
     def grid_threads(self):

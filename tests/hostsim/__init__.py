@@ -200,7 +200,9 @@ def floating_generate(arm, dynamic, task_space, q, dq=None, u=None, dtype=np.flo
     return u
 
 
-def avoid_obstacles_generate(arm, params, q, u=None, dtype=np.float64):
+def avoid_obstacles_generate(arm, params, q, u=None, dtype=np.float64, plain=False):
+    """plain=False: what libabrk dispatches (orthogonal chains of three joints and more: phase A + one heavy pair at a
+    time + finish, the row-level form of obstacles_lds_kernel); plain=True: the one-pass row program everywhere"""
     name, desc, n = _arm(arm)
     dt = np.dtype(dtype)
     q = _in(q, dt)
@@ -208,7 +210,7 @@ def avoid_obstacles_generate(arm, params, q, u=None, dtype=np.float64):
     acc = u is not None
     u = np.full((B, n), np.nan, dt) if u is None else u
     rc = _lib_for(arm).hostsim_obstacles(name, desc, _dtype_code(dt), C.byref(params), C.c_int64(B), _p(q), _p(u),
-                                         int(acc))
+                                         int(acc), int(plain))
     assert rc == 0, rc
     return u
 

@@ -318,13 +318,19 @@ extern "C" int hostsim_floating(const char* builtin, const abrk_arm_desc* d, int
     return 0;
   });
 }
+// plain != 0: the one-pass row program everywhere; else what libabrk dispatches - the split program (phase A, one heavy
+// pair at a time, finish) on orthogonal chains of three joints and more with at most 64 heavy slots
 extern "C" int hostsim_obstacles(const char* builtin, const abrk_arm_desc* d, int dtype,
-                                 const abrk_obstacles_params* P, int64_t B, const void* q, void* u, int acc) {
+                                 const abrk_obstacles_params* P, int64_t B, const void* q, void* u, int acc, int plain) {
   return with_arm(builtin, d, dtype, [&](const auto& a, auto t, int) {
     using A = std::decay_t<decltype(a)>;
     using T = decltype(t);
     ObsP<T> p = make_obsp<T>(*P);
-    for (long b = 0; b < B; b++) obstacles_body<A, T>(b, a, p, (const T*)q, (T*)u, acc);
+    const bool split = !plain && A::kOrtho && A::N >= 3 && p.n * (A::N - 2) <= 64;
+    for (long b = 0; b < B; b++) {
+      if (split) obstacles_split_body<A, T>(b, a, p, (const T*)q, (T*)u, acc);
+      else obstacles_body<A, T>(b, a, p, (const T*)q, (T*)u, acc);
+    }
     return 0;
   });
 }

@@ -1787,6 +1787,68 @@ def test_gpu_six_row_second_pass_forms_meet_at_the_batch_threshold():
     assert np.percentile(cases.rel_err(u_big[:1500], uo), 99) < 1e-9 and np.percentile(cases.rel_err(u_h[:1500], uo), 99) < 1e-9
 
 
+_OBS_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from abr_control_amd import _abi
+from tests import cases
+d = np.load(sys.argv[2], allow_pickle=True)
+out = {}
+for arm in ("ur5", "threejoint"):
+    be = cases.GpuBackend(arm)
+    q = d["q_" + arm]
+    for i in range(int(d["n_sets"])):
+        P = _abi.make_obstacles_params(d[f"obs{i}"].tolist(), float(d[f"thr{i}"]), 30)
+        out[f"{arm}_{i}_f64"] = be.obstacles(P, q)
+        out[f"{arm}_{i}_f32"] = be.obstacles(P, q, dtype=np.float32)
+np.savez(sys.argv[3], **out)
+"""
+
+
+def test_gpu_obstacles_redistributed_pairs_equal_one_pass_kernel(tmp_path):
+    """obstacles_lds_kernel (the heavy pairs of a wavefront's 64 rows spread over its lanes through LDS) against the
+    one-pass kernel (measurement switch ABRK_OBS_PLAIN) and the oracle: 1 / 3 / 16 obstacles, every pair near (more pairs
+    than the wavefront's list holds: the overflow stays with its row), a batch that is not a multiple of 64, fp64 and
+    fp32"""
+    import subprocess
+    import sys
+
+    from tests.conftest import REPO
+
+    rng = np.random.RandomState(8)
+    sets = [([[0.3, 0.2, 0.4, 0.1], [-0.2, 0.4, 0.3, 0.05], [0.1, -0.3, 0.6, 0.15]], 0.3),
+            ([[0.25, 0.1, 0.5, 0.1]], 0.4),
+            ((rng.uniform(-0.6, 0.6, (16, 4)) * [1, 1, 1, 0.2] + [0, 0, 0.4, 0.12]).tolist(), 0.3),
+            ((rng.uniform(-0.6, 0.6, (16, 4)) * [1, 1, 1, 0.1] + [0, 0, 0.4, 0.06]).tolist(), 5.0)]
+    data = dict(n_sets=len(sets), q_ur5=rng.uniform(0, 2 * np.pi, (5003, 6)), q_threejoint=rng.uniform(0, 2 * np.pi, (5003, 3)))
+    for i, (obs, thr) in enumerate(sets):
+        data[f"obs{i}"], data[f"thr{i}"] = np.array(obs), thr
+    np.savez(tmp_path / "in.npz", **data)
+    (tmp_path / "run.py").write_text(_OBS_SCRIPT)
+    res = {}
+    for name, sw in (("lds", {}), ("plain", dict(ABRK_OBS_PLAIN="1"))):
+        env = {k: v for k, v in os.environ.items() if k != "ABRK_OBS_PLAIN"}
+        env.update(sw)
+        r = subprocess.run([sys.executable, str(tmp_path / "run.py"), REPO, str(tmp_path / "in.npz"),
+                            str(tmp_path / f"{name}.npz")], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[name] = np.load(tmp_path / f"{name}.npz")
+    for k in res["lds"].files:
+        a, b = res["lds"][k].astype(float), res["plain"][k].astype(float)
+        assert np.all(np.isfinite(a)), k
+        tol = 1e-11 if k.endswith("f64") else 2e-3
+        assert np.max(np.abs(a - b)) <= tol * max(1.0, np.max(np.abs(b))), (k, np.max(np.abs(a - b)))
+    # and the oracle (rows the reference itself inverts noise on are left out: its mobility diagnostic)
+    from oracle.oracle import Oracle
+
+    P = _abi.make_obstacles_params(sets[0][0], sets[0][1], 30)
+    uo, diag = Oracle(_abi.load_table("ur5")).avoid_obstacles_batch(P, data["q_ur5"][:600])
+    ok = (diag[:, 0] > 1e-7) & (diag[:, 1] > 1e-20)
+    err = np.max(np.abs(res["lds"]["ur5_0_f64"][:600] - uo), axis=1) / np.maximum(np.max(np.abs(uo), axis=1), 1e-9)
+    assert err[ok].max() <= 1e-6
+
+
 def test_gpu_table_sincos_negative_and_large_angles():
     """the OSC / Sliding kernels take sin/cos through the 128-entry LDS table (abrk_sincos_table.h): negative angles,
     angles up to the routine's range (|q| < 1e5; beyond it the library path), fp64 and fp32, builtin and user arms,

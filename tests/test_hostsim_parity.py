@@ -110,6 +110,32 @@ def test_rows_six_row_handover_form_fuzz_on_user_arms():
     assert ran > 0, "no fuzz row went through the hand-over records"
 
 
+@pytest.mark.parametrize("arm", ["ur5", "threejoint"])
+def test_rows_obstacles_split_program_equals_one_pass(arm):
+    """AvoidObstacles on orthogonal chains runs as phase A (kinematics, near tests, the cheap first two segments) + one
+    heavy (obstacle, segment) pair at a time from the row's record + finish - on the GPU the pairs of a wavefront's 64
+    rows are spread over its lanes through LDS (obstacles_lds_kernel).  Against the one-pass row program: the same
+    contributions, summed in another order"""
+    from abr_control_amd import _abi
+    from tests import hostsim
+
+    n = _abi.load_table(arm)["n_joints"]
+    rng = np.random.RandomState(8)
+    q = rng.uniform(0, 2 * np.pi, (700, n))
+    sets = [([[0.3, 0.2, 0.4, 0.1], [-0.2, 0.4, 0.3, 0.05], [0.1, -0.3, 0.6, 0.15]], 0.3),
+            ([[0.25, 0.1, 0.5, 0.1]], 0.4),
+            ((rng.uniform(-0.6, 0.6, (16, 4)) * [1, 1, 1, 0.2] + [0, 0, 0.4, 0.12]).tolist(), 0.3),
+            ((rng.uniform(-0.6, 0.6, (16, 4)) * [1, 1, 1, 0.1] + [0, 0, 0.4, 0.06]).tolist(), 5.0)]  # every pair near
+    for obstacles, thr in sets:
+        P = _abi.make_obstacles_params(obstacles, thr, 30)
+        for dt, tol in ((np.float64, 1e-11), (np.float32, 2e-3)):
+            a = hostsim.avoid_obstacles_generate(arm, P, q, dtype=dt).astype(float)
+            b = hostsim.avoid_obstacles_generate(arm, P, q, dtype=dt, plain=True).astype(float)
+            assert np.all(np.isfinite(a))
+            # (clipping at +-maximum hides nothing here: both sides clip the same sums)
+            assert np.max(np.abs(a - b)) <= tol * max(1.0, np.max(np.abs(b))), (arm, len(obstacles), thr, dt)
+
+
 def test_rows_twojoint_closed_forms():
     """reference's analytic known answers (arms/tests/dummy_base_arm.py) on its test grids"""
     k = golden("known_answers")
