@@ -28,7 +28,7 @@ run() {  # name, runtime .so, environment
 # (gcc's runtime, not ROCm's compiler-rt: the latter intercepts HSA allocations for device-side ASan and aborts hipInit
 #  on an xnack- GPU - csrc/Makefile)
 GCCASAN=$(readlink -f "$(gcc -print-file-name=libasan.so)")
-run asan "$GCCASAN" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:halt_on_error=0
+run asan "$GCCASAN" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:use_sigaltstack=0
 # TSan: only the instrumented module (libabrk's host layer) is judged; the interpreter and the HIP runtime are not built for it
 run tsan libclang_rt.tsan-x86_64.so TSAN_OPTIONS=ignore_noninstrumented_modules=1:halt_on_error=0:report_signal_unsafe=0
 run ubsan libclang_rt.ubsan_standalone-x86_64.so UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0
