@@ -36,4 +36,9 @@ cd /tmp && export TMPDIR=/tmp
 # (kernel, grid) over ALL its launches is what the bench line's `frac` must reproduce
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $ALSO > $O/stats.log 2>&1
 find $O -name "*.db" -delete 2>/dev/null
+# the summary of everything (kernel stats, trace means per leg, PMC means per launch, bench lines), made HERE: what comes
+# back is capped at 64 MiB, and the raw counter files of the PMC passes alone exceed that
+ABRK_PROFILE_COMMIT=${ABRK_PROFILE_COMMIT:-unknown} python tools/summarize_profiles.py $O $O/summary > $O/summarize_final.log 2>&1; tail -2 $O/summarize_final.log
+find $O -path "*pmc_*" -name "*.csv" -size +512k -delete 2>/dev/null
+find $O -name "*.csv" -size +12M -delete 2>/dev/null
 du -sh $O; ls $O | head -80
