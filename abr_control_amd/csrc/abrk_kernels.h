@@ -236,7 +236,14 @@ constexpr bool km6_first_pass_plain(int km, bool use_c, int feat, bool ortho, in
 // wavefronts per workgroup (osc_waves; ABRK_OSC_WAVES) - built to test whether the dispatch of single-wavefront
 // workgroups (~1.1 per ns chip-wide) bounds the 131072-row shard of BASELINE config 4: it does not (osc_waves).  The LDS
 // of a workgroup is dynamic: [sin/cos table][slab of wavefront 0][slab of wavefront 1]...
-constexpr int kOscMaxWaves = 4;
+// ABRK_OSC_MAX_WAVES (measurement switch, default 1 = single-wavefront workgroups with static LDS, as ever): > 1
+// compiles the x,y,z kernels for workgroups of up to that many wavefronts.  The general form is not free at the
+// config-sized batch - a runtime loop for the table load, a real s_barrier behind it, the wavefront's slab offset: the
+// 4096-row step of BASELINE config 2 measured 3.81 us against 3.55 - 3.64 us - and bought nothing at any size (osc_waves).
+#ifndef ABRK_OSC_MAX_WAVES
+#define ABRK_OSC_MAX_WAVES 1
+#endif
+constexpr int kOscMaxWaves = ABRK_OSC_MAX_WAVES;
 constexpr int osc_max_threads(int km) { return km <= 3 ? kOscMaxWaves * kBlock : kBlock; }
 template <class A, class T, int KM, bool USE_C>
 constexpr bool osc_uses_slab() {
@@ -270,6 +277,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
   // the slab: scratch of the Coriolis recursion (orthogonal chains) and / or the row store of the six-row law
   constexpr bool kLds = osc_uses_slab<A, T, KM, USE_C>();
   using V2 = typename LdsScratch<T, A::N>::V2;
+#if ABRK_OSC_MAX_WAVES > 1
   T* const sctab = reinterpret_cast<T*>(osc_smem);
   const int lane = (int)(threadIdx.x & (kBlock - 1));
   V2* slab = reinterpret_cast<V2*>(osc_smem + (kTab ? 2 * kSinCosN * sizeof(T) : 16));
@@ -279,6 +287,12 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
   } else {
     if constexpr (kTab) load_sincos_table(sctab, lane);
   }
+#else
+  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
+  const int lane = (int)threadIdx.x;
+  if constexpr (kTab) load_sincos_table(sctab, lane);  // every lane takes part: before any exit
+  __shared__ V2 slab[kLds ? slab_pairs<A::N>() * kBlock : 1];
+#endif
   const bool handover = rec != nullptr;
   auto row = [&](long b, bool allow_defer) ABRK_LAMBDA {
     auto go = [&](auto& scr) ABRK_LAMBDA {
@@ -845,8 +859,8 @@ struct Launch {
   template <int KM, bool UC, int FEAT>
   static hipError_t osc_launch(const LaunchArgs& la, const OscArgs& a) {
     // workgroups of `waves` wavefronts (the x,y,z kernels of large launches; the six-row kernels: one), LDS to match
-    const int waves = KM <= 3 ? osc_waves(la.B) : 1;
-    const size_t lds = osc_lds_bytes<A, T, KM, UC>(waves);
+    const int waves = (KM <= 3 && kOscMaxWaves > 1) ? osc_waves(la.B) : 1;
+    const size_t lds = kOscMaxWaves > 1 ? osc_lds_bytes<A, T, KM, UC>(waves) : 0;  // (default build: static LDS)
     auto go = [&](auto pass, dim3 grid, int mode) {
       if (lds > 65536) {  // beyond the default dynamic-LDS limit: raise it for this instantiation, once
         static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&osc_kernel<A, T, KM, UC, FEAT, pass()>),

@@ -1725,47 +1725,6 @@ def test_gpu_six_row_many_short_lived_streams():
     assert a.scratch_stats(0)["worklist_slots"] <= base["worklist_slots"] + 1
 
 
-_WAVES_SCRIPT = r"""
-import sys
-import numpy as np
-sys.path.insert(0, sys.argv[1])
-from abr_control_amd import _abi
-from tests import cases
-rng = np.random.RandomState(3)
-B = 70001
-q, dq, t = rng.uniform(0, 2 * np.pi, (B, 6)), rng.uniform(0, 5, (B, 6)), rng.uniform(-1, 1, (B, 6))
-out = {}
-for arm in ("ur5", "jaco2"):
-    be = cases.GpuBackend(arm)
-    for i, kw in enumerate((dict(kp=200), dict(kp=200, use_C=True), dict(kp=200, null_controllers=[_abi.make_damping(10)]))):
-        out[f"{arm}{i}"] = be.osc(_abi.make_osc_params(6, **kw), q, dq, t)[0]
-    out[arm + "f32"] = be.osc(_abi.make_osc_params(6, kp=200, use_C=True), q.astype(np.float32), dq.astype(np.float32),
-                              t.astype(np.float32), dtype=np.float32)[0]
-np.savez(sys.argv[2], **out)
-"""
-
-
-def test_gpu_workgroups_of_several_wavefronts_equal_single_wavefront_ones(tmp_path):
-    """the x,y,z OSC kernels run with 1 - 4 wavefronts per workgroup (dynamic LDS: one sin/cos table per workgroup, one
-    Coriolis slab per wavefront; measurement switch ABRK_OSC_WAVES): the same bits whatever the shape, including a
-    last workgroup that is partly past the end of the batch"""
-    import subprocess
-    import sys
-
-    from tests.conftest import REPO
-
-    (tmp_path / "run.py").write_text(_WAVES_SCRIPT)
-    res = {}
-    for w in ("1", "2", "4"):
-        r = subprocess.run([sys.executable, str(tmp_path / "run.py"), REPO, str(tmp_path / f"w{w}.npz")],
-                           env=dict(os.environ, ABRK_OSC_WAVES=w), capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stderr[-3000:]
-        res[w] = np.load(tmp_path / f"w{w}.npz")
-    for k in res["1"].files:
-        assert np.all(np.isfinite(res["1"][k]))
-        assert np.array_equal(res["1"][k], res["2"][k]) and np.array_equal(res["1"][k], res["4"][k]), k
-
-
 def test_gpu_six_row_second_pass_forms_meet_at_the_batch_threshold():
     """up to 65536 rows the six-row law hands records to the finish kernel, beyond it the second pass recomputes its
     rows: a batch just above the threshold and its two halves (below it) agree to rounding on every row, and both meet

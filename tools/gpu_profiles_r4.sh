@@ -35,9 +35,28 @@ cd /tmp && export TMPDIR=/tmp
 # (every leg runs its full sustained protocol, so the trace mean of a
 # (kernel, grid) over ALL its launches is what the bench line's `frac` must reproduce
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $ALSO > $O/stats.log 2>&1
+# 4. the 4096-row six-row step as plain launches: first pass + finish kernel, and the round-3 scheme beside it
+cd /tmp
+for mode in handover round3; do
+  E="A=1"; [ $mode = round3 ] && E="ABRK_NO_HANDOVER=1"
+  env $E ABRK_BENCH_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/osc6step_$mode -o t -- python $GRAFT_REPO_ROOT/bench.py --workload osc6 --steps 200 --warmup 20 --no-roofline-leg --no-strong-leg --no-cpu-baseline --no-streams-leg --no-extras > $O/osc6step_$mode.log 2>&1
+done
+cd $GRAFT_REPO_ROOT
+python - "$O" > $O/osc6_step_trace.txt 2>&1 <<'PY'
+import sys, glob, pandas as pd
+O = sys.argv[1]
+for mode in ("handover", "round3"):
+    f = glob.glob(f"{O}/osc6step_{mode}/**/t_kernel_trace.csv", recursive=True)
+    if not f: continue
+    df = pd.read_csv(f[0]); df["kernel"] = df["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:80]
+    df["us"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3
+    print(mode); print(df.groupby(["kernel", "Grid_Size_X", "Workgroup_Size_X"]).agg(n=("us", "size"), mean_us=("us", "mean"), med_us=("us", "median"), min_us=("us", "min")).to_string())
+PY
+cat $O/osc6_step_trace.txt
 find $O -name "*.db" -delete 2>/dev/null
 # the summary of everything (kernel stats, trace means per leg, PMC means per launch, bench lines), made HERE: what comes
 # back is capped at 64 MiB, and the raw counter files of the PMC passes alone exceed that
+cd $GRAFT_REPO_ROOT
 ABRK_PROFILE_COMMIT=${ABRK_PROFILE_COMMIT:-unknown} python tools/summarize_profiles.py $O $O/summary > $O/summarize_final.log 2>&1; tail -2 $O/summarize_final.log
 find $O -path "*pmc_*" -name "*.csv" -size +512k -delete 2>/dev/null
 find $O -name "*.csv" -size +12M -delete 2>/dev/null

@@ -68,7 +68,7 @@ lines = ["# rocprofv3 evidence (MI355X, ROCm 7.2)", "",
          f"Commands: `{os.environ.get('ABRK_PROFILE_SCRIPT', 'tools/gpu_profiles_r4.sh')}` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
          "`--pmc` passes as MI355X_MICROARCH.md prescribes).  `FETCH_SIZE`/`WRITE_SIZE` are in KiB; on gfx950 "
          "FETCH_SIZE counts 64 B per 128-B request, so read bytes = FETCH_SIZE x 1024 x 2.", ""]
-for f in ("pytest_gpu.log", "smoke.log", "coop_ab.md", "rt_ab.md", "valu_rates.txt", "host.txt"):
+for f in ("pytest_gpu.log", "smoke.log", "coop_ab.md", "rt_ab.md", "valu_rates.txt", "host.txt", "osc6_step_trace.txt"):
     if os.path.exists(os.path.join(src, f)):
         shutil.copy(os.path.join(src, f), os.path.join(dst, f))
 for f in sorted(os.listdir(src)):
