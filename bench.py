@@ -253,9 +253,11 @@ class Runner:
             blocks = min(blocks, 256 * 32 * 4)
         elif self.kind == "obstacles":
             blocks = min(blocks, 4096)
-        elif (self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name() and self.B >= 16384
-              and os.environ.get("ABRK_BENCH_KM6_P1_LOOP")):
-            blocks = min(blocks, 4096)  # a library built with -DABRK_KM6_P1_LOOP=1 (the first pass as a persistent grid)
+        elif (self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name()
+              and (self.arm == "jaco2" or (self.B >= 16384 and os.environ.get("ABRK_BENCH_KM6_P1_LOOP")))):
+            # the six-row first pass of a general chain (Jaco2: one wave per SIMD) is a persistent grid; so is every
+            # first pass of a library built with -DABRK_KM6_P1_LOOP=1
+            blocks = min(blocks, 4096)
         return blocks * 64
 
     def step(self):
