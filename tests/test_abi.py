@@ -37,16 +37,18 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "abrk.h"
-int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(abrk_arm_desc), sizeof(abrk_dyn_out),
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(abrk_arm_desc), sizeof(abrk_dyn_out),
   sizeof(abrk_null_ctrl), sizeof(abrk_osc_params), sizeof(abrk_sliding_params), offsetof(abrk_osc_params, null_ctrl),
-  sizeof(abrk_limits_params), sizeof(abrk_obstacles_params), offsetof(abrk_obstacles_params, obstacles));return 0;}'''
+  sizeof(abrk_limits_params), sizeof(abrk_obstacles_params), offsetof(abrk_obstacles_params, obstacles),
+  sizeof(abrk_scratch_info), offsetof(abrk_scratch_info, device_free_bytes));return 0;}'''
     exe = "/tmp/abrk_layout_probe"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(REPO, "include"), "-o", exe], input=src.encode(),
                    check=True)
     sizes = [int(v) for v in subprocess.run([exe], capture_output=True, check=True).stdout.split()]
     assert sizes == [C.sizeof(_abi.ArmDesc), C.sizeof(_abi.DynOut), C.sizeof(_abi.NullCtrl),
                      C.sizeof(_abi.OSCParams), C.sizeof(_abi.SlidingParams), _abi.OSCParams.null_ctrl.offset,
-                     C.sizeof(_abi.LimitsParams), C.sizeof(_abi.ObstaclesParams), _abi.ObstaclesParams.obstacles.offset]
+                     C.sizeof(_abi.LimitsParams), C.sizeof(_abi.ObstaclesParams), _abi.ObstaclesParams.obstacles.offset,
+                     C.sizeof(_abi.ScratchInfo), _abi.ScratchInfo.device_free_bytes.offset]
 
 
 def test_builtin_arm_registry_matches_tables(L):
