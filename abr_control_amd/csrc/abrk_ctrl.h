@@ -1250,6 +1250,12 @@ ABRK_INL void osc6_finish_row(const T* __restrict__ rec, bool nulls, T (&u)[N], 
 #ifndef ABRK_LAW6_YB_FIRST
 #define ABRK_LAW6_YB_FIRST 6
 #endif
+// rows of the task Jacobian read from the row store one AHEAD of their use (first pass: Y and J^T f).  Same box, three
+// interleaved repetitions: the 4096-row step 16.65 / 16.71 / 16.75 us against 17.09 / 16.94 / 16.95; 8 M rows 766.9 / 767.1 /
+// 770.8 against 769.9 / 769.8 / 771.7 us; no register more (224 - 248).
+#ifndef ABRK_LAW6_PREFETCH
+#define ABRK_LAW6_PREFETCH 1
+#endif
 template <int N, class T, bool USE_C, int FEAT, class Rows, int QSTEPS = 3>
 ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
                        const T (&cvec)[N], Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
@@ -1385,7 +1391,18 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     sfor<KM / YB>([&](auto bi) ABRK_LAMBDA {
       constexpr int r0 = bi() * YB;
       T Ya[YB][N];
-      sfor<YB>([&](auto r) ABRK_LAMBDA { yrow(ic<r0 + r()>{}, Ya[r()]); });
+      if constexpr (YB == KM && (ABRK_LAW6_PREFETCH != 0)) {
+        // the row store is read one row AHEAD of the forward solve that consumes it: at small batches one wavefront
+        // per SIMD has nothing else to hide the LDS round trip behind (12 more registers: the first pass has them)
+        T rb[2][N];
+        js.get_row(ic<0>{}, rb[0]);
+        sfor<YB>([&](auto r) ABRK_LAMBDA {
+          if constexpr (r() + 1 < YB) js.get_row(ic<r() + 1>{}, rb[(r() + 1) & 1]);
+          chol_fwd<N>(L, il, rb[r() & 1], Ya[r()]);
+        });
+      } else {
+        sfor<YB>([&](auto r) ABRK_LAMBDA { yrow(ic<r0 + r()>{}, Ya[r()]); });
+      }
       sfor<YB>([&](auto r) ABRK_LAMBDA {
         sfor<r() + 1>([&](auto c) ABRK_LAMBDA { Am[tri(r0 + r(), r0 + c())] = ydot(Ya[r()], Ya[c()]); });
       });
@@ -1565,6 +1582,17 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   T a1[N], a2[FEAT >= 1 ? N : 1];
   sfor<N>([&](auto i) ABRK_LAMBDA { a1[i()] = T(-0.0); });
   if constexpr (FEAT >= 1) sfor<N>([&](auto i) ABRK_LAMBDA { a2[i()] = T(-0.0); });
+  if constexpr (Rows::kDeferOnly && (ABRK_LAW6_PREFETCH != 0)) {
+    T rb[2][N];
+    js.get_row(ic<0>{}, rb[0]);
+    sfor<KM>([&](auto r) ABRK_LAMBDA {
+      if constexpr (r() + 1 < KM) js.get_row(ic<r() + 1>{}, rb[(r() + 1) & 1]);
+      sfor<N>([&](auto i) ABRK_LAMBDA { a1[i()] += rb[r() & 1][i()] * f[r()]; });
+      if constexpr (FEAT >= 1) {
+        if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { a2[i()] += rb[r() & 1][i()] * f2[r()]; });
+      }
+    });
+  } else {
   sfor<KM>([&](auto r) ABRK_LAMBDA {
     T row[N];
     js.get_row(r, row);
@@ -1573,6 +1601,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { a2[i()] += row[i()] * f2[r()]; });
     }
   });
+  }
   sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = u0[i()] - a1[i()]; });
   if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= cvec[i()]; });  // osc.py:291-292
   sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297 (kNoTs: not stored)
