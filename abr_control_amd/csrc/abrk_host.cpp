@@ -760,7 +760,10 @@ int finish_coop_max() {
   return v;
 }
 int finish_coop_rounds() {
-  static const int v = env_int("ABRK_FINISH_ROUNDS", 2);
+  static const int v = [] {
+    const int e = env_int("ABRK_FINISH_ROUNDS", 2);
+    return e < 0 ? 0 : e > kFinishMaxRounds ? kFinishMaxRounds : e;  // (the finish kernel's row list holds that many rounds)
+  }();
   return v;
 }
 int finish_grid_for(int64_t B) {
