@@ -1485,10 +1485,14 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
         sfor<KM>([&](auto r) ABRK_LAMBDA { sv[tri(r(), r())] = sel[r()] ? Am[tri(r(), r())] : T(0); });
         sv[21] = T(0);
         store_pairs<22>(rec, sv);
+        // (the rows come back from the row store one ahead of the stores that copy them: few lanes are in this branch,
+        //  but their wavefront waits for every LDS round trip in full)
+        T rb[2][N];
+        js.get_row(ic<0>{}, rb[0]);
         sfor<KM>([&](auto r) ABRK_LAMBDA {
           T xr[XS];
-          T row[N];
-          js.get_row(r, row);
+          if constexpr (r() + 1 < KM) js.get_row(ic<r() + 1>{}, rb[(r() + 1) & 1]);
+          const T(&row)[N] = rb[r() & 1];
           T jv = T(-0.0);
           sfor<N>([&](auto i) ABRK_LAMBDA { xr[i()] = row[i()]; });
           if constexpr (FEAT >= 1) {

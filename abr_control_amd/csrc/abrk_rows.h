@@ -9,7 +9,7 @@
 #define ABRK_LATE_TARGET 0
 #endif
 #ifndef ABRK_KM6_EARLY
-#define ABRK_KM6_EARLY 0  // measurement switch: the six-row kernels request every input up front as well
+#define ABRK_KM6_EARLY 0  // measurement switch: EVERY six-row kernel requests its inputs up front (see osc_body)
 #endif
 
 namespace abrk {
@@ -157,7 +157,11 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
   // kinematics to keep that kernel's register peak down.
   // (the six-row kernels ask late as well: their law, not the kinematics, is the register peak)
-  constexpr bool EARLY = FEAT < 2 && (KM <= 3 || (ABRK_KM6_EARLY != 0));
+  // (the six-row FIRST pass of orthogonal chains asks early too since round 4: its law was restructured to 224 - 246
+  //  registers, and at two waves per SIMD one memory round trip fewer per wavefront is worth 2.7 % at 8 M rows - 740 / 746 /
+  //  744 us against 760 / 765 / 767 us, same box; the one-wave six-row kernels keep asking late)
+  constexpr bool EARLY = FEAT < 2 && (KM <= 3 || (ABRK_KM6_EARLY != 0) ||
+                                      (std::remove_reference<Scr>::type::kDeferOnly && A::kOrtho && A::kStatic));
   // (ABRK_LATE_TARGET = 1 requests the target after the kinematics in the use_C kernels; measured unnecessary once
   //  the link wrenches of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
   constexpr bool EARLY_T = EARLY && !(USE_C && ABRK_LATE_TARGET);
