@@ -117,7 +117,8 @@ def threshold_band(g, key, eps=1e-6):
         return None
     det, sv = np.abs(g[f"{key}_det"]), g[f"{key}_sv"]
     near_det = np.abs(det - 1e-3) <= eps * 1e-3
-    ratio = sv / sv.max(axis=1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):  # an all-zero Mx_inv (a row without task rows) has no band
+        ratio = sv / sv.max(axis=1, keepdims=True)
     near_cut = (np.abs(ratio - 1e-4) <= eps * 1e-4).any(axis=1) & (det < 1e-3 * (1 + eps))
     return near_det | near_cut
 
@@ -138,7 +139,8 @@ def mx_rows_clear_of_thresholds(det, sv, eps=1e-6):
     """the same band test for `_Mx` called directly (fixtures oschelpers_<arm>.npz): True = safe to compare"""
     det, sv = np.abs(np.asarray(det)), np.asarray(sv)
     near_det = np.abs(det - 1e-3) <= eps * 1e-3
-    ratio = sv / sv.max(axis=1, keepdims=True)
+    with np.errstate(invalid="ignore", divide="ignore"):  # an all-zero Mx_inv (a row without task rows) has no band
+        ratio = sv / sv.max(axis=1, keepdims=True)
     near_cut = (np.abs(ratio - 1e-4) <= eps * 1e-4).any(axis=1) & (det < 1e-3 * (1 + eps))
     return ~(near_det | near_cut)
 
