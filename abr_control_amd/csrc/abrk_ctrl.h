@@ -1193,14 +1193,19 @@ ABRK_INL void pinv_weights(const T (&lam)[K], T rcond, T (&wv)[K]) {
 // own column; lanes N / N + 1 hand their transformed column to the others at the end) or all of them on one lane (the
 // host check build: NV = N + 2).  `col`: index of the first column held.  -> a1[k] = (J^T Mx u_task)_(col+k),
 // a2[k] = (J^T Mx J v)_(col+k) given the transformed u_task / J v columns gu, gw.
-template <int N, class T, int NV, bool UNI>
-ABRK_INL void osc6_rec_transform(const T* __restrict__ rec, int col, T (&G)[NV][6], T (&wv)[6]) {
+// (in two steps, so that a caller can ask for a record before it knows that there is one: osc6_finish_kernel)
+template <int N, class T, int NV>
+ABRK_INL void osc6_rec_load(const T* __restrict__ rec, int col, T (&S)[21], T (&G)[NV][6]) {
   constexpr int XS = rec_xs(N);
-  T S[21], lam[6];
   sfor<21>([&](auto e) ABRK_LAMBDA { S[e()] = rec[e()]; });
   sfor<NV>([&](auto k) ABRK_LAMBDA {
     sfor<6>([&](auto r) ABRK_LAMBDA { G[k()][r()] = rec[rec_off_x() + r() * XS + col + k()]; });
   });
+}
+template <int N, class T, int NV, bool UNI>
+ABRK_INL void osc6_rec_solve(const T* __restrict__ rec, int col, T (&S)[21], T (&G)[NV][6], T (&wv)[6]) {
+  constexpr int XS = rec_xs(N);
+  T lam[6];
   if (!ql_core<6, T, NV, false, UNI>(S, G, lam)) {
     if constexpr (UNI) {  // (cold: a rotation radius underflowed - the predicated form has tql2's recovery path)
       sfor<NV>([&](auto k) ABRK_LAMBDA {
@@ -1210,6 +1215,12 @@ ABRK_INL void osc6_rec_transform(const T* __restrict__ rec, int col, T (&G)[NV][
     }
   }
   pinv_weights<6>(lam, T(1e-3) * T(0.1), wv);
+}
+template <int N, class T, int NV, bool UNI>
+ABRK_INL void osc6_rec_transform(const T* __restrict__ rec, int col, T (&G)[NV][6], T (&wv)[6]) {
+  T S[21];
+  osc6_rec_load<N, T, NV>(rec, col, S, G);
+  osc6_rec_solve<N, T, NV, UNI>(rec, col, S, G, wv);
 }
 // the whole second pass of one row on one lane (host check build; the GPU spreads the columns over lanes)
 template <int N, class T>
@@ -1483,7 +1494,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
         T sv[22];
         sfor<21>([&](auto e) ABRK_LAMBDA { sv[e()] = Am[e()]; });
         sfor<KM>([&](auto r) ABRK_LAMBDA { sv[tri(r(), r())] = sel[r()] ? Am[tri(r(), r())] : T(0); });
-        sv[21] = T(0);
+        sv[21] = T(js.row);  // the row's index: the records of a chunk are packed (ScratchBase::record)
         store_pairs<22>(rec, sv);
         // (the rows come back from the row store one ahead of the stores that copy them: few lanes are in this branch,
         //  but their wavefront waits for every LDS round trip in full)

@@ -927,9 +927,9 @@ struct ScratchBase {
   bool allow_defer = false, deferred = false;
   ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
   // where a deferring row parks itself (set by the kernel; the host check build passes plain arrays).
-  //   hand-over mode (rec_base != nullptr; batches up to 262144 rows): the row's record is rec_base[row] - no list, no
-  //     atomic; the kernel notes WHICH rows deferred as one 64-bit mask per 64-row chunk (osc_kernel: a ballot after the
-  //     row program), and the finish kernel compacts the masks;
+  //   hand-over mode (rec_base != nullptr; batches up to 262144 rows): the row leaves a record (record() below) - no
+  //     list, no atomic; the kernel notes WHICH rows deferred as one 64-bit mask per 64-row chunk (osc_kernel: a ballot
+  //     after the row program), and the finish kernel works each chunk's records off;
   //   recompute mode: the row's index joins sub-list wl_sub of the worklist `wl` (an atomic slot) and the second pass
   //     runs the complete row program on it.
   int* wl = nullptr;
@@ -955,8 +955,22 @@ struct ScratchBase {
     wl[16 * kWlLists + (long)wl_sub * wl_cap + k] = (int)row;
     return false;
   }
+  // The records of a 64-row chunk are packed at the chunk's first slots, in lane order: the deferring lanes of a
+  // wavefront are inside one branch together, so a ballot there numbers them (the same set the kernel's mask holds
+  // afterwards), and the finish kernel's wavefront (chunk, s) can ask for record chunk * 64 + s at the same time as for
+  // the chunk's mask - one memory round trip instead of mask -> row -> record.  The row's own index travels in the
+  // record (its 22nd value).  (The host check build runs rows one by one: record = row.)
   template <class T>
-  ABRK_INL T* record(int len) const { return static_cast<T*>(rec_base) + row * len; }
+  ABRK_INL T* record(int len) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long act = __ballot(1);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u));
+    return static_cast<T*>(rec_base) + (row - lane + rank) * len;
+#else
+    return static_cast<T*>(rec_base) + row * len;
+#endif
+  }
 };
 template <class T, int N>
 struct RegScratch : ScratchBase {

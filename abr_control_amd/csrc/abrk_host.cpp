@@ -663,7 +663,8 @@ int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, in
   if (!handover && B < 16384) return 0;
   const size_t need = (size_t)wl_ints(B) * sizeof(int);
   // (hand-over mode keeps one 64-bit mask per 64-row chunk in `wl` - far less than the recompute form's lists)
-  const size_t need_rec = handover ? (size_t)B * rec_len(n) * esz(dtype) : 0;
+  // (whole chunks: the finish kernel asks for a chunk's slot before it knows whether a record is there)
+  const size_t need_rec = handover ? (size_t)((B + kBlock - 1) / kBlock * kBlock) * rec_len(n) * esz(dtype) : 0;
   if (Recorder* r = t_rec) {
     void *p = nullptr, *q = nullptr;
     hipError_t e = hipMalloc(&p, need);
@@ -752,24 +753,15 @@ int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
-// deferred rows up to which a wavefront takes ONE row (above: one row per lane): while there is about one such wavefront
-// per SIMD (1024) the cooperative form is bound by a single instruction stream (~8 us); two on a SIMD halve each other's
-// issue rate, and from there the per-lane form's 64 rows per wavefront (~12 us whatever the count) wins.
-int finish_coop_max() {
-  static const int v = env_int("ABRK_FINISH_COOP_MAX", 1536);
-  return v;
+// wavefronts per chunk and records per wavefront of the finish kernel (abrk_kernels.h finish_slots / finish_rounds);
+// measurement switches, read once
+int finish_slots_for(int64_t B) {
+  static const int forced = env_int("ABRK_FINISH_SLOTS", 0);
+  return forced >= 1 && forced <= kBlock ? forced : finish_slots((long)B);
 }
-int finish_coop_rounds() {
-  static const int v = [] {
-    const int e = env_int("ABRK_FINISH_ROUNDS", 2);
-    return e < 0 ? 0 : e > kFinishMaxRounds ? kFinishMaxRounds : e;  // (the finish kernel's row list holds that many rounds)
-  }();
-  return v;
-}
-int finish_grid_for(int64_t B) {
-  static const int forced = env_int("ABRK_FINISH_GRID", 0);
-  const int lo = (int)((B + (int64_t)kFinishMaxRounds * kBlock - 1) / ((int64_t)kFinishMaxRounds * kBlock));
-  return forced >= lo ? forced : finish_grid((long)B, finish_coop_max() > 0 ? finish_coop_max() : 1);
+int finish_rounds_for(int64_t B) {
+  static const int forced = env_int("ABRK_FINISH_ROUNDS", -1);  // (0: every chunk goes one record per lane)
+  return forced >= 0 ? (forced > kBlock ? kBlock : forced) : finish_rounds((long)B);
 }
 
 int check_common(int arm_id, int dtype, int64_t B, ArmEntry** a) {
@@ -929,8 +921,8 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   const ArmOps* ops = a->ops;
   const hipStream_t hs = (hipStream_t)stream;
   // hand-over mode: the arm's first pass, then the arm-independent finish kernel on the records it left
-  FinishArgs fa{oa.wl, oa.rec, (P->n_null > 0 || u_null_ext) ? 1 : 0, finish_grid_for(B), finish_coop_max(),
-                finish_coop_rounds(), oa.u, oa.ts};
+  FinishArgs fa{oa.wl, oa.rec, (P->n_null > 0 || u_null_ext) ? 1 : 0, finish_slots_for(B), finish_rounds_for(B),
+                oa.u, oa.ts};
   return dispatch(st, a, dtype, [=](const void* rt) {
     OscArgs o = oa;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;

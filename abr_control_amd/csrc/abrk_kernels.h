@@ -377,22 +377,26 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
   }
 }
 
-// ---- second pass of the six-row law on hand-over records (osc_law6's deferral branch wrote them, one per deferring
-// row, at rec[row]; abrk_device.h rec_*; the arithmetic: abrk_ctrl.h osc6_rec_transform).  Which rows deferred arrives
-// as one 64-bit mask per 64-row chunk (the first pass's ballot).  Every workgroup compacts ALL masks (<= 32 KB at
-// 262144 rows; a block-wide prefix sum of the popcounts) and takes the deferred rows whose global index falls on its
-// slots - the rows are spread evenly over the grid whatever wavefronts they came from.  Two forms, one per launch:
-//   * wave-cooperative (P <= coop_max rows, <= coop_rounds per slot): a slot is a WAVEFRONT (= a workgroup).  Every lane decomposes the
-//     row's 6 x 6 Mx_inv - redundantly, so nothing crosses lanes and every data-dependent branch of the QL iteration is
-//     uniform (only the rotations that exist are executed: ~35 of the 68 slots the predicated per-lane form walks) -
-//     and applies the transformations to ITS column of [J | u_task | J v]; lanes N and N + 1 then hand their column to
-//     the others (v_readlane) and lane c < N finishes joint c.  A lone lane's eigen-decomposition was the critical
-//     path of every small six-row step (4096 rows: 95 % of the 64 wavefronts have a truncating row, 21 us per step of
-//     which ~15 us are ONE lane's 4800 dependent instructions); here the per-lane work is the scalar recurrence plus
-//     one vector, and a 4096-row step's ~190 such rows run on 190 of the 1024 SIMDs at once.
-//   * one row per lane (more rows than that: arms whose Mx_inv always truncates, large batches): a slot is a LANE, the
-//     same arithmetic with all N + 2 columns on it - issue-efficient where there are enough rows to fill wavefronts.
-constexpr int kFinishMaxRounds = 4;  // rows per slot at most: the host sizes the grid for it (finish_grid)
+// ---- second pass of the six-row law on hand-over records (osc_law6's deferral branch wrote them; abrk_device.h rec_*,
+// ScratchBase::record: the records of a 64-row chunk packed at the chunk's first slots, each carrying its row's index;
+// the arithmetic: abrk_ctrl.h osc6_rec_solve).  Which rows deferred arrives as one 64-bit mask per 64-row chunk (the
+// first pass's ballot).  The grid is (chunks, slots): wavefront (j, s) asks for chunk j's mask AND for the record in the
+// chunk's slot s at once - one memory round trip; whether there is such a record it learns from the mask's popcount.
+// (Round 4 began with a global compaction of all masks in every wavefront - a prefix sum, a second walk over the masks,
+// a row list in LDS - and the dependent chain mask -> row -> record: ~1.5 us of an 8.9 us kernel.)  Two forms, chosen
+// per chunk from its own count:
+//   * wave-cooperative (count <= coop_rounds x slots): wavefront (j, s) takes the chunk's records s, s + slots, ...
+//     Every lane decomposes the record's 6 x 6 Mx_inv - redundantly, so nothing crosses lanes and every data-dependent
+//     branch of the QL iteration is uniform (only the rotations that exist are executed: ~35 of the 68 slots the
+//     predicated per-lane form walks) - and applies the transformations to ITS column of [J | u_task | J v]; lanes N
+//     and N + 1 then hand their column to the others (v_readlane) and lane c < N finishes joint c.  A lone lane's
+//     eigen-decomposition was the critical path of every small six-row step (4096 rows: 95 % of the 64 wavefronts
+//     have a truncating row, 21 us per step of which ~15 us are ONE lane's 4800 dependent instructions); here the
+//     per-lane work is the scalar recurrence plus one vector, and a 4096-row step's ~190 such rows run on 190 of the
+//     1024 SIMDs at once.
+//   * one record per lane (more than that: arms whose Mx_inv always truncates, large batches where `slots` is small):
+//     wavefront (j, 0) takes all of the chunk's records, the same arithmetic with all N + 2 columns on the lane.
+// Both are the same solver with contraction pinned off: a row's bits do not depend on which ran.
 template <class T>
 __device__ __forceinline__ T lane_bcast(T v, int src) {
   if constexpr (sizeof(T) == 8) {
@@ -404,76 +408,55 @@ __device__ __forceinline__ T lane_bcast(T v, int src) {
     return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
   }
 }
+// (keeps a value that was asked for ahead of a branch from being asked for behind it)
+template <class T>
+__device__ __forceinline__ void pin_loaded(T& v) {
+  asm volatile("" : "+v"(v));
+}
 // Workgroups are single wavefronts: the wave-cooperative form is bound by ONE wavefront's instruction stream, and two
 // of them on a SIMD halve each other's issue rate (measured with 512-thread workgroups: eight working wavefronts per
-// CU, 14.4 us for 190 rows; the dispatcher spreads single-wavefront workgroups over the CUs).  Every wavefront scans
-// all masks itself (lane t owns masks [t per, (t + 1) per); a wavefront-level prefix sum, no barrier).
+// CU, 14.4 us for 190 rows; the dispatcher spreads single-wavefront workgroups over the CUs).  blockIdx.x is the chunk:
+// the wavefronts that have a record (slots 0, 1, 2 of most chunks) come first in dispatch order and spread over all XCDs.
 template <int N, class T>
 __global__ void __launch_bounds__(kBlock)
-osc6_finish_kernel(long B, const unsigned long long* __restrict__ masks, const T* __restrict__ recs, int nulls,
-                   int coop_max, int coop_rounds, T* __restrict__ ug, T* __restrict__ tsg) {
-  __shared__ int mine[kFinishMaxRounds * kBlock];
+osc6_finish_kernel(const unsigned long long* __restrict__ masks, const T* __restrict__ recs, int nulls, int coop_rounds,
+                   T* __restrict__ ug, T* __restrict__ tsg) {
   const int lane = (int)threadIdx.x;
-  // ---- the global index of each deferred row
-  const long nchunk = (B + kBlock - 1) / kBlock;
-  const int per = (int)((nchunk + kBlock - 1) / kBlock);
-  const long m0 = (long)lane * per;
-  int cnt = 0;
-  for (int k = 0; k < per; k++) cnt += (m0 + k < nchunk) ? __popcll(masks[m0 + k]) : 0;
-  int incl = cnt;
-  for (int d = 1; d < kBlock; d <<= 1) {
-    const int v = __shfl_up(incl, d);
-    if (lane >= d) incl += v;
-  }
-  const int P = __builtin_amdgcn_readlane(incl, kBlock - 1);
-  if (P == 0) return;
-  const bool coop = P <= coop_max && P <= coop_rounds * (int)gridDim.x;
-  const int SB = coop ? 1 : kBlock;  // slots of a workgroup (a slot: the wavefront / a lane)
-  const int S = (int)gridDim.x * SB;
-  const int rounds = (P + S - 1) / S;
-  if ((int)blockIdx.x * SB >= P) return;  // no row falls on this workgroup's slots
-  // the rows on this workgroup's slots: round r covers the global indices [lo, hi); a lane whose deferred rows
-  // [pre, pre + cnt) meet that range walks ITS masks once more (L2-resident) and delivers exactly those rows
-  {
-    const int pre = incl - cnt;
-    for (int r = 0; r < rounds && r < kFinishMaxRounds; r++) {
-      const int lo = r * S + (int)blockIdx.x * SB;
-      int hi = lo + SB;
-      hi = hi < P ? hi : P;
-      int a = pre > lo ? pre : lo;
-      const int b = pre + cnt < hi ? pre + cnt : hi;
-      if (a < b) {
-        int p = pre;
-        for (int k = 0; k < per && p < b; k++) {
-          unsigned long long bits = masks[m0 + k];  // (cnt > 0: every index of this lane below nchunk that matters)
-          const int c = __popcll(bits);
-          if (p + c <= a) {  // the whole mask lies before the range
-            p += c;
-            continue;
-          }
-          while (bits && p < b) {
-            const int bit = __builtin_ctzll(bits);
-            bits &= bits - 1;
-            if (p >= a) mine[r * SB + (p - lo)] = (int)((m0 + k) * kBlock + bit);
-            p++;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (coop) {
-    for (int r = 0; r < rounds && r < kFinishMaxRounds; r++) {
-      if (r * S + (int)blockIdx.x >= P) break;
-      const long b = mine[r];
-      const T* rec = recs + b * rec_len(N);
-      const int c = lane < N + 2 ? lane : N + 1;  // (idle lanes shadow the last column)
-      // the two joint-space sums are asked for with the rest of the record: one memory round trip, not two
-      const T b1 = rec[rec_off_b1(N) + (lane < N ? lane : 0)], b2 = rec[rec_off_b1(N) + N + (lane < N ? lane : 0)];
+  const long j = blockIdx.x;
+  const int s0 = (int)blockIdx.y, slots = (int)gridDim.y;
+  const int c = lane < N + 2 ? lane : N + 1;  // (idle lanes shadow the last column)
+  const int jc = lane < N ? lane : 0;
+  const T* rec = recs + (j * kBlock + s0) * rec_len(N);
+  // mask and record together (the record's slot exists whatever it holds: the host sizes `recs` in whole chunks)
+  // (the mask through the vector memory path, like the record's columns: as a scalar load the compiler queues it behind
+  //  the wait for the record's scalar loads - two round trips again)
+  long jv = j;
+  pin_loaded(jv);
+  unsigned long long mask = masks[jv];
+  T S[21], G[1][6], ridx, b1, b2;
+  auto load = [&]() ABRK_LAMBDA {
+    osc6_rec_load<N, T, 1>(rec, c, S, G);
+    ridx = rec[21];
+    // the two joint-space sums are asked for with the rest of the record: one memory round trip, not two
+    b1 = rec[rec_off_b1(N) + jc];
+    b2 = rec[rec_off_b1(N) + N + jc];
+  };
+  load();
+  sfor<21>([&](auto e) ABRK_LAMBDA { pin_loaded(S[e()]); });
+  sfor<6>([&](auto r) ABRK_LAMBDA { pin_loaded(G[0][r()]); });
+  pin_loaded(ridx);
+  pin_loaded(b1);
+  pin_loaded(b2);
+  pin_loaded(mask);
+  const int cnt = __builtin_amdgcn_readfirstlane(__popcll(mask));
+  if (s0 >= cnt) return;  // nothing in this slot
+  if (cnt <= coop_rounds * slots) {
+    for (int s = s0;;) {
+      const long b = (long)ridx;
       {
 #pragma clang fp contract(off)  // the same bits as osc6_finish_row
-        T G[1][6], wv[6];
-        osc6_rec_transform<N, T, 1, true>(rec, c, G, wv);
+        T wv[6];
+        osc6_rec_solve<N, T, 1, true>(rec, c, S, G, wv);
         T a1 = T(-0.0), a2 = T(-0.0);
         sfor<6>([&](auto i) ABRK_LAMBDA {
           const T gu = lane_bcast(G[0][i()], N), gw = lane_bcast(G[0][i()], N + 1);
@@ -486,29 +469,33 @@ osc6_finish_kernel(long B, const unsigned long long* __restrict__ masks, const T
           if (tsg) tsg[b * N + lane] = ts;
         }
       }
+      s += slots;
+      if (s >= cnt) break;
+      rec = recs + (j * kBlock + s) * rec_len(N);
+      load();
     }
-  } else {
-    for (int r = 0; r < rounds && r < kFinishMaxRounds; r++) {
-      if (r * S + (int)blockIdx.x * SB + lane >= P) break;
-      const long b = mine[r * SB + lane];
-      T u[N], ts[N];
-      osc6_finish_row<N, T>(recs + b * rec_len(N), nulls != 0, u, ts);
-      store_row<N>(ug, b, u);
-      if (tsg) store_row<N>(tsg, b, ts);
-    }
+  } else if (s0 == 0 && lane < cnt) {
+    rec = recs + (j * kBlock + lane) * rec_len(N);
+    const long b = (long)rec[21];
+    T u[N], ts[N];
+    osc6_finish_row<N, T>(rec, nulls != 0, u, ts);
+    store_row<N>(ug, b, u);
+    if (tsg) store_row<N>(tsg, b, ts);
   }
 }
-// workgroups (= wavefronts) of the finish kernel for a B-row call: one per deferred row while ~7 % of the rows defer
-// (random UR5 states with all six task rows: 4.6 %), as many as the wave-cooperative form can use at most, and never
-// fewer than one lane per kFinishMaxRounds rows (every row may defer: arms whose Mx_inv always truncates)
-inline int finish_grid(long B, int coop_max) {
-  long g = (B * 7 + 99) / 100;
-  const long lo = (B + (long)kFinishMaxRounds * kBlock - 1) / ((long)kFinishMaxRounds * kBlock);
-  if (g > coop_max) g = coop_max;  // (beyond coop_max deferred rows the per-lane form runs: 64 rows per workgroup)
-  if (g < lo) g = lo;
-  return (int)(g < 1 ? 1 : g);
+// Wavefronts per chunk and records a wavefront takes at most, by batch size (random UR5 states with all six task rows:
+// 4.6 % defer, 2.9 per chunk, more than 12 never).  Measured, us per step new / round-4 global compaction: 4096 rows
+// 15.6 / 16.4, 8192 15.7, 16 k 19.4 / 17.4, 32 k 20.2 / 23.0, 64 k 27.6 / 36.8.  Up to 8192 rows every (chunk, slot)
+// has a SIMD of its own; at 16 k rows the wavefronts of slots >= 4 share a SIMD with a working one (the finish kernel
+// lasts 12.0 us instead of 8.2 - the one size where compacting over the whole batch was better); beyond that the
+// working wavefronts outnumber the SIMDs anyway, a second round costs more than a second wavefront on the SIMD, and
+// chunks with more records than slots go one record per lane.
+inline int finish_slots(long B) {
+  const long nchunk = (B + kBlock - 1) / kBlock;
+  return nchunk <= 256 ? 12 : nchunk <= 512 ? 8 : 2;
 }
-constexpr long kHandoverMaxRows = 262144;  // 4096 masks: 64 per lane of a scanning wavefront
+inline int finish_rounds(long B) { return (B + kBlock - 1) / kBlock <= 256 ? 2 : 1; }
+constexpr long kHandoverMaxRows = 262144;  // (the finish kernel's grid: 4096 chunks x slots)
 
 // Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
 // cooperative stores and (use_C) the scratch of the Coriolis recursion, which is dead by the time the first row is
@@ -592,7 +579,9 @@ struct LaunchArgs {
 struct FinishArgs {
   const void* masks;  // one 64-bit mask per 64-row chunk: the rows the first pass deferred
   const void* rec;
-  int nulls, grid, coop_max, coop_rounds;
+  int nulls;
+  int slots;        // wavefronts per 64-row chunk (finish_slots)
+  int coop_rounds;  // records a wavefront takes at most; a chunk with more than slots x coop_rounds goes one record per lane
   void *u, *ts;
 };
 // (abrk_law.hip; arm-independent: the record holds everything)

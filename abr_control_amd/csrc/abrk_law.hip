@@ -21,13 +21,13 @@ hipError_t launch_osc_law(int n, int dtype, const LaunchArgs& la, const LawArgs&
 }
 template <int N, class T>
 static hipError_t finish_launch(const LaunchArgs& la, const FinishArgs& a) {
-  hipLaunchKernelGGL((osc6_finish_kernel<N, T>), dim3((unsigned)a.grid), dim3(kBlock), 0, la.stream, la.B,
-                     (const unsigned long long*)a.masks, (const T*)a.rec, a.nulls, a.coop_max, a.coop_rounds, (T*)a.u,
-                     (T*)a.ts);
+  const unsigned nchunk = (unsigned)((la.B + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL((osc6_finish_kernel<N, T>), dim3(nchunk, (unsigned)a.slots), dim3(kBlock), 0, la.stream,
+                     (const unsigned long long*)a.masks, (const T*)a.rec, a.nulls, a.coop_rounds, (T*)a.u, (T*)a.ts);
   return hipGetLastError();
 }
 hipError_t launch_osc6_finish(int n, int dtype, const LaunchArgs& la, const FinishArgs& a) {
-  if (a.grid < 1 || la.B > kHandoverMaxRows) return hipErrorInvalidValue;
+  if (a.slots < 1 || a.slots > kBlock || la.B < 1 || la.B > kHandoverMaxRows) return hipErrorInvalidValue;
 #define ABRK_CASE(NN) \
   case NN:            \
     return dtype == 0 ? finish_launch<NN, double>(la, a) : finish_launch<NN, float>(la, a);

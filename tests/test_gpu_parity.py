@@ -1639,10 +1639,12 @@ np.savez(sys.argv[3], **out)
 
 
 def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
-    """the finish kernel takes one deferred row per WAVEFRONT (few of them) or one per LANE (many): a row's result must
-    not depend on which ran - the two are different instantiations of the same solver with contraction pinned off.
-    The same batch forced through each form (measurement switches ABRK_FINISH_COOP_MAX / _ROUNDS / _GRID), fp64 and
-    fp32: equal bit for bit, and equal to what the default rule picks"""
+    """the finish kernel takes one record per WAVEFRONT (chunks with few of them) or one per LANE (many): a row's result
+    must not depend on which ran - the two are different instantiations of the same solver with contraction pinned off.
+    The same batch forced through each form (measurement switches ABRK_FINISH_ROUNDS / _SLOTS: no cooperative round at
+    all; 4 wavefronts per chunk that take up to 16 records each, one after the other), fp64 and fp32, a batch that ends
+    in a partial chunk, a controller whose every row truncates (64 records per chunk): equal bit for bit, and equal to
+    what the default rule picks"""
     import subprocess
     import sys
 
@@ -1655,8 +1657,8 @@ def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
     np.savez(tmp_path / "in.npz", arm="ur5", q=q, dq=dq, t=t)
     (tmp_path / "run.py").write_text(_FORMS_SCRIPT)
     res = {}
-    forms = (("lane", dict(ABRK_FINISH_COOP_MAX="0")),
-             ("wave", dict(ABRK_FINISH_COOP_MAX="1000000", ABRK_FINISH_ROUNDS="4", ABRK_FINISH_GRID="256")),
+    forms = (("lane", dict(ABRK_FINISH_ROUNDS="0")),
+             ("wave", dict(ABRK_FINISH_ROUNDS="64", ABRK_FINISH_SLOTS="4")),
              ("default", {}))
     for name, sw in forms:
         env = {k: v for k, v in os.environ.items() if not k.startswith("ABRK_FINISH_")}
