@@ -222,7 +222,7 @@ class Runner:
             fast = dof == [1, 1, 1, 0, 0, 0] and p.ref_frame == 2 * self.n + 1
             b = lambda v: "true" if v else "false"
             # six task rows: first pass (PASS = 1, the dominant kernel) + a second pass for the rows whose pseudo-inverse
-            # truncates - up to 262144 rows the finish kernel on hand-over records (osc6_finish_kernel), beyond that the
+            # truncates - 64 ... 65536 rows the finish kernel on hand-over records (osc6_finish_kernel), beyond that the
             # complete row program once more (PASS = 0); ABRK_NO_HANDOVER=1: the round-3 scheme (inline below 16 k rows)
             six_two_pass = (not fast) and (self.B >= 16384 or not os.environ.get("ABRK_NO_HANDOVER"))
             km = 3 if fast else (2 if dof == [1, 1, 0, 0, 0, 0] and self.n <= 3 and p.ref_frame == 2 * self.n + 1 else 6)

@@ -1,5 +1,6 @@
 #!/bin/bash
 # finish kernel: LDS asked for per workgroup as an occupancy cap (40 KiB: four wavefronts per CU)  -> gpurun_out/r4pc3/
+# (ABRK_FINISH_LDS existed in the experiment build only: the cap changed nothing and was not kept - profiles/round4/NOTES.md)
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/r4pc3; mkdir -p $O
 S="--steps 400 --warmup 50 --no-roofline-leg --no-strong-leg --no-cpu-baseline --no-streams-leg --no-extras"
