@@ -103,8 +103,9 @@ int run_osc_handover(const A& arm, int n, const abrk_osc_params* P, int64_t B, c
   if (P->ki == 0) ie = nullptr;
   const int feat = (tv || ie || une) ? 2 : (p.n_null > 0 ? 1 : 0);
   const bool nulls = p.n_null > 0 || une != nullptr;
-  // hand-over mode as on the device: the record of row b at rec[b]; which rows deferred is the kernel's business there
-  // (a ballot per 64-row chunk) and a plain flag array here
+  // hand-over mode as on the device, rows one by one: the record of row b at rec[b] (the device packs a chunk's records
+  // at the chunk's first slots - ScratchBase::record - and carries the row's index in the record); which rows deferred is
+  // the kernel's business there (a ballot per 64-row chunk) and a plain flag array here
   std::vector<T> rec((size_t)B * rec_len(A::N), T(0));
   std::vector<char> flag((size_t)B, 0);
   auto first = [&](long b, auto& scr, auto uc, auto ft) {
