@@ -18,24 +18,39 @@ def dist_env():
 
 class HostGroup:
     """Barrier / max / gather between the ranks of ONE node (bench.py --gpus N: one process per GPU): rank 0 listens on
-    a Unix socket in the abstract namespace, keyed by MASTER_PORT and the launcher's pid (the ranks are siblings - the
-    launcher's own rendezvous store may occupy MASTER_PORT itself, so no TCP port is taken); every operation is one
-    exchange of a small JSON value: each rank sends its value, rank 0 answers with the list of all of them."""
+    a Unix socket in the abstract namespace (Linux), keyed by a per-run token when the launcher exports one
+    (ABRK_GROUP_KEY - bench.py's self-launch does - or TORCHELASTIC_RUN_ID), by MASTER_PORT and by the launcher's pid
+    (the ranks are siblings - the launcher's own rendezvous store may occupy MASTER_PORT itself, so no TCP port is
+    taken); every operation is one exchange of a small JSON value: each rank sends its value, rank 0 answers with the
+    list of all of them."""
 
     def __init__(self, rank, world, timeout=120.0, key=None):
+        if world < 1 or not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world of {world}")
         self.rank, self.world = rank, world
-        key = key or f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        run = os.environ.get("ABRK_GROUP_KEY") or os.environ.get("TORCHELASTIC_RUN_ID") or ""
+        key = key or f"{run}_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         name = "\0abrk_hostgroup_" + key
         if rank == 0:
             self.srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
-            self.srv.bind(name)
+            try:
+                self.srv.bind(name)
+            except OSError as e:
+                self.srv.close()
+                raise RuntimeError(f"HostGroup: the rendezvous name for key {key!r} is taken ({e}): another run of the "
+                                   f"same launcher is using it - export a distinct ABRK_GROUP_KEY per run") from e
             self.srv.listen(world)
             self.srv.settimeout(timeout)
             self.peers = [None] * world
             for _ in range(world - 1):
                 c, _addr = self.srv.accept()
                 c.settimeout(timeout)
-                self.peers[struct.unpack("<i", self._recvn(c, 4))[0]] = c
+                r = struct.unpack("<i", self._recvn(c, 4))[0]
+                if not 0 < r < world or self.peers[r] is not None:
+                    c.close()
+                    raise RuntimeError(f"HostGroup: a peer announced rank {r} (world {world}"
+                                       f"{', already connected' if 0 < r < world else ''}): stray or duplicate rank")
+                self.peers[r] = c
         else:
             deadline = time.monotonic() + timeout
             while True:

@@ -2,8 +2,11 @@
 """Benchmark of the hot path: batched OSC.generate on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment the command LAUNCHES ITSELF: it starts N copies of itself, one process
+per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT exported, HIP_VISIBLE_DEVICES untouched), relays rank
+0's ONE JSON line and fails if any rank fails; fewer than N devices -> one JSON line {"error": ..., "devices_seen": k},
+rc 1.  Under an external one-process-per-GPU launcher that exports the same variables the command is a rank.
 
 One "step" = one pass of the fused OSC kernel over one batch of synthetic joint states that
 are already resident in HBM.  Default workload = BASELINE.json configs[1] (UR5 6-DOF OSC,
@@ -495,7 +498,9 @@ def roofline(runner, ms_per_launch, label):
     }
     # the VALU view from EXECUTED instructions (SQ_INSTS_VALU / row of the committed PMC pass), not from a
     # reference-derived flop count: lane-instructions per second against the issue peak at the nominal clock
-    c, csrc, ccommit = _profiled("counters.json", kname, runner.B)
+    # (HBM-sized legs only: the PMC pass of a config-sized batch is one cold dispatch, and its cycle counters divided by
+    # a replayed kernel's time are not a clock - round 4's line printed 5.27 "GHz" that way)
+    c, csrc, ccommit = _profiled("counters.json", kname, runner.B) if runner.B >= (1 << 20) else (None, None, None)
     if c is not None:
         lane_instr_s = evals_s * c["valu_per_row"]
         peak = ISSUE_PEAK_NOMINAL[dts]
@@ -698,6 +703,88 @@ def cpu_baseline(workload, budget_s=12.0):
     return port
 
 
+def _free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one process per GPU (the contract's
+    environment: RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR, MASTER_PORT; HIP_VISIBLE_DEVICES is left alone - rank r opens
+    device r), relay rank 0's stdout (the ONE JSON line), send every other rank's stdout to stderr.  Returns the exit
+    code: 0 only if every rank exited 0; the first failing rank takes the others down (they would wait for it at the next
+    barrier until the HostGroup timeout)."""
+    import subprocess
+    import uuid
+
+    n = args.gpus
+    if not args.dry_run:
+        import abr_control_amd as a
+
+        seen = a.device_count()
+        if seen < n and not args.allow_shared_device:
+            print(json.dumps({"error": f"--gpus {n} but {seen} HIP device(s) enumerated; nothing was run "
+                                       f"(--allow-shared-device maps rank r to device r mod devices: a test flag, "
+                                       f"not a measurement)", "devices_seen": seen, "n_gpus": n}), flush=True)
+            return 1
+    env0 = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=os.environ.get("MASTER_PORT") or str(_free_port()),
+                ABRK_GROUP_KEY=f"{os.getpid()}_{uuid.uuid4().hex[:12]}")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=True))
+    # rank 0's stdout is drained by a thread (a full pipe must not stall it while this loop polls)
+    import threading
+
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    rd.start()
+    rc, failed = 0, None
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            pending.discard(r)
+            if c != 0 and failed is None:
+                rc, failed = (c if 0 < c < 256 else 1), r
+                for o in pending:  # this rank's peers would sit in a barrier until their timeout
+                    procs[o].terminate()
+        time.sleep(0.02)
+    rd.join(timeout=5)
+    sys.stdout.write("".join(out0))
+    sys.stdout.flush()
+    if failed is not None:
+        print(f"bench.py: the run is void - exit codes of ranks 0..{n - 1}: {[p.returncode for p in procs]} "
+              f"(negative: terminated by this launcher after the first failure)", file=sys.stderr)
+    return rc
+
+
+def dry_run_rank(args, rank, world, group):
+    """TEST leg of the self-launch (--dry-run): the ranks meet exactly as a real run's do - barrier, max of a wall time,
+    gather of a per-rank record - and rank 0 prints one stub line.  No device, no kernels, nothing measured."""
+    if group:
+        group.barrier()
+    if rank == args.dry_run_fail_rank:
+        raise SystemExit(3)
+    wall = 1e-3 * (1 + rank)
+    seen = [{"rank": rank, "pid": os.getpid(), "local_rank": int(os.environ.get("LOCAL_RANK", 0))}]
+    if group:
+        wall = group.max(wall)
+        seen = group.exchange(seen[0])
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "n_ranks_seen": len(seen), "ranks": seen,
+                          "wall_max": wall, "steps": args.steps, "warmup": args.warmup}), flush=True)
+    if group:
+        group.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -717,6 +804,13 @@ def main():
     ap.add_argument("--no-strong-leg", action="store_true", help="skip the strong-scaling leg (cfg4, global batch 2^20)")
     ap.add_argument("--no-streams-leg", action="store_true", help="skip the concurrent_streams leg (rocprofv3's "
                     "kernel tracing crashes inside hipGraphLaunch when 16 streams replay graphs at once)")
+    ap.add_argument("--allow-shared-device", action="store_true",
+                    help="TEST flag: with fewer devices than ranks, rank r runs on device r mod devices (the N > 1 launch "
+                         "contract on a one-GPU box) instead of the run failing with `devices_seen`")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="TEST flag: no device is touched; the ranks only meet (barrier, max, gather) and rank 0 prints "
+                         "a stub line - drives the spawn / collect / failure logic of the self-launch on a CPU box")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="TEST flag: this rank exits 3 after the barrier")
     ap.add_argument("--also", default="", help="comma-separated extra workloads: one HBM-sized roofline leg each "
                                                "(same process, so one rocprofv3 session sees every kernel)")
     args = ap.parse_args()
@@ -727,8 +821,8 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        # no launcher around this process: be the launcher (one process per GPU, this same command line)
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     # coordination only (barrier + max of the timings + one gather of per-GPU figures): a few bytes over a local socket
     # (abr_control_amd.sharding.HostGroup) - no communication library, nothing on the data path
     group = None
@@ -738,10 +832,18 @@ def main():
         group = HostGroup(rank, world)
         group.barrier()
 
+    if args.dry_run:
+        return dry_run_rank(args, rank, world, group)
+
     import abr_control_amd as a
 
     if a.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: abr_control_amd has no CPU fallback")
+    if local_rank >= a.device_count() and not args.allow_shared_device:
+        # never double up silently: a rank without a device of its own fails the run (the self-launcher checks before
+        # it starts anything; this is the same rule under an external launcher)
+        raise SystemExit(json.dumps({"error": f"rank {rank} (LOCAL_RANK {local_rank}) has no device of its own",
+                                     "devices_seen": a.device_count(), "n_gpus": world}))
     device = local_rank % a.device_count()
     stream = a.Stream(device)
     arm, B0, dts, kind, kw, _ = WORKLOADS[args.workload]
@@ -757,8 +859,12 @@ def main():
         run.graph_steps = int(os.environ.get("ABRK_BENCH_GRAPH", "100"))
         _, ms_long = run.timed(2000, 0)
         run.graph_steps = gs
+    ranks_seen = [{"rank": rank, "device": device, "wall_s": round(wall, 9)}]
     if group:
-        wall = group.max(wall)
+        # every rank's wall time for the K steps and the device it ran on: `value` takes the MAX, the list is the
+        # line's own evidence of how many ranks (and which devices) took part
+        ranks_seen = group.exchange(ranks_seen[0])
+        wall = max(r["wall_s"] for r in ranks_seen)
     value = world * run.evals_per_launch * args.steps / wall
 
     out = None
@@ -766,7 +872,9 @@ def main():
         out = {
             "metric": "OSC control steps/sec (batched UR5 6-DOF)" if args.workload == "cfg2"
             else f"control steps/sec ({args.workload})",
-            "value": round(value, 1), "unit": "control steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 1), "unit": "control steps/s", "n_gpus": world, "n_ranks_seen": len(ranks_seen),
+            "ranks": ranks_seen, "shared_device": len({r["device"] for r in ranks_seen}) < len(ranks_seen),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(wall / args.steps * 1e3, 6), "higher_is_better": True, "scaling": "weak",
             "us_per_step_long_run": None if ms_long is None else round(ms_long * 1e3, 3),
             "vs_baseline": None, "dtype": dts, "data": "synthetic",
@@ -789,8 +897,10 @@ def main():
         r4 = Runner("cfg4", hi - lo, device, stream, global_rows=(lo, G))
         k4 = max(min(args.steps, 400), 8)
         wall4, ms4 = r4.timed(k4, min(args.warmup, 50), barrier)
+        n_seen4 = 1
         if group:
-            wall4 = group.max(wall4)
+            walls4 = group.exchange(float(wall4))  # every rank's wall: their count is what the line reports as seen
+            wall4, n_seen4 = max(walls4), len(walls4)
         if args.dump_shard_u:  # test hook: this rank's shard of u (tests compare with the unsharded call, bit for bit)
             import hashlib
 
@@ -803,7 +913,7 @@ def main():
         if rank == 0:
             out["strong_scaling_cfg4"] = {
                 "workload": "cfg4: ur5 OSC + g + C, global batch 2^20 sharded by contiguous rows, no collective",
-                "global_batch": G, "n_gpus": world, "rows_per_gpu": hi - lo, "steps": k4,
+                "global_batch": G, "n_gpus": world, "n_ranks_seen": n_seen4, "rows_per_gpu": hi - lo, "steps": k4,
                 "us_per_step": round(wall4 / k4 * 1e6, 3), "evals_per_s": round(G * k4 / wall4, 1),
                 "kernel_us_rank0": round(ms4 * 1e3, 3), "scaling": "strong"}
         del r4
@@ -819,7 +929,7 @@ def main():
         gathered = group.exchange({"rank": rank, "device": device, "us_per_launch": mine["us_per_launch"],
                                    "achieved": mine["achieved"], "frac": mine["frac"]})
         if rank == 0:
-            out["roofline_per_gpu"] = gathered
+            out["roofline_per_gpu"] = {"n_ranks_seen": len(gathered), "gpus": gathered}
     # HBM-sized leg for the roofline (rank 0 only; the figure is per GPU)
     if rank == 0 and not args.no_roofline_leg:
         del run

@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from tests.conftest import REPO
 
@@ -95,3 +96,46 @@ def test_timing_plots_replica_settings_have_a_staged_reference_workload():
         assert os.path.isdir(os.path.join(REPO, "abr_control_amd", "arms", arm))
         want = "OSC(rc)" if not kw else "OSC(rc, ctrlr_dof=" + ("[True] * 6" if all(kw["ctrlr_dof"]) else "[True] * 5 + [False]") + ")"
         assert factory == want
+
+
+def _bench(*argv, timeout=120):
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *argv], capture_output=True, text=True,
+                          timeout=timeout, env=env, cwd=REPO)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher around it starts N ranks of itself, they meet through the HostGroup
+    (barrier, max, gather), and exactly ONE JSON line comes out of rank 0 (--dry-run: no device is touched)"""
+    p = _bench("--gpus", "4", "--steps", "20", "--warmup", "5", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 4 and d["n_ranks_seen"] == 4 and d["steps"] == 20 and d["warmup"] == 5
+    assert [r["rank"] for r in d["ranks"]] == [0, 1, 2, 3] == [r["local_rank"] for r in d["ranks"]]
+    assert len({r["pid"] for r in d["ranks"]}) == 4 and d["wall_max"] == 4e-3  # MAX over the ranks
+
+
+def test_bench_self_launch_fails_when_a_rank_fails():
+    """a rank that dies takes the run down: non-zero exit code, no contract line"""
+    p = _bench("--gpus", "3", "--dry-run", "--dry-run-fail-rank", "2")
+    assert p.returncode != 0
+    assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert "the run is void" in p.stderr
+
+
+def test_bench_self_launch_refuses_to_double_up_on_devices():
+    """fewer devices than ranks: ONE JSON error line with devices_seen, rc 1, nothing started (this container has no
+    device at all; on a one-GPU box the same line says devices_seen = 1)"""
+    import abr_control_amd as a
+
+    if a.device_count() >= 2:
+        pytest.skip("needs a machine with fewer than 2 HIP devices")
+    p = _bench("--gpus", "2", "--steps", "20", "--warmup", "5")
+    assert p.returncode == 1
+    d = json.loads(p.stdout.strip())
+    assert d["devices_seen"] == a.device_count() and d["n_gpus"] == 2 and "error" in d

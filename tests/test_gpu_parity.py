@@ -748,34 +748,47 @@ def test_gpu_six_row_first_pass_without_training_signal():
         assert np.max(np.abs(u_no - u_small) / scale) < 1e-13, kw
 
 
-def test_gpu_bench_two_ranks_share_one_device(tmp_path):
-    """the N > 1 launch contract on a one-GPU box (VERDICT r2 #5a): `torch.distributed.run --nproc-per-node 2 bench.py
-    --gpus 2` with both ranks on device 0 prints ONE contract line with n_gpus = 2, the strong-scaling leg cuts BASELINE
-    config 4's 2^20 rows into two contiguous shards, and each rank's shard of u is bit-equal to the same rows of the
-    unsharded call"""
+@pytest.mark.parametrize("launcher", ["self", "external"])
+def test_gpu_bench_two_ranks_share_one_device(tmp_path, launcher):
+    """the N > 1 launch contract on a one-GPU box: plain `python bench.py --gpus 2` (the command launches its own ranks;
+    VERDICT r4 #1) and the same command under an external one-process-per-GPU launcher (`torch.distributed.run`), both
+    ranks on device 0 behind the explicit --allow-shared-device test flag: ONE contract line with n_gpus = 2, the
+    strong-scaling leg cuts BASELINE config 4's 2^20 rows into two contiguous shards, and each rank's shard of u is
+    bit-equal to the same rows of the unsharded call.  Without the flag the run refuses to double up."""
     import hashlib
     import json
     import subprocess
     import sys
 
+    import abr_control_amd as a
     from tests.conftest import REPO
 
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "100",
-           "--warmup", "10", "--roofline-batch", "262144", "--roofline-steps", "5", "--sustain-seconds", "0.2",
-           "--dump-shard-u", str(tmp_path)]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    bench_args = ["--gpus", "2", "--steps", "100", "--warmup", "10", "--roofline-batch", "262144", "--roofline-steps",
+                  "5", "--sustain-seconds", "0.2", "--dump-shard-u", str(tmp_path)]
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(REPO, "bench.py")] + bench_args
+        if a.device_count() < 2:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+            assert p.returncode == 1 and json.loads(p.stdout.strip())["devices_seen"] == a.device_count()
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", "29533", os.path.join(REPO, "bench.py")] + bench_args
+    p = subprocess.run(cmd + ["--allow-shared-device"], capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 100 and d["value"] > 1e6
+    assert d["n_ranks_seen"] == 2 and [r["rank"] for r in d["ranks"]] == [0, 1]
+    assert d["shared_device"] == (a.device_count() < 2)
     assert d["config"]["global_batch"] == 2 * 4096 and "cpu_baseline" not in d
     s4 = d["strong_scaling_cfg4"]
     assert s4["n_gpus"] == 2 and s4["rows_per_gpu"] == 1 << 19 and s4["global_batch"] == 1 << 20 and s4["scaling"] == "strong"
+    assert s4["n_ranks_seen"] == 2
     per = d["roofline_per_gpu"]
-    assert [g["rank"] for g in per] == [0, 1] and all(0 < g["frac"] < 1 for g in per)
+    assert per["n_ranks_seen"] == 2 and [g["rank"] for g in per["gpus"]] == [0, 1] and all(0 < g["frac"] < 1 for g in per["gpus"])
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["sustained"]["seconds"] >= 0.15  # (the run is sized from a 5-launch estimate: about the 0.2 s asked for)
     # the shards: rows [0, 2^19) and [2^19, 2^20) of the one seeded global batch, against the unsharded call
     import bench
