@@ -26,7 +26,8 @@ WANT_T = 1 << 7
 WANT_TINV = 1 << 8
 WANT_QUAT = 1 << 9
 
-ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ENOARM", -5: "EFRAME"}
+ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ENOARM", -5: "EFRAME", -6: "ESINGULAR"}
+ESINGULAR = -6
 
 
 class ArmDesc(C.Structure):

@@ -115,7 +115,14 @@ def lib():
     return _lib
 
 
+class SingularMatrixError(AbrkError, np.linalg.LinAlgError):
+    """ABRK_ESINGULAR: a row's joint-space inertia matrix is not positive definite.  Also a numpy.linalg.LinAlgError -
+    what the reference's `np.linalg.inv(M)` raises at controllers/osc.py:136 - so `except LinAlgError` keeps working."""
+
+
 def check(rc):
+    if rc == _abi.ESINGULAR:
+        raise SingularMatrixError(rc, lib().abrk_last_error().decode())
     if rc < 0:
         raise AbrkError(rc, lib().abrk_last_error().decode())
     return rc

@@ -6,13 +6,6 @@
 #pragma once
 #include "abrk_device.h"
 
-#ifndef ABRK_PINV_FAST_MINK
-#define ABRK_PINV_FAST_MINK 1
-#endif
-#ifndef ABRK_C_TWO_PASS
-#define ABRK_C_TWO_PASS 1
-#endif
-
 namespace abrk {
 
 // ---------------------------------------------------------------- device-side parameter blocks
@@ -40,7 +33,25 @@ struct OscP {
   int ref_frame, m_joints, has_off;
   int n_null;
   NullP<T> nul[4];
+  // where a row whose joint-space inertia matrix has a non-positive Cholesky pivot raises the flag (the reference's
+  // numpy.linalg.inv(M) raises LinAlgError there, osc.py:136): a host-visible word the host layer reads after the stream
+  // is drained and reports as ABRK_ESINGULAR; nullptr = nobody listens
+  int* status;
 };
+// (a plain store of 1 by however many rows: benign race, rare branch).  A non-finite M - NaN / Inf joint angles - is not
+// "singular": numpy.linalg.inv returns NaNs for it without raising, and so do the kernels.  The test reads the bit
+// pattern of the entries' sum (non-finite as soon as one entry is): -ffinite-math-only leaves integer compares alone.
+template <int N, class T>
+ABRK_INL void flag_singular(const OscP<T>& P, bool ok, const T (&Ms)[N * (N + 1) / 2]) {
+  if (!ok && P.status) {
+    T sum = Ms[0];
+    sfor<N*(N + 1) / 2 - 1>([&](auto e) ABRK_LAMBDA { sum += Ms[e() + 1]; });
+    bool finite;
+    if constexpr (sizeof(T) == 8) finite = ((__builtin_bit_cast(unsigned long long, sum) >> 52) & 0x7ffull) != 0x7ffull;
+    else finite = ((__builtin_bit_cast(unsigned, sum) >> 23) & 0xffu) != 0xffu;
+    if (finite) *P.status = 1;
+  }
+}
 
 template <class T>
 struct SlidingP {
@@ -300,9 +311,6 @@ ABRK_INL void jacobi_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
 // Accuracy: backward stable - eigenvalues to a few eps |A|, eigenvectors orthonormal to a few eps (jacobi_eig's
 // RELATIVE accuracy on tiny eigenvalues is not needed by its callers: eigenvalues below rcond * max are dropped, the
 // kept ones are at least 1e-4 |A|).
-#ifndef ABRK_QL_BRANCHFREE
-#define ABRK_QL_BRANCHFREE 1
-#endif
 // a condition that holds on every lane of the wavefront alike (the wave-cooperative second pass: all lanes carry the
 // same matrix): as a scalar, so that the branch on it is a scalar branch
 ABRK_INL bool uni(bool c) {
@@ -451,7 +459,6 @@ ABRK_INL bool ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K])
           // one matrix per wavefront: the slots that exist, behind scalar compares (QlChain)
           QlChain<K, T, NR, l, K - 2>::run(d, e, V, m, sn, cs, pp, g, bad);
         } else {
-#if ABRK_QL_BRANCHFREE
         // Every slot K-2 .. l is executed by every lane, inactive ones (i >= m, or after a stop) as the identity
         // rotation: the pass is ONE basic block, so the six independent eigenvector updates of a slot overlap with the
         // next slot's scalar recurrence (a lone lane is latency-bound: with a branch per slot nothing overlapped)
@@ -482,34 +489,6 @@ ABRK_INL bool ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K])
             V[kk()][i] = Rm<T>::fma(ce, V[kk()][i], -(se * fz));
           });
         });
-#else
-        sfor<K - 1 - l>([&](auto ii) ABRK_LAMBDA {
-          constexpr int i = K - 2 - ii();  // K-2 .. l
-          if (i < m && !stop) {
-            const T f = sn * e[i], b = cs * e[i];
-            const T r2 = Rm<T>::fma(f, f, g * g);
-            if (!(r2 > T(0))) {
-              d[i + 1] -= pp;
-              stop = true;
-            } else {
-              const T ir = Rm<T>::rsqrt(r2), r = r2 * ir;
-              e[i + 1] = r;
-              sn = f * ir;
-              cs = g * ir;
-              g = d[i + 1] - pp;
-              const T rr = Rm<T>::fma(d[i] - g, sn, T(2) * cs * b);
-              pp = sn * rr;
-              d[i + 1] = g + pp;
-              g = Rm<T>::fma(cs, rr, -b);
-              sfor<NR>([&](auto kk) ABRK_LAMBDA {
-                const T fz = V[kk()][i + 1];
-                V[kk()][i + 1] = Rm<T>::fma(sn, V[kk()][i], cs * fz);
-                V[kk()][i] = Rm<T>::fma(cs, V[kk()][i], -(sn * fz));
-              });
-            }
-          }
-        });
-#endif
         }
         // e[m] = 0 in either case (as value selects: an `if (m == j) e[j] = 0` chain becomes ONE store through a
         // selected pointer, which sends e[] to scratch memory)
@@ -533,13 +512,10 @@ ABRK_INL void ql_eig(const T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
   ql_core<K, T, K, true, false>(S, V, lam);
 }
 
-#ifndef ABRK_EIG_QL
-#define ABRK_EIG_QL 1  // 0: cyclic Jacobi for every size (rounds 1-2)
-#endif
 // eigen-decomposition behind a truncating pinv: Jacobi up to 3 x 3 (one / three rotation pairs), QL above
 template <int K, class T>
 ABRK_INL void sym_eig(T (&S)[K * (K + 1) / 2], T (&V)[K][K], T (&lam)[K]) {
-  if constexpr (K >= 4 && (ABRK_EIG_QL != 0)) ql_eig<K>(S, V, lam);
+  if constexpr (K >= 4) ql_eig<K>(S, V, lam);  // (cyclic Jacobi for every size: rounds 1-2)
   else jacobi_eig<K>(S, V, lam);
 }
 
@@ -622,7 +598,7 @@ ABRK_INL void sym3_eig(const T (&S)[6], T (&V)[3][3], T (&lam)[3]) {
 // values keep their relative accuracy, which an eigen-decomposition of J J^T would lose.
 template <int K, int N, class T>
 ABRK_INL void pinv_KxN(const T (&J)[N][K] /* J[i][r] = J(r,i) */, T rcond, T (&P)[N][K] /* P[i][r] */) {
-  if constexpr (K <= N && K >= ABRK_PINV_FAST_MINK) {
+  if constexpr (K <= N) {
     // Well-conditioned full row rank (the common case along an IK path or a sliding-mode step): pinv(J) =
     // J^T (J J^T)^-1 through a K x K Cholesky factor.  cond(J J^T) <= trace^K / det; below 1e6 (fp32: 1e2) the
     // squared conditioning costs at most ~1e-10 (1e-5) relative and nothing is truncated at rcond = 1e-15.
@@ -908,9 +884,6 @@ ABRK_INL void opaque(T& x) {
 #endif
 }
 
-#ifndef ABRK_SMALL_INVERSE
-#define ABRK_SMALL_INVERSE 1  // measurement switch: 0 = the three-row law's Mx through a Cholesky factor (rounds 1-2)
-#endif
 // ---------------------------------------------------------------- OSC.generate, one row
 // KM = 3 or 2 (FAST: task rows are exactly x,y,z / x,y of the EE) or 6 (all six task rows, unselected
 // rows masked: their Jacobian row is zeroed and Mx_inv gets a unit diagonal there, which
@@ -941,7 +914,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   ABRK_MARK("law3:chol_M");
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T through the Cholesky factor of M
   T L[N * (N + 1) / 2], il[N];
-  chol<N, T, false>(Ms, L, il);
+  flag_singular<N>(P, chol<N, T, false>(Ms, L, il), Ms);
   ABRK_MARK("law3:Y");
   T Y[N][KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA {
@@ -967,7 +940,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   // x,y,z / x,y: Mx by cofactors (spd_inverse_small); otherwise through the Cholesky factor of Mx_inv
   // (fp64 only: the cofactors carry a relative error of eps * trace^K / det - see below -, which single precision
   //  cannot afford on the everyday rows)
-  constexpr bool kClosed = FAST && (ABRK_SMALL_INVERSE != 0) && sizeof(T) == 8;
+  constexpr bool kClosed = FAST && sizeof(T) == 8;
   bool okA;
   T det = T(1);
   if constexpr (kClosed) {
@@ -1222,21 +1195,62 @@ ABRK_INL void osc6_rec_transform(const T* __restrict__ rec, int col, T (&G)[NV][
   osc6_rec_load<N, T, NV>(rec, col, S, G);
   osc6_rec_solve<N, T, NV, UNI>(rec, col, S, G, wv);
 }
-// the whole second pass of one row on one lane (host check build; the GPU spreads the columns over lanes)
+// The truncating pseudo-inverse and the tail of the six-row law on ONE lane, from the values a hand-over record holds:
+// S = Mx_inv (masked rows as isolated zeros), G[c] = column c of [J | u_task | J v], the two joint-space sums b1, b2.
+// ONE routine for every place a row can meet it - the finish kernel's one-record-per-lane form (from a record), the
+// complete row program (from its registers: batches below one wavefront of rows, the recompute pass of large batches,
+// sharded and fused-output calls) - so that a row's bits do not depend on the batch it arrives in; the finish
+// kernel's wave-cooperative form is the same arithmetic with the columns spread over lanes (contraction pinned off).
 template <int N, class T>
-ABRK_INL void osc6_finish_row(const T* __restrict__ rec, bool nulls, T (&u)[N], T (&ts)[N]) {
+ABRK_INL void osc6_tail(const T (&S)[21], T (&G)[N + 2][6], const T (&b1)[N], const T (&b2)[N], bool nulls, T (&u)[N],
+                        T (&ts)[N]) {
 #pragma clang fp contract(off)  // the same bits as the wave-cooperative form (abrk_kernels.h osc6_finish_kernel)
-  T G[N + 2][6], wv[6];
-  osc6_rec_transform<N, T, N + 2, false>(rec, 0, G, wv);
+  T lam[6], wv[6];
+  ql_core<6, T, N + 2, false, false>(S, G, lam);
+  pinv_weights<6>(lam, T(1e-3) * T(0.1), wv);
   sfor<N>([&](auto c) ABRK_LAMBDA {
     T a1 = T(-0.0), a2 = T(-0.0);
     sfor<6>([&](auto i) ABRK_LAMBDA {
       a1 = Rm<T>::fma(G[c()][i()], wv[i()] * G[N][i()], a1);
       a2 = Rm<T>::fma(G[c()][i()], wv[i()] * G[N + 1][i()], a2);
     });
-    ts[c()] = rec[rec_off_b1(N) + c()] - a1;
-    u[c()] = ts[c()] + rec[rec_off_b1(N) + N + c()] - (nulls ? a2 : T(0));
+    ts[c()] = b1[c()] - a1;
+    u[c()] = ts[c()] + b2[c()] - (nulls ? a2 : T(0));
   });
+}
+// the whole second pass of one row on one lane, from its record
+template <int N, class T>
+ABRK_INL void osc6_finish_row(const T* __restrict__ rec, bool nulls, T (&u)[N], T (&ts)[N]) {
+  T S[21], G[N + 2][6], b1[N], b2[N];
+  osc6_rec_load<N, T, N + 2>(rec, 0, S, G);
+  sfor<N>([&](auto c) ABRK_LAMBDA {
+    b1[c()] = rec[rec_off_b1(N) + c()];
+    b2[c()] = rec[rec_off_b1(N) + N + c()];
+  });
+  osc6_tail<N, T>(S, G, b1, b2, nulls, u, ts);
+}
+// What a deferring row hands over besides Mx_inv and its Jacobian rows - (J v)[r] of the secondary controllers and the two
+// joint-space sums around J^T f - with contraction pinned off: the first pass (into the record) and the complete row
+// program (into registers) are different instantiations and must arrive at the same bits.
+template <int N, class T>
+ABRK_INL T osc6_jv(const T (&row)[N], const T (&v)[N]) {
+#pragma clang fp contract(off)
+  T jv = T(-0.0);
+  sfor<N>([&](auto i) ABRK_LAMBDA { jv += row[i()] * v[i()]; });
+  return jv;
+}
+template <int N, bool USE_C, bool NOTS, class T, int NU>
+ABRK_INL void osc6_sums(const OscP<T>& P, T gscale, const T (&gz)[N], const T (&u0)[N], const T (&cvec)[N], bool nulls,
+                        const T (&un)[NU], T (&b1)[N], T (&b2)[N]) {
+#pragma clang fp contract(off)
+  const T gsc = (!NOTS && P.use_g) ? gscale : T(0);
+  sfor<N>([&](auto i) ABRK_LAMBDA {
+    b1[i()] = USE_C ? u0[i()] - cvec[i()] : u0[i()];
+    b2[i()] = gsc * gz[i()];
+  });
+  if constexpr (NU == N) {
+    if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { b2[i()] += un[i()]; });
+  }
 }
 
 // ---- the same law for all six task rows (any ctrlr_dof, ref_frame, orientation control), restructured around its
@@ -1251,22 +1265,15 @@ ABRK_INL void osc6_finish_row(const T* __restrict__ rec, bool nulls, T (&u)[N], 
 //   * Y is held three rows at a time: Mx_inv = Y Y^T in two row blocks of three (+3 forward solves, -18 live values).
 // Same arithmetic per entry as osc_law (Gram form of Mx_inv, Cholesky, the two certificates, Jacobi behind them);
 // only the order of independent steps differs.  Two waves per SIMD on the six-joint arms.
-#ifndef ABRK_LAW6_YB
-#define ABRK_LAW6_YB 3  // rows of Y held at a time (2 was measured: 12 instead of 9 solves cost more than 16 B of scratch)
-#endif
+constexpr int kLaw6Yb = 3;  // rows of Y held at a time (2 was measured: 12 instead of 9 solves cost more than 16 B of scratch)
 // ... in the first pass (compiled without the eigen-decomposition: 202 - 210 registers on the UR5, room to spare under the
 // 256 of two waves per SIMD) all six rows at once: 6 forward solves instead of 9, 224 - 246 registers, still no scratch.
 // Same box, 8 M UR5 rows: 762 / 763 us against 786 / 794 us with three rows (and 815 / 817 with two); the 4096-row step
 // 16.9 - 17.0 against 17.1 - 17.4 us.
-#ifndef ABRK_LAW6_YB_FIRST
-#define ABRK_LAW6_YB_FIRST 6
-#endif
+constexpr int kLaw6YbFirst = 6;
 // rows of the task Jacobian read from the row store one AHEAD of their use (first pass: Y and J^T f).  Same box, three
 // interleaved repetitions: the 4096-row step 16.65 / 16.71 / 16.75 us against 17.09 / 16.94 / 16.95; 8 M rows 766.9 / 767.1 /
 // 770.8 against 769.9 / 769.8 / 771.7 us; no register more (224 - 248).
-#ifndef ABRK_LAW6_PREFETCH
-#define ABRK_LAW6_PREFETCH 1
-#endif
 template <int N, class T, bool USE_C, int FEAT, class Rows, int QSTEPS = 3>
 ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
                        const T (&cvec)[N], Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
@@ -1368,7 +1375,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   ABRK_MARK("law6:chol_M");
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T = Y Y^T, Y = J L^-T (rows y_r = L^-1 j_r)
   T L[N * (N + 1) / 2], il[N];
-  chol<N, T, false>(Ms, L, il);
+  flag_singular<N>(P, chol<N, T, false>(Ms, L, il), Ms);
   if constexpr (FEAT >= 2) {
     if (have_ext) {  // caller-evaluated u_null: v_ext = M^-1 u_ext
       T y[N], w[N];
@@ -1397,12 +1404,12 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     // more row at a time (recomputed when its own block comes up).  Three rows per block cost 9 forward solves for the
     // six rows, two rows 12 (measured with the training signal among the outputs, where u0 AND the gravity sums stay
     // live across the law: 957 us against 937 us at 8 M UR5 rows - the 16 B of scratch it saves do not pay for 3 solves)
-    constexpr int YB = Rows::kDeferOnly ? ABRK_LAW6_YB_FIRST : ABRK_LAW6_YB;
+    constexpr int YB = Rows::kDeferOnly ? kLaw6YbFirst : kLaw6Yb;
     static_assert(KM % YB == 0, "block size divides the six rows");
     sfor<KM / YB>([&](auto bi) ABRK_LAMBDA {
       constexpr int r0 = bi() * YB;
       T Ya[YB][N];
-      if constexpr (YB == KM && (ABRK_LAW6_PREFETCH != 0)) {
+      if constexpr (YB == KM) {
         // the row store is read one row AHEAD of the forward solve that consumes it: at small batches one wavefront
         // per SIMD has nothing else to hide the LDS round trip behind (12 more registers: the first pass has them)
         T rb[2][N];
@@ -1437,7 +1444,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   bool okA = chol<KM, T, false>(Am, LA, ila);
   T det = T(1);
   sfor<KM>([&](auto r) ABRK_LAMBDA { det *= LA[tri(r(), r())] * LA[tri(r(), r())]; });
-  bool mx_explicit = FEAT != 0, f_ready = false;
+  bool mx_explicit = FEAT != 0;
   T f[KM], f2[FEAT >= 1 ? KM : 1];
   // (only where the factor exists: after a non-positive pivot LA / ila hold non-finite values, which -ffinite-math-only
   //  makes unspecified to compute with; every reader of Mx below sits behind okA or overwrites it)
@@ -1507,72 +1514,51 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
           T jv = T(-0.0);
           sfor<N>([&](auto i) ABRK_LAMBDA { xr[i()] = row[i()]; });
           if constexpr (FEAT >= 1) {
-            if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { jv += row[i()] * v[i()]; });
+            if (nulls) jv = osc6_jv<N>(row, v);
           }
           xr[N] = uts[r()];
           xr[N + 1] = jv;
           if constexpr (XS > N + 2) xr[XS - 1] = T(0);
           store_pairs<XS>(rec + rec_off_x() + r() * XS, xr);
         });
-        T bb[2 * N];
-        const T gsc = (!Rows::kNoTs && P.use_g) ? gscale : T(0);
+        T bb[2 * N], b1[N], b2[N];
+        osc6_sums<N, USE_C, Rows::kNoTs>(P, gscale, gz, u0, cvec, nulls, un, b1, b2);
         sfor<N>([&](auto i) ABRK_LAMBDA {
-          bb[i()] = USE_C ? u0[i()] - cvec[i()] : u0[i()];
-          bb[N + i()] = gsc * gz[i()];
+          bb[i()] = b1[i()];
+          bb[N + i()] = b2[i()];
         });
-        if constexpr (FEAT >= 1) {
-          if (nulls) sfor<N>([&](auto i) ABRK_LAMBDA { bb[N + i()] += un[i()]; });
-        }
         store_pairs<2 * N>(rec + rec_off_b1(N), bb);
       }
       return;
     }
     if constexpr (!Rows::kDeferOnly) if (truncates) {
-      T S[KM * (KM + 1) / 2], V[KM][KM], lam[KM];
+      // the truncating pseudo-inverse, here and now: exactly what a hand-over record would carry, into osc6_tail - the
+      // routine the finish kernel runs on records - so that this row's bits are those of every other form of the law.
+      // (A masked row is an isolated diagonal entry: with 0 there its eigenpair is (0, e_r) - below every cut-off, so it
+      //  drops out of the pseudo-inverse whatever position the solver leaves it in.)
+      T S[KM * (KM + 1) / 2], G[N + 2][6], b1[N], b2[N];
       sfor<KM*(KM + 1) / 2>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
-      // a masked row is an isolated diagonal entry: with 0 there its eigenpair is (0, e_r) - below every cut-off, so it
-      // drops out of the pseudo-inverse whatever position the solver leaves it in (ql_eig orders nothing)
-      sfor<KM>([&](auto r) ABRK_LAMBDA { S[tri(r(), r())] = sel[r()] ? S[tri(r(), r())] : T(0); });
-      sym_eig<KM>(S, V, lam);
-      T smax = T(0);
-      sfor<KM>([&](auto r) ABRK_LAMBDA { smax = Rm<T>::fmax(smax, Rm<T>::fabs(lam[r()])); });
-      T cut = rcond * smax;
-      T wv[KM];
+      sfor<KM>([&](auto r) ABRK_LAMBDA { S[tri(r(), r())] = sel[r()] ? Am[tri(r(), r())] : T(0); });
       sfor<KM>([&](auto r) ABRK_LAMBDA {
-        const bool keep = Rm<T>::fabs(lam[r()]) > cut;
-        wv[r()] = keep ? rcp(keep ? lam[r()] : T(1)) : T(0);
+        T row[N];
+        js.get_row(r, row);
+        T jv = T(-0.0);
+        if constexpr (FEAT >= 1) {
+          if (nulls) jv = osc6_jv<N>(row, v);
+        }
+        sfor<N>([&](auto i) ABRK_LAMBDA { G[i()][r()] = row[i()]; });
+        G[N][r()] = uts[r()];
+        G[N + 1][r()] = jv;
       });
-      if constexpr (FEAT == 0) {
-        // Mx is applied once: f = V W V^T u_task without forming V W V^T (78 instead of 288 multiply-adds)
-        T tv[KM];
-        sfor<KM>([&](auto r) ABRK_LAMBDA {
-          T acc = T(-0.0);
-          sfor<KM>([&](auto a) ABRK_LAMBDA { acc = Rm<T>::fma(V[a()][r()], uts[a()], acc); });
-          tv[r()] = acc * wv[r()];
-        });
-        sfor<KM>([&](auto a) ABRK_LAMBDA {
-          T acc = T(-0.0);
-          sfor<KM>([&](auto r) ABRK_LAMBDA { acc = Rm<T>::fma(V[a()][r()], tv[r()], acc); });
-          f[a()] = acc;
-        });
-        f_ready = true;
-      } else {
-        sfor<KM>([&](auto a) ABRK_LAMBDA {
-          sfor<a() + 1>([&](auto b) ABRK_LAMBDA {
-            T acc = T(-0.0);
-            sfor<KM>([&](auto r) ABRK_LAMBDA { acc += V[a()][r()] * V[b()][r()] * wv[r()]; });
-            Mx[tri(a(), b())] = acc;
-          });
-        });
-        mx_explicit = true;
-      }
+      osc6_sums<N, USE_C, Rows::kNoTs>(P, gscale, gz, u0, cvec, nulls, un, b1, b2);
+      osc6_tail<N, T>(S, G, b1, b2, nulls, u, ts);
+      return;
     }
   }
 
   ABRK_MARK("law6:f");
   // f = Mx u_task[ctrlr_dof] (osc.py:285-288); f2 = Mx (J v) for the null-space filter
-  if (f_ready) {
-  } else if (mx_explicit) {
+  if (mx_explicit) {
     symv<KM>(Mx, uts, f);
   } else {
     T y[KM];
@@ -1597,7 +1583,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   T a1[N], a2[FEAT >= 1 ? N : 1];
   sfor<N>([&](auto i) ABRK_LAMBDA { a1[i()] = T(-0.0); });
   if constexpr (FEAT >= 1) sfor<N>([&](auto i) ABRK_LAMBDA { a2[i()] = T(-0.0); });
-  if constexpr (Rows::kDeferOnly && (ABRK_LAW6_PREFETCH != 0)) {
+  if constexpr (Rows::kDeferOnly) {
     T rb[2][N];
     js.get_row(ic<0>{}, rb[0]);
     sfor<KM>([&](auto r) ABRK_LAMBDA {
@@ -1653,12 +1639,12 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
                       Emit&& emit = Emit{}, EmitPre&& emit_pre = EmitPre{}) {
   constexpr int N = A::N;
   constexpr bool FAST = (KM <= 3);
-  // OSC(use_C) on orthogonal chains (ABRK_C_TWO_PASS): the Coriolis vector rides on the dynamics pass.  The link
+  // OSC(use_C) on orthogonal chains (the two-pass form): the Coriolis vector rides on the dynamics pass.  The link
   // visitor of the forward kinematics also advances a body recursion (rne_forward_step) and parks each link's wrench
   // in `scr` - LDS on the GPU, so the 12 N registers they would take stay free and the kernel keeps two waves per
   // SIMD -; one backward sweep (rne_backward) then projects the sums onto the joint axes.  (Until round 2 the
   // recursion ran as a pass of its own with a second forward kinematics: +128 instructions per row.)
-  constexpr bool TWO_PASS = USE_C && !MAT && A::kOrtho && (ABRK_C_TWO_PASS != 0);
+  constexpr bool TWO_PASS = USE_C && !MAT && A::kOrtho;
   // the frame rotation of an orthogonal chain is a product of exact rotations: one power step in quat_from_R
   constexpr int kQSteps = A::kOrthoFrames ? 1 : 3;
   Joints<A, T> jt;
@@ -1733,6 +1719,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     emit(p, Jv, Jw, d, jt, m);
     ABRK_SCHED_FENCE();
     late();
+    ABRK_STAMP(scr, 3, false);  // (timeline build) kinematics, dynamics, Coriolis sweep and Jacobian done
     if constexpr (MAT && USE_C)
       osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cvm, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
                                     ierr, have_ext, une, u, ts, scr.defer_ptr());

@@ -45,15 +45,33 @@
 #else
 #define ABRK_MARK(name) ((void)0)
 #endif
+// development aid: -DABRK_TIMELINE stamps a wavefront's progress with the constant-rate counter (s_memrealtime, 100 MHz)
+// at a handful of points of the x,y,z OSC kernel (entry, table barrier, inputs landed, dynamics done, law done, stores
+// issued, stores complete); the stamps ride in scalar registers of the row's scratch object and leave through the
+// kernel's (otherwise unused) worklist pointer.  tools/microbench/shard_step_timeline.hip is the one user; the product
+// library is never built with it.
+#if defined(ABRK_TIMELINE) && defined(__HIP_DEVICE_COMPILE__)
+#if defined(ABRK_TIMELINE_LIGHT)  // no forced waits: how much do the stamps themselves cost?
+#define ABRK_STAMP_WAITS 0
+#else
+#define ABRK_STAMP_WAITS 1
+#endif
+#define ABRK_STAMP(scr, id, wait)                                   \
+  do {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                              \
+    if ((wait) && ABRK_STAMP_WAITS) __builtin_amdgcn_s_waitcnt(0);  \
+    (scr).tl[id] = __builtin_amdgcn_s_memrealtime();                \
+    __builtin_amdgcn_sched_barrier(0);                              \
+  } while (0)
+#else
+#define ABRK_STAMP(scr, id, wait) ((void)0)
+#endif
 // Inside a block guarded by a condition that is UNIFORM over the launch (a controller parameter): keeps the block a real
 // branch.  Left alone the compiler if-converts such blocks into vector selects - two v_cndmask per double, each as
 // expensive as an FMA on gfx950 (tools/microbench/valu_rates.hip) - or, asked for 0 / 1 factors instead, parks the
 // factors in scalar registers across the six-row kernel's persistent loop, which runs out of them (v_readlane per use).
 // A scalar branch costs the vector pipeline nothing.
 #define ABRK_UNIFORM_BLOCK() asm volatile("")
-#ifndef ABRK_SINCOS_AHEAD
-#define ABRK_SINCOS_AHEAD 1
-#endif
 
 namespace abrk {
 
@@ -925,6 +943,9 @@ struct ScratchBase {
   // pass's 256-register budget was short of (it spilled them: 86 B per row of scratch writes, PMC)
   static constexpr bool kNoTs = false;
   bool allow_defer = false, deferred = false;
+#if defined(ABRK_TIMELINE)
+  unsigned long long tl[8] = {};
+#endif
   ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
   // where a deferring row parks itself (set by the kernel; the host check build passes plain arrays).
   //   hand-over mode (rec_base != nullptr; batches up to 262144 rows): the row leaves a record (record() below) - no
@@ -1133,7 +1154,7 @@ ABRK_INL void kin_dyn_hook(const A& arm, const T (&q)[A::N], const T (&dq)[A::N]
     T sv[A::N][2];
     sincos_all_tab<A::N>(q, sv, scp.tab);
     fk_forward(arm, q, jt, XR, xo, cap, visit, ScUse<T, A::N>{sv});
-  } else if constexpr (std::is_same<Sc, ScCompute>::value && ABRK_SINCOS_AHEAD) {
+  } else if constexpr (std::is_same<Sc, ScCompute>::value) {
     T sv[A::N][2];
     sincos_all<A::N>(q, sv);
     fk_forward(arm, q, jt, XR, xo, cap, visit, ScUse<T, A::N>{sv});

@@ -263,6 +263,51 @@ static int use_device(int device) {
   return 0;
 }
 
+// ---- the "M is not positive definite" flag (ABRK_ESINGULAR; the reference raises LinAlgError at osc.py:136).  The OSC
+// kernels store 1 through OscP::status where a row's Cholesky factor of M meets a non-positive pivot.  The word lives
+// in pinned, device-mapped host memory, so reading it costs the host nothing once the stream is drained:
+//   * a call that hands over HOST arrays is synchronous - it uses the calling thread's own word and returns the code;
+//   * a call on DEVICE pointers is asynchronous - it uses its device's sticky word, which abrk_stream_sync reports once.
+struct StatusWord {
+  volatile int* host = nullptr;
+  int* dev = nullptr;
+  bool alloc() {
+    if (host) return true;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (h) (void)hipHostFree(h);
+      return false;
+    }
+    *(volatile int*)h = 0;
+    host = (volatile int*)h;
+    dev = (int*)d;
+    return true;
+  }
+  bool take() {  // -> was it raised?  (cleared)
+    if (!host || !*host) return false;
+    *host = 0;
+    return true;
+  }
+};
+static thread_local StatusWord t_status;
+static constexpr int kMaxStatusDevices = 64;
+static StatusWord g_dev_status[kMaxStatusDevices];
+static std::mutex g_status_mu;
+// the word a call's kernels report to (nullptr: the allocation failed - nobody listens, as before round 5)
+static StatusWord* status_word(bool synchronous, int device) {
+  if (synchronous) return t_status.alloc() ? &t_status : nullptr;
+  if (device < 0 || device >= kMaxStatusDevices) return nullptr;
+  std::lock_guard<std::mutex> lk(g_status_mu);
+  return g_dev_status[device].alloc() ? &g_dev_status[device] : nullptr;
+}
+static int singular_error() {
+  return fail(ABRK_ESINGULAR, "Singular matrix: the joint-space inertia matrix M of at least one row is not positive "
+                              "definite (numpy.linalg.inv(M) raises LinAlgError there, osc.py:136); the outputs of "
+                              "those rows are unspecified");
+}
+
 extern "C" int abrk_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -335,16 +380,18 @@ extern "C" int abrk_stream_sync(int device, void* stream) {
   if (int rc = use_device(device)) return rc;
   // ABRK_SYNC_SPIN=1 (measurement switch): poll the stream instead of blocking in hipStreamSynchronize - whether the
   // wake-up latency of the blocking wait shows in a 20-step replay (it does not: profiles/round3/launch_latency.txt)
-  static const bool spin = getenv("ABRK_SYNC_SPIN") != nullptr;
+  static const bool spin = measurement_env("ABRK_SYNC_SPIN") != nullptr;
   if (spin) {
     hipError_t e;
     while ((e = hipStreamQuery((hipStream_t)stream)) == hipErrorNotReady) {
     }
     (void)hipGetLastError();
     HIPCHK(e);
-    return 0;
+  } else {
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   }
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  // the device's sticky "M not positive definite" flag of asynchronous (device-pointer) OSC calls: reported once
+  if (device < kMaxStatusDevices && g_dev_status[device].take()) return singular_error();
   return 0;
 }
 extern "C" int abrk_device_sync(int device) {
@@ -553,10 +600,23 @@ const void* arm_table(const ArmEntry* a, int dtype) {
   return dtype == ABRK_F64 ? (const void*)a->rt64.data() : (const void*)a->rt32.data();
 }
 
+// A caller's grip on its (device, stream) scratch slot of the six-row kernels (worklist cache, below): the slot's mutex
+// AND a reference to the slot - a slot evicted or forgotten between the look-up and the lock stays alive (and simply
+// leaves the cache) until the last holder lets go.
+struct WorklistSlot;
+struct WlHold {
+  std::shared_ptr<WorklistSlot> slot;
+  std::unique_lock<std::mutex> lk;
+  void release() {
+    if (lk.owns_lock()) lk.unlock();
+    slot.reset();
+  }
+};
+
 // enqueue now (and finish the staging), or keep the launch for the plan being recorded.  fn(arm_rt) launches the
 // kernel; it captures its arguments by value.
 template <class F>
-int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn, std::unique_lock<std::mutex>* held = nullptr) {
+int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn, WlHold* held = nullptr) {
   if (Recorder* r = t_rec) {
     if (st.staged) return fail(ABRK_EINVAL, "plans take device pointers only (got a host pointer)");
     if (st.device != r->device || st.stream != r->stream)
@@ -570,7 +630,7 @@ int dispatch(Stager& st, const ArmEntry* a, int dtype, F&& fn, std::unique_lock<
     return 0;
   }
   const hipError_t le = fn(arm_table(a, dtype));
-  if (held && held->owns_lock()) held->unlock();  // everything that uses the shared scratch is enqueued
+  if (held) held->release();  // everything that uses the shared scratch is enqueued
   HIPCHK(le);
   return st.finish();
 }
@@ -596,10 +656,13 @@ struct WorklistSlot {
   void* rec = nullptr;     // hand-over records
   size_t rec_cap = 0;      // bytes
   uint64_t last_use = 0;
+  bool retired = false;    // left the cache (evicted / its stream destroyed): buffers released, never handed out again
   std::mutex mu;
 };
 std::mutex g_wl_mu;
-std::vector<std::unique_ptr<WorklistSlot>> g_wl_cache;
+// shared ownership: a caller copies the pointer under g_wl_mu and locks the slot afterwards - an eviction or
+// abrk_stream_destroy in that window removes the slot from the cache but cannot free the mutex under the caller
+std::vector<std::shared_ptr<WorklistSlot>> g_wl_cache;
 uint64_t g_wl_clock = 0;
 std::atomic<int64_t> g_wl_inline_fallbacks{0}, g_wl_evictions{0};
 // batches up to here take the hand-over form of the six-row law (kHandoverMaxRows is what the finish kernel can scan).
@@ -612,7 +675,7 @@ constexpr size_t kWlCacheSlots = 64;
 // batches up to kHandoverRows (below) hand the deferred rows' intermediate results over to the second pass (43 MB of
 // records for a six-joint arm in fp64); beyond, the second pass recomputes its rows
 
-void wl_release(WorklistSlot& s) {  // caller holds s.mu (or owns the slot exclusively); the slot's stream is drained
+void wl_release(WorklistSlot& s) {  // caller holds s.mu; the slot's stream is drained
   (void)hipSetDevice(s.device);
   if (s.buf) (void)hipFree(s.buf);
   if (s.rec) (void)hipFree(s.rec);
@@ -620,10 +683,21 @@ void wl_release(WorklistSlot& s) {  // caller holds s.mu (or owns the slot exclu
   s.rec = nullptr;
   s.cap = s.rec_cap = 0;
 }
+// a slot that left the cache: wait for whoever is enqueueing on it, drain its stream if that still exists, free
+void wl_retire(const std::shared_ptr<WorklistSlot>& s, bool stream_alive) {
+  std::lock_guard<std::mutex> sl(s->mu);
+  s->retired = true;
+  if (stream_alive) {
+    (void)hipSetDevice(s->device);
+    (void)hipStreamSynchronize(s->stream);
+    (void)hipGetLastError();
+  }
+  wl_release(*s);
+}
 // abrk_stream_destroy: the stream's slot leaves the cache (its launches are drained by the caller's hipStreamDestroy,
 // which waits for the stream's work; the buffers are freed after an explicit drain here)
 void wl_forget_stream(int device, hipStream_t stream) {
-  std::unique_ptr<WorklistSlot> mine;
+  std::shared_ptr<WorklistSlot> mine;
   {
     std::lock_guard<std::mutex> lk(g_wl_mu);
     for (size_t i = 0; i < g_wl_cache.size(); i++)
@@ -633,26 +707,42 @@ void wl_forget_stream(int device, hipStream_t stream) {
         break;
       }
   }
-  if (!mine) return;
-  std::lock_guard<std::mutex> sl(mine->mu);  // a caller that found the slot just before may still be enqueueing
-  (void)hipStreamSynchronize(stream);
-  wl_release(*mine);
+  if (mine) wl_retire(mine, true);  // (a caller that found the slot just before may still be enqueueing: s->mu)
 }
 bool handover_enabled() {
-  static const bool off = getenv("ABRK_NO_HANDOVER") != nullptr;  // measurement switch: the round-3 scheme
+  static const bool off = measurement_env("ABRK_NO_HANDOVER") != nullptr;  // measurement switch: the round-3 scheme
   return !off;
+}
+// one of the slot's two buffers grown to `need` bytes (+ 25 %); the other one is left alone.  The slot's stream is
+// drained first if the old buffer may still be in use (every earlier user enqueued under s->mu).  false: no memory
+bool wl_grow(hipStream_t stream, void** buf, size_t* cap, size_t need, bool* drained) {
+  if (*cap >= need) return true;
+  if (*buf) {
+    if (!*drained) (void)hipStreamSynchronize(stream);
+    *drained = true;
+    (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, need + need / 4) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  *buf = p;
+  *cap = need + need / 4;
+  return true;
 }
 // -> 0 and *wl = the worklist (nullptr: run the sweeps inline), *rec = the record store (nullptr: recompute form), or
 // an error code.  n / dtype: the arm's joint count and the arithmetic type (record size).
-int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, int** wl, void** rec,
-                 std::unique_lock<std::mutex>& hold) {
+int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, int** wl, void** rec, WlHold& hold) {
   *wl = nullptr;
   *rec = nullptr;
-  static const bool off = getenv("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
+  static const bool off = measurement_env("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
   // (row indices are parked as 32-bit ints: batches beyond 2^31 rows - they fit the 288 GB for fp32 arms - run inline)
   if (off || B > 0x7fffffffLL) return 0;
   static const int64_t ho_max = [] {  // measurement switch: the largest batch that takes the hand-over form
-    const char* e = getenv("ABRK_HANDOVER_MAX");
+    const char* e = measurement_env("ABRK_HANDOVER_MAX");
     const int64_t v = e ? atoll(e) : kHandoverRows;
     return v < kHandoverMaxRows ? v : (int64_t)kHandoverMaxRows;
   }();
@@ -681,76 +771,82 @@ int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, in
     *rec = q;
     return 0;
   }
-  WorklistSlot* s = nullptr;
-  std::unique_ptr<WorklistSlot> evicted;
-  {
-    std::lock_guard<std::mutex> lk(g_wl_mu);
-    for (auto& e : g_wl_cache)
-      if (e->device == device && e->stream == stream) s = e.get();
-    if (!s) {
-      if (g_wl_cache.size() >= kWlCacheSlots) {
-        // full: the least recently used slot whose stream has nothing in flight (or no longer exists) makes room
-        size_t pick = g_wl_cache.size();
-        for (size_t i = 0; i < g_wl_cache.size(); i++) {
-          WorklistSlot& c = *g_wl_cache[i];
-          if (pick < g_wl_cache.size() && c.last_use >= g_wl_cache[pick]->last_use) continue;
-          if (!c.mu.try_lock()) continue;  // somebody is enqueueing on it
-          (void)hipSetDevice(c.device);
-          const hipError_t q = c.stream ? hipStreamQuery(c.stream) : hipErrorNotReady;  // the NULL stream stays
-          (void)hipGetLastError();
-          c.mu.unlock();
-          if (q != hipErrorNotReady) pick = i;
+  for (int attempt = 0;; attempt++) {
+    std::shared_ptr<WorklistSlot> s, evicted;
+    bool evicted_stream_alive = false;
+    {
+      std::lock_guard<std::mutex> lk(g_wl_mu);
+      for (auto& e : g_wl_cache)
+        if (e->device == device && e->stream == stream) s = e;
+      if (!s) {
+        if (g_wl_cache.size() >= kWlCacheSlots) {
+          // full: the least recently used slot whose stream has nothing in flight (or no longer exists) makes room
+          size_t pick = g_wl_cache.size();
+          bool pick_alive = false;
+          for (size_t i = 0; i < g_wl_cache.size(); i++) {
+            WorklistSlot& c = *g_wl_cache[i];
+            if (pick < g_wl_cache.size() && c.last_use >= g_wl_cache[pick]->last_use) continue;
+            if (g_wl_cache[i].use_count() > 1) continue;  // a caller holds (or is about to lock) it
+            if (!c.mu.try_lock()) continue;               // somebody is enqueueing on it
+            (void)hipSetDevice(c.device);
+            const hipError_t q = c.stream ? hipStreamQuery(c.stream) : hipErrorNotReady;  // the NULL stream stays
+            (void)hipGetLastError();
+            c.mu.unlock();
+            if (q != hipErrorNotReady) {
+              pick = i;
+              pick_alive = q == hipSuccess;
+            }
+          }
+          (void)hipSetDevice(device);
+          if (pick == g_wl_cache.size()) {  // every cached stream is busy: inline sweeps for this call
+            g_wl_inline_fallbacks++;
+            return 0;
+          }
+          g_wl_evictions++;
+          evicted = std::move(g_wl_cache[pick]);
+          evicted_stream_alive = pick_alive;
+          g_wl_cache.erase(g_wl_cache.begin() + pick);
         }
-        (void)hipSetDevice(device);
-        if (pick == g_wl_cache.size()) {  // every cached stream is busy: inline sweeps for this call
-          g_wl_inline_fallbacks++;
-          return 0;
-        }
-        g_wl_evictions++;
-        evicted = std::move(g_wl_cache[pick]);
-        g_wl_cache.erase(g_wl_cache.begin() + pick);
+        s = std::make_shared<WorklistSlot>();
+        s->device = device;
+        s->stream = stream;
+        g_wl_cache.push_back(s);
       }
-      g_wl_cache.emplace_back(new WorklistSlot);
-      s = g_wl_cache.back().get();
-      s->device = device;
-      s->stream = stream;
+      s->last_use = ++g_wl_clock;
     }
-    s->last_use = ++g_wl_clock;
-  }
-  if (evicted) {
-    std::lock_guard<std::mutex> sl(evicted->mu);
-    wl_release(*evicted);
-    (void)hipSetDevice(device);
-  }
-  hold = std::unique_lock<std::mutex>(s->mu);
-  if (s->cap < need || s->rec_cap < need_rec) {
-    if (s->buf || s->rec) {
-      (void)hipStreamSynchronize(stream);  // launches in flight may still use the old buffers (all enqueued: see above)
-      wl_release(*s);
+    if (evicted) {
+      wl_retire(evicted, evicted_stream_alive);
+      (void)hipSetDevice(device);
     }
-    void *p = nullptr, *q = nullptr;
-    hipError_t e = hipMalloc(&p, need + need / 4);
-    if (e == hipSuccess && need_rec) e = hipMalloc(&q, need_rec + need_rec / 4);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      if (p) (void)hipFree(p);
-      hold.unlock();
+    hold.slot = s;
+    hold.lk = std::unique_lock<std::mutex>(s->mu);
+    if (s->retired) {  // evicted / forgotten between the look-up and the lock: look again (a fresh slot)
+      hold.release();
+      if (attempt < 4) continue;
+      g_wl_inline_fallbacks++;
+      return 0;
+    }
+    bool drained = false;
+    void* b = s->buf;
+    // the two buffers grow independently, and a recompute-form call (need_rec = 0) leaves the record store alone: a
+    // stream alternating hand-over batches with large ones keeps both
+    const bool ok = wl_grow(stream, &b, &s->cap, need, &drained) &&
+                    (!need_rec || wl_grow(stream, &s->rec, &s->rec_cap, need_rec, &drained));
+    s->buf = (int*)b;
+    if (!ok) {
+      hold.release();
       g_wl_inline_fallbacks++;
       return 0;  // no scratch on an immediate call: inline sweeps (same results)
     }
-    s->buf = (int*)p;
-    s->cap = need + need / 4;
-    s->rec = q;
-    s->rec_cap = q ? need_rec + need_rec / 4 : 0;
+    *wl = s->buf;
+    if (handover) *rec = s->rec;
+    return 0;
   }
-  *wl = s->buf;
-  if (handover) *rec = s->rec;
-  return 0;
 }
 
 // finish kernel of the hand-over form: measurement switches (read once)
 int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
+  const char* e = measurement_env(name);
   return e ? atoi(e) : dflt;
 }
 // wavefronts per chunk and records per wavefront of the finish kernel (abrk_kernels.h finish_slots / finish_rounds);
@@ -913,17 +1009,20 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   oa.ts = st.fix(ts_, training_signal);
   oa.use_C = P->use_C ? 1 : 0;
   oa.fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
-  std::unique_lock<std::mutex> wl_hold;  // the (device, stream) worklist stays ours until the launches are enqueued
+  WlHold wl_hold;  // the (device, stream) worklist stays ours until the launches are enqueued
   if (oa.fast == 0 && !want)
     if (int rc = worklist_for(device, (hipStream_t)stream, B, n, dtype, &oa.wl, &oa.rec, wl_hold)) return rc;
-  const OscP<double> p64 = make_oscp<double>(*P, n);
-  const OscP<float> p32 = make_oscp<float>(*P, n);
+  OscP<double> p64 = make_oscp<double>(*P, n);
+  OscP<float> p32 = make_oscp<float>(*P, n);
+  StatusWord* sw = status_word(st.staged, device);
+  p64.status = p32.status = sw ? sw->dev : nullptr;
+  if (sw && st.staged) *sw->host = 0;  // (this thread's word: nothing of an earlier, failed call is left in it)
   const ArmOps* ops = a->ops;
   const hipStream_t hs = (hipStream_t)stream;
   // hand-over mode: the arm's first pass, then the arm-independent finish kernel on the records it left
   FinishArgs fa{oa.wl, oa.rec, (P->n_null > 0 || u_null_ext) ? 1 : 0, finish_slots_for(B), finish_rounds_for(B),
                 oa.u, oa.ts};
-  return dispatch(st, a, dtype, [=](const void* rt) {
+  const int rc = dispatch(st, a, dtype, [=](const void* rt) {
     OscArgs o = oa;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
     const LaunchArgs la{rt, (long)B, hs};
@@ -931,6 +1030,9 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
     if (e != hipSuccess || !o.rec) return e;
     return launch_osc6_finish(n, dtype, la, fa);
   }, &wl_hold);
+  // host arrays: the call is complete (outputs copied back) - report a non-positive-definite M now
+  if (rc == 0 && st.staged && sw && sw->take()) return singular_error();
+  return rc;
 }
 
 // ------------------------------------------------------------------------------- OSC, wave-cooperative mapping
@@ -1121,13 +1223,17 @@ extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_p
   const int n = a->desc.n_joints;
   const size_t s = esz(dtype);
   void* ie = (P->ki != 0) ? integrated_error : nullptr;
-  const OscP<double> p64 = make_oscp<double>(*P, n);
-  const OscP<float> p32 = make_oscp<float>(*P, n);
+  OscP<double> p64 = make_oscp<double>(*P, n);
+  OscP<float> p32 = make_oscp<float>(*P, n);
+  // (a synchronous call: the calling thread's word, shared by every shard - the word is portable pinned host memory)
+  StatusWord* sw = status_word(true, devices[0]);
+  p64.status = p32.status = sw ? sw->dev : nullptr;
+  if (sw) *sw->host = 0;
   const ShardPiece pieces[8] = {{q, nullptr, n * s},           {dq, nullptr, n * s},        {target, nullptr, 6 * s},
                                 {target_velocity, nullptr, 6 * s}, {ie, ie, 6 * s},          {u_null_ext, nullptr, n * s},
                                 {nullptr, u, n * s},           {nullptr, training_signal, n * s}};
   const int use_C = P->use_C ? 1 : 0, fast = osc_fast_rows(*P, n, u_null_ext != nullptr);
-  return run_sharded(B, n_shards, devices, pieces, 8, [&](char* const* dev, int64_t rows, hipStream_t st) {
+  const int rc = run_sharded(B, n_shards, devices, pieces, 8, [&](char* const* dev, int64_t rows, hipStream_t st) {
     OscArgs oa;
     oa.q = dev[0];
     oa.dq = dev[1];
@@ -1142,6 +1248,8 @@ extern "C" int abrk_osc_generate_sharded(int arm_id, int dtype, const abrk_osc_p
     oa.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
     return a->ops->osc(dtype, LaunchArgs{arm_table(a, dtype), (long)rows, st}, oa);
   });
+  if (rc == 0 && sw && sw->take()) return singular_error();
+  return rc;
 }
 
 extern "C" int abrk_sliding_generate_sharded(int arm_id, int dtype, const abrk_sliding_params* P, int64_t B,
@@ -1465,15 +1573,20 @@ extern "C" int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params
   a.une = st.fix(une_, u_null_ext);
   a.u = st.fix(u_, u);
   a.ts = st.fix(ts_, training_signal);
-  const OscP<double> p64 = make_oscp<double>(*P, n);
-  const OscP<float> p32 = make_oscp<float>(*P, n);
+  OscP<double> p64 = make_oscp<double>(*P, n);
+  OscP<float> p32 = make_oscp<float>(*P, n);
+  StatusWord* sw = status_word(st.staged, device);
+  p64.status = p32.status = sw ? sw->dev : nullptr;
+  if (sw && st.staged) *sw->host = 0;  // (this thread's word: nothing of an earlier, failed call is left in it)
   a.P = nullptr;
   const hipStream_t hs = (hipStream_t)stream;
-  return dispatch(st, nullptr, dtype, [=](const void*) {
+  const int rc = dispatch(st, nullptr, dtype, [=](const void*) {
     LawArgs o = a;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
     return launch_osc_law(n, dtype, LaunchArgs{nullptr, (long)B, hs}, o);
   });
+  if (rc == 0 && st.staged && sw && sw->take()) return singular_error();
+  return rc;
 }
 
 // ------------------------------------------------------------------------------- helper methods of OSC
@@ -1652,19 +1765,24 @@ extern "C" int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_
   ra.qt = st.fix(qt_, q_traj);
   ra.dqt = st.fix(dqt_, dq_traj);
   ra.ut = st.fix(ut_, u_traj);
-  const OscP<double> p64 = make_oscp<double>(*P, n);
-  const OscP<float> p32 = make_oscp<float>(*P, n);
+  OscP<double> p64 = make_oscp<double>(*P, n);
+  OscP<float> p32 = make_oscp<float>(*P, n);
+  StatusWord* sw = status_word(st.staged, device);
+  p64.status = p32.status = sw ? sw->dev : nullptr;
+  if (sw && st.staged) *sw->host = 0;  // (this thread's word: nothing of an earlier, failed call is left in it)
   const TwoLinkP<double> k64 = make_plant<double>(*plant);
   const TwoLinkP<float> k32 = make_plant<float>(*plant);
   ra.P = ra.K = nullptr;
   const ArmOps* ops = a->ops;
   const hipStream_t hs = (hipStream_t)stream;
-  return dispatch(st, a, dtype, [=](const void* rt) {
+  const int rc = dispatch(st, a, dtype, [=](const void* rt) {
     RolloutArgs o = ra;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;
     o.K = dtype == ABRK_F64 ? (const void*)&k64 : (const void*)&k32;
     return ops->rollout(dtype, LaunchArgs{rt, (long)B, hs}, o);
   });
+  if (rc == 0 && st.staged && sw && sw->take()) return singular_error();
+  return rc;
 }
 
 // ------------------------------------------------------------------------------- launch plans

@@ -8,13 +8,18 @@
 
 namespace abrk {
 
-#ifndef ABRK_BLOCK
-#define ABRK_BLOCK 64
-#endif
-#ifndef ABRK_MIN_WAVES
-#define ABRK_MIN_WAVES 1
-#endif
-constexpr int kBlock = ABRK_BLOCK;  // rows are independent, no LDS sharing: one wavefront per workgroup
+constexpr int kBlock = 64;  // rows are independent, no LDS sharing: one wavefront per workgroup
+constexpr int kMinWaves = 1;  // kernels without a register cap: whatever occupancy their register count allows
+// Measurement switches of the host-side launch logic (ABRK_NO_HANDOVER, ABRK_FINISH_SLOTS, ABRK_OBS_PLAIN, ...: listed in
+// INTEGRATION.md) are read only when ABRK_MEASUREMENT=1 is set: no stray environment variable changes which algorithm a
+// production call runs.
+inline const char* measurement_env(const char* name) {
+  static const bool on = [] {
+    const char* e = getenv("ABRK_MEASUREMENT");
+    return e && e[0] == '1';
+  }();
+  return on ? getenv(name) : nullptr;
+}
 
 #define ABRK_ROW_INDEX                                     \
   long b = (long)blockIdx.x * kBlock + threadIdx.x;        \
@@ -58,7 +63,7 @@ struct LdsStore {
 };
 
 template <class A, class T, bool WITH_DQ>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, const T* __restrict__ qg,
            const T* __restrict__ dqg, DynOutP<T> out) {
   __shared__ __attribute__((aligned(16))) T slab[kBlock * max_row(A::N)];
@@ -72,51 +77,25 @@ dyn_kernel(A arm, int frame, int m, T ox, T oy, T oz, unsigned want, long B, con
 // (xyz kernel) asked to fit two waves per SIMD (<= 256 VGPRs; measured +6 % on Jaco2 whose general-chain state would
 // otherwise take 256 + 18 parked registers); the heavier variants keep the full budget - forcing them
 // under 256 spills hundreds of bytes per lane and loses 2-3x (measured).
-#ifndef ABRK_C_TWO_WAVES
-#define ABRK_C_TWO_WAVES ABRK_C_TWO_PASS
-#endif
-#ifndef ABRK_FEAT1_TWO_WAVES
-#define ABRK_FEAT1_TWO_WAVES 1
-#endif
-// (use_C: only the two-pass form of orthogonal chains, abrk_ctrl.h osc_row, fits the two-wave budget)
-#ifndef ABRK_KM6_LDS
-#define ABRK_KM6_LDS 1  // six-row law: task Jacobian rows in the wavefront's LDS slab (0: registers, as in round 2)
-#endif
-#ifndef ABRK_KM6_TWO_WAVES
-#define ABRK_KM6_TWO_WAVES 1  // six-row law with its Jacobian rows in LDS (osc_law6)
-#endif
-#ifndef ABRK_KM6_TWO_WAVES_GENERAL
-#define ABRK_KM6_TWO_WAVES_GENERAL 0
-#endif
+// (use_C: only the two-pass form of orthogonal chains, abrk_ctrl.h osc_row, fits the two-wave budget; the six-row law
+//  keeps its task Jacobian rows in the wavefront's LDS slab - osc_law6 - which is what lets its first pass fit)
 // Runtime-table arms (the table rides in SGPRs, every frame product is a dense 3 x 4 multiply, every joint carries a
 // 3 x 3 W): capped at 256 registers the three-row kernels spill 130-220 B per lane in the hot path.  One wave per SIMD
 // without spills is faster (round 3, UR5's table as a user arm, 8 M rows: 908 -> 787 us; Jaco2's: 906 -> 782 us; the
-// 4096-row step 8.55 -> 7.50 us).  1 = the round-2 behaviour.
-#ifndef ABRK_RT_TWO_WAVES
-#define ABRK_RT_TWO_WAVES 0
-#endif
+// 4096-row step 8.55 -> 7.50 us).
 constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho, int pass = 0, bool is_static = true) {
-  if (!is_static && !ABRK_RT_TWO_WAVES && km <= 3) return ABRK_MIN_WAVES;
+  if (!is_static && km <= 3) return kMinWaves;
   // six-row law: the first pass of orthogonal chains fits 256 registers (UR5: 100-216 B of scratch, all of it in cold
   // branches); general chains carry a 3 x 3 W per joint through the kinematics and would spill 250-650 B in the hot
-  // path (ABRK_KM6_TWO_WAVES_GENERAL = 1 forces them too - a measurement switch)
-  if (km == 6)
-    return (pass == 1 && ABRK_KM6_TWO_WAVES && ABRK_KM6_LDS && (ortho || ABRK_KM6_TWO_WAVES_GENERAL) && feat <= 1) ? 2 : ABRK_MIN_WAVES;
-  return ((!use_c || (ABRK_C_TWO_WAVES && ortho)) && (feat == 0 || (feat == 1 && ABRK_FEAT1_TWO_WAVES)))
-             ? 2
-             : ABRK_MIN_WAVES;
+  // path (measured in round 3: forcing them under 256 registers loses)
+  if (km == 6) return (pass == 1 && ortho && feat <= 1) ? 2 : kMinWaves;
+  return ((!use_c || ortho) && feat <= 1) ? 2 : kMinWaves;
 }
 
 // Scratch of the Coriolis recursion in LDS: per link one force and one moment (6 values), laid out [link][pair][lane]
 // so that every access is a 16-byte (fp64) / 8-byte (fp32) piece per lane, contiguous across the wavefront (no bank
 // conflicts).  6 N values per lane: 18 KiB per wavefront for a six-joint arm in fp64 - eight wavefronts per CU (two
 // per SIMD) fit the 160 KiB.  Rows never share data, so no barrier is needed: each lane reads what it wrote.
-#ifndef ABRK_C_LDS
-#define ABRK_C_LDS 1
-#endif
-#ifndef ABRK_SINCOS_TABLE
-#define ABRK_SINCOS_TABLE 1
-#endif
 
 // The wavefront's copy of the sin/cos table (abrk_sincos_table.h; 2 KiB in fp64, 1 KiB in fp32): two entries per
 // lane, from L2
@@ -132,19 +111,6 @@ __device__ __forceinline__ void load_sincos_table(T* tab, int lane) {
   __syncthreads();
 }
 static_assert(kBlock == 64 && kSinCosN == 128, "two table entries per lane");
-// ... by a workgroup of any number of wavefronts (the x,y,z OSC kernels: 1 - 4, osc_waves below): one copy per workgroup
-template <class T>
-__device__ __forceinline__ void load_sincos_table_wg(T* tab) {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  typedef T t2 __attribute__((ext_vector_type(2)));
-  const d2* src = reinterpret_cast<const d2*>(&kSinCosTab[0][0]);
-  t2* dst = reinterpret_cast<t2*>(tab);
-  for (int i = (int)threadIdx.x; i < kSinCosN; i += (int)blockDim.x) {
-    const d2 a = src[i];
-    dst[i] = t2{(T)a.x, (T)a.y};
-  }
-  __syncthreads();
-}
 // scratch of kernels without a Coriolis recursion: nothing but the table pointer
 template <class T, int N>
 struct TabScratch : RegScratch<T, N> {
@@ -158,7 +124,7 @@ template <int N>
 constexpr int slab_pairs() { return 3 * N > 6 * ((N + 1) / 2) ? 3 * N : 6 * ((N + 1) / 2); }
 template <class T, int N>
 struct LdsScratch : ScratchBase {
-  static constexpr bool kHasTab = (ABRK_SINCOS_TABLE != 0);
+  static constexpr bool kHasTab = true;
   using V2 = T __attribute__((ext_vector_type(2)));
   V2* slab;  // [N][3][kBlock] wrenches, then [6][(N + 1) / 2][kBlock] Jacobian rows
   int lane;
@@ -212,16 +178,11 @@ struct LdsScratch : ScratchBase {
 
 // (the worklist of deferred rows and the hand-over record: abrk_device.h, next to ScratchBase)
 static_assert(kWlBlock == kBlock, "wl_capacity assumes one first-pass workgroup per kBlock rows");
-#ifndef ABRK_KM6_GRID_CAP
-#define ABRK_KM6_GRID_CAP 4096  // first pass of the six-row law: a persistent grid of at most this many blocks (a multiple of kWlLists)
-#endif
-#ifndef ABRK_KM6_P1_LOOP
-#define ABRK_KM6_P1_LOOP 0  // measurement switch: 1 = the first pass as a persistent grid too (rounds 2-3)
-#endif
+constexpr unsigned kKm6GridCap = 4096;  // one-wave first pass of the six-row law: a persistent grid of at most this many blocks (a multiple of kWlLists)
 // the first pass of the six-row law as one row per lane (no persistent grid): where it holds two waves per SIMD - a
 // one-wave first pass (general chains) keeps the loop, whose next row hides the stores of the last
 constexpr bool km6_first_pass_plain(int km, bool use_c, int feat, bool ortho, int pass, bool is_static) {
-  return km == 6 && pass == 1 && !ABRK_KM6_P1_LOOP && osc_min_waves(km, use_c, feat, ortho, pass, is_static) >= 2;
+  return km == 6 && pass == 1 && osc_min_waves(km, use_c, feat, ortho, pass, is_static) >= 2;
 }
 // `mode`: 0 = every row start to finish; 1 = rows whose law needs the Jacobi eigen-decomposition (a truncating pinv that
 // neither certificate excludes) only leave their index in the worklist `wl`; 2 = work that list off, densely packed
@@ -231,71 +192,53 @@ constexpr bool km6_first_pass_plain(int km, bool use_c, int feat, bool ortho, in
 // PASS (six-row kernels): 0 = the complete row program (modes 0 and 2: the sweeps are compiled in; one wave per SIMD),
 // 1 = the first pass (mode 1) - no eigen-decomposition in the code at all, two waves per SIMD.
 // NOTS (first pass of the plain six-row law only): the caller wants no training signal - see ScratchBase::kNoTs.
-// Workgroup shape of the OSC kernels.  Rows never share data, so a workgroup is just a dispatch unit: one wavefront for
-// the six-row kernels (their worklist / mask bookkeeping is per 64-row chunk); the x,y,z kernels can take 1 - 4
-// wavefronts per workgroup (osc_waves; ABRK_OSC_WAVES) - built to test whether the dispatch of single-wavefront
-// workgroups (~1.1 per ns chip-wide) bounds the 131072-row shard of BASELINE config 4: it does not (osc_waves).  The LDS
-// of a workgroup is dynamic: [sin/cos table][slab of wavefront 0][slab of wavefront 1]...
-// ABRK_OSC_MAX_WAVES (measurement switch, default 1 = single-wavefront workgroups with static LDS, as ever): > 1
-// compiles the x,y,z kernels for workgroups of up to that many wavefronts.  The general form is not free at the
-// config-sized batch - a runtime loop for the table load, a real s_barrier behind it, the wavefront's slab offset: the
-// 4096-row step of BASELINE config 2 measured 3.81 us against 3.55 - 3.64 us - and bought nothing at any size (osc_waves).
-#ifndef ABRK_OSC_MAX_WAVES
-#define ABRK_OSC_MAX_WAVES 1
-#endif
-constexpr int kOscMaxWaves = ABRK_OSC_MAX_WAVES;
-constexpr int osc_max_threads(int km) { return km <= 3 ? kOscMaxWaves * kBlock : kBlock; }
+// Workgroup shape of the OSC kernels: single wavefronts with static LDS.  Rows never share data, so a workgroup is just
+// a dispatch unit.  Workgroups of 2 - 4 wavefronts for the x,y,z kernels (dynamic LDS, one table per workgroup) were built
+// and measured in round 4 to test whether the dispatch of single-wavefront workgroups (~1.1 per ns chip-wide) bounds the
+// 131072-row shard of BASELINE config 4: it does not (UR5 + g + C, us per step with 1 / 2 / 4 wavefronts per workgroup:
+// 131072 rows 10.53 / 10.22 / 10.43, 2^20 rows 58.8 / 60.6 / 58.7, 8 M rows 495.9 / 494.9 / 496.8), and the general form
+// cost the config-sized step 3-4 % (profiles/round4/mw_ab.txt).  The form was removed in round 5.
 template <class A, class T, int KM, bool USE_C>
 constexpr bool osc_uses_slab() {
-  return (USE_C && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) || (KM == 6 && (ABRK_KM6_LDS != 0));
+  return (USE_C && A::kOrtho) || KM == 6;
 }
-template <class A, class T, int KM, bool USE_C>
-constexpr size_t osc_lds_bytes(int waves) {
-  return ((ABRK_SINCOS_TABLE != 0) ? 2 * kSinCosN * sizeof(T) : 16) +
-         (osc_uses_slab<A, T, KM, USE_C>() ? (size_t)waves * slab_pairs<A::N>() * kBlock * 2 * sizeof(T) : 0);
-}
-inline int osc_waves(long B) {
-  static const int forced = [] {
-    const char* e = getenv("ABRK_OSC_WAVES");  // measurement switch
-    return e ? atoi(e) : 0;
-  }();
-  if (forced >= 1 && forced <= kOscMaxWaves) return forced;
-  // Measured (round 4, UR5 + g + C, us per step with 1 / 2 / 4 wavefronts per workgroup): 131072 rows 10.53 / 10.22 /
-  // 10.43, 262144 rows 18.4 / 19.5 / 18.7, 2^20 rows 58.8 / 60.6 / 58.7, 8 M rows 495.9 / 494.9 / 496.8: no effect - the
-  // shard-sized step is one residency round of 2048 wavefronts at ~1650 issue slots each, not dispatch.  One it stays.
-  (void)B;
-  return 1;
-}
-extern __shared__ __attribute__((aligned(16))) unsigned char osc_smem[];
 template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOTS = false>
-__global__ void __launch_bounds__(osc_max_threads(KM), osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic))
+__global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
            const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, int mode, int* __restrict__ wl,
            T* __restrict__ rec) {
-  constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
   // the slab: scratch of the Coriolis recursion (orthogonal chains) and / or the row store of the six-row law
   constexpr bool kLds = osc_uses_slab<A, T, KM, USE_C>();
   using V2 = typename LdsScratch<T, A::N>::V2;
-#if ABRK_OSC_MAX_WAVES > 1
-  T* const sctab = reinterpret_cast<T*>(osc_smem);
-  const int lane = (int)(threadIdx.x & (kBlock - 1));
-  V2* slab = reinterpret_cast<V2*>(osc_smem + (kTab ? 2 * kSinCosN * sizeof(T) : 16));
-  if constexpr (KM <= 3) {
-    if constexpr (kTab) load_sincos_table_wg(sctab);  // every lane takes part: before any exit
-    if constexpr (kLds) slab += __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kBlock)) * (slab_pairs<A::N>() * kBlock);
-  } else {
-    if constexpr (kTab) load_sincos_table(sctab, lane);
-  }
-#else
-  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
-  const int lane = (int)threadIdx.x;
-  if constexpr (kTab) load_sincos_table(sctab, lane);  // every lane takes part: before any exit
-  __shared__ V2 slab[kLds ? slab_pairs<A::N>() * kBlock : 1];
+#if defined(ABRK_TIMELINE)
+  const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime(), tl_clk0 = __builtin_amdgcn_s_memtime();
 #endif
+  __shared__ T sctab[2 * kSinCosN];
+  const int lane = (int)threadIdx.x;
+  load_sincos_table(sctab, lane);  // every lane takes part: before any exit
+#if defined(ABRK_TIMELINE)
+  const unsigned long long tl_tab = __builtin_amdgcn_s_memrealtime();
+#endif
+  __shared__ V2 slab[kLds ? slab_pairs<A::N>() * kBlock : 1];
   const bool handover = rec != nullptr;
   auto row = [&](long b, bool allow_defer) ABRK_LAMBDA {
     auto go = [&](auto& scr) ABRK_LAMBDA {
+#if defined(ABRK_TIMELINE)
+      if constexpr (KM <= 3) {  // stamps 0 .. 7 of this wavefront leave through `wl` (unused by the x,y,z kernels)
+        osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+        ABRK_STAMP(scr, 5, false);
+        ABRK_STAMP(scr, 6, true);
+        scr.tl[0] = tl_entry;
+        scr.tl[1] = tl_tab;
+        scr.tl[7] = __builtin_amdgcn_s_memtime() - tl_clk0;  // shader-clock cycles from entry to the end
+        if (wl && threadIdx.x == 0) {
+          unsigned long long* o = reinterpret_cast<unsigned long long*>(wl) + (size_t)blockIdx.x * 8;
+          for (int k = 0; k < 8; k++) o[k] = scr.tl[k];
+        }
+        return false;
+      }
+#endif
       scr.allow_defer = allow_defer;
       if (allow_defer) {  // where a deferring row parks itself (ScratchBase::claim, called by the law)
         scr.wl = wl;
@@ -309,8 +252,8 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       return scr.deferred;
     };
     if constexpr (kLds && NOTS) {
-      static_assert(PASS == 1 && KM == 6 && FEAT == 0, "NOTS is instantiated for the first pass of the plain six-row law");
-      NoTs<DeferOnly<LdsScratch<T, A::N>>> scr;
+      static_assert(KM == 6 && FEAT == 0, "NOTS is instantiated for the plain six-row law");
+      NoTs<std::conditional_t<PASS == 1, DeferOnly<LdsScratch<T, A::N>>, LdsScratch<T, A::N>>> scr;
       scr.slab = slab;
       scr.lane = lane;
       scr.sctab = sctab;
@@ -321,12 +264,9 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       scr.lane = lane;
       scr.sctab = sctab;
       return go(scr);
-    } else if constexpr (kTab) {
+    } else {
       std::conditional_t<PASS == 1, DeferOnly<TabScratch<T, A::N>>, TabScratch<T, A::N>> scr;
       scr.sctab = sctab;
-      return go(scr);
-    } else {
-      std::conditional_t<PASS == 1, DeferOnly<RegScratch<T, A::N>>, RegScratch<T, A::N>> scr;
       return go(scr);
     }
   };
@@ -353,7 +293,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
     // their row, mode 2 strides a persistent grid over the worklist.  (Only the six-row kernels defer: with x,y,z
     // alone the two certificates leave < 0.01 % of the rows to the sweeps, and the loop form costs the three-row
     // kernels 40 registers.)
-    // Large batches run as a persistent grid (Launch::osc_launch caps it at ABRK_KM6_GRID_CAP blocks): the kernel holds
+    // Large batches run as a persistent grid (Launch::osc_launch caps it at kKm6GridCap blocks): the kernel holds
     // one wavefront per SIMD (390-490 registers), so nothing hides a row's memory round trips but its neighbours in
     // time - in the loop a row's stores drain under the next row's arithmetic (UR5, 8 M rows: 1133 -> 985 us).
     // Requesting row i + step's inputs before working on row i was measured too: 36 more live registers cost more
@@ -371,7 +311,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       if (mode == 1) note(i - threadIdx.x, deferred);
     }
   } else {
-    const long b = (long)blockIdx.x * blockDim.x + threadIdx.x;  // 1 - 4 wavefronts per workgroup (osc_waves)
+    const long b = (long)blockIdx.x * kBlock + threadIdx.x;
     if (b >= B) return;
     row(b, false);
   }
@@ -500,11 +440,9 @@ constexpr long kHandoverMaxRows = 262144;  // (the finish kernel's grid: 4096 ch
 // Mode F: u + Tx, J, M, g in one launch (840 B per UR5 row in fp64: HBM-bound).  One LDS slab serves both the
 // cooperative stores and (use_C) the scratch of the Coriolis recursion, which is dead by the time the first row is
 // parked.  FEAT is 0 (the plain law) or 2 (every optional input).
-#ifndef ABRK_VEL_WAVES
-#define ABRK_VEL_WAVES ABRK_MIN_WAVES  // measurement switch: 2 caps the C / dJ variant at 256 registers (364-424 B of scratch)
-#endif
+// (the C / dJ variant is not capped at 256 registers: that costs 364-424 B of scratch, measured in round 3)
 template <class A, class T, int KM, bool USE_C, int FEAT, bool VEL = false>
-__global__ void __launch_bounds__(kBlock, VEL ? (ABRK_VEL_WAVES) : osc_min_waves(KM, USE_C, FEAT, A::kOrtho, 0, A::kStatic))
+__global__ void __launch_bounds__(kBlock, VEL ? kMinWaves : osc_min_waves(KM, USE_C, FEAT, A::kOrtho, 0, A::kStatic))
 osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                 const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
                 const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, unsigned want, DynOutP<T> out) {
@@ -514,34 +452,30 @@ osc_full_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __r
   const long row0 = (long)blockIdx.x * kBlock;
   const long b = row0 + threadIdx.x;
   LdsStore<T> st{slab, row0, B, (int)threadIdx.x};
-  constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
-  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
-  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);
-  if constexpr ((USE_C && !VEL && A::kOrtho && (ABRK_C_TWO_PASS != 0) && (ABRK_C_LDS != 0)) || (KM == 6 && (ABRK_KM6_LDS != 0))) {
+  __shared__ T sctab[2 * kSinCosN];
+  load_sincos_table(sctab, (int)threadIdx.x);
+  if constexpr ((USE_C && !VEL && A::kOrtho) || KM == 6) {
     using V2 = typename LdsScratch<T, A::N>::V2;
     LdsScratch<T, A::N> scr;
     scr.slab = reinterpret_cast<V2*>(slab);
     scr.lane = (int)threadIdx.x;
     scr.sctab = sctab;
     osc_full_body<A, T, KM, USE_C, FEAT, VEL>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
-  } else if constexpr (kTab) {
+  } else {
     TabScratch<T, A::N> scr;
     scr.sctab = sctab;
-    osc_full_body<A, T, KM, USE_C, FEAT, VEL>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
-  } else {
-    RegScratch<T, A::N> scr;
     osc_full_body<A, T, KM, USE_C, FEAT, VEL>(b, b < B, st, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, want, out, scr);
   }
 }
 
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 sliding_kernel(A arm, SlidingP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                const T* __restrict__ tg, const T* __restrict__ tvg, const T* __restrict__ tag,
                T* __restrict__ ug, T* __restrict__ sg) {
-  constexpr bool kTab = (ABRK_SINCOS_TABLE != 0);
-  __shared__ T sctab[kTab ? 2 * kSinCosN : 1];
-  if constexpr (kTab) load_sincos_table(sctab, (int)threadIdx.x);
+  constexpr bool kTab = true;
+  __shared__ T sctab[2 * kSinCosN];
+  load_sincos_table(sctab, (int)threadIdx.x);
   // grid-stride over the row blocks (the launcher caps the grid at kSlidingMaxBlocks): a threejoint fp32 wavefront
   // lives ~5 us, and one-wavefront workgroups are dispatched at ~1.1 per ns chip-wide - too slowly to keep the 7
   // wavefronts per SIMD this kernel could hold resident (8 M rows: 131 k dispatches)
@@ -551,7 +485,7 @@ sliding_kernel(A arm, SlidingP<T> P, long B, const T* __restrict__ qg, const T* 
 constexpr long kSlidingMaxBlocks = 256L * 32 * 4;  // four rounds of a full chip of wavefronts
 
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 joint_kernel(A arm, JointP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
              const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ug) {
   ABRK_ROW_INDEX
@@ -559,7 +493,7 @@ joint_kernel(A arm, JointP<T> P, long B, const T* __restrict__ qg, const T* __re
 }
 
 template <int N, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 osc_law_kernel(OscP<T> P, long B, const T* __restrict__ Jg, const T* __restrict__ Mg, const T* __restrict__ gg,
                const T* __restrict__ cg, const T* __restrict__ xg, const T* __restrict__ Rg,
                const T* __restrict__ qg, const T* __restrict__ dqg, const T* __restrict__ tg,
@@ -587,7 +521,7 @@ struct FinishArgs {
 // (abrk_law.hip; arm-independent: the record holds everything)
 hipError_t launch_osc6_finish(int n_joints, int dtype, const LaunchArgs& la, const FinishArgs& a);
 template <class A, class T, bool USE_C, int KM>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 rollout_kernel(A arm, OscP<T> P, TwoLinkP<T> K, long B, int n_steps, int every, T* __restrict__ qg,
                T* __restrict__ dqg, const T* __restrict__ tg, T* __restrict__ ierrg, T* __restrict__ qt,
                T* __restrict__ dqt, T* __restrict__ ut) {
@@ -603,7 +537,7 @@ twolink_step_kernel(TwoLinkP<T> K, long B, T* __restrict__ qg, T* __restrict__ d
 }
 
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 ik_kernel(A arm, IkP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ tg, T* __restrict__ pp,
           T* __restrict__ vp) {
   ABRK_ROW_INDEX
@@ -618,20 +552,17 @@ limits_kernel(LimitsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug
 }
 
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_MIN_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 floating_kernel(A arm, int dynamic, int task_space, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
                 T* __restrict__ ug, int acc) {
   ABRK_ROW_INDEX
   floating_body<A, T>(b, arm, dynamic, task_space, qg, dqg, ug, acc);
 }
 
-// measurement switch: 2 = cap at 256 VGPRs for two waves per SIMD (UR5 fp64: 320 -> 256 + 172 B of scratch).  Measured
-// no faster at 8 M rows (2830 vs 2822 us: the kernel is issue-bound) and slower at 4096 (38.5 vs 30.2 us), so 1 stays.
-#ifndef ABRK_OBS_WAVES
-#define ABRK_OBS_WAVES ABRK_MIN_WAVES
-#endif
+// (capped at 256 VGPRs for two waves per SIMD - UR5 fp64: 320 -> 256 + 172 B of scratch - the one-pass kernel measured no
+// faster at 8 M rows, 2830 vs 2822 us: it is issue-bound, and slower at 4096, 38.5 vs 30.2 us)
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_OBS_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 obstacles_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
   // grid-stride (the launcher caps the grid at kObstaclesMaxBlocks): one wavefront per SIMD in fp64, so in the loop a
   // row's stores drain under the next row's arithmetic, as in the six-row OSC kernels
@@ -647,7 +578,7 @@ constexpr int kObsPairCap = 2048;  // pairs of a wavefront that are redistribute
 template <class A, class T>
 constexpr bool obstacles_use_lds() { return A::kOrtho && A::N >= 3; }
 template <class A, class T>
-__global__ void __launch_bounds__(kBlock, ABRK_OBS_WAVES)
+__global__ void __launch_bounds__(kBlock, kMinWaves)
 obstacles_lds_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __restrict__ ug, int acc) {
   constexpr int N = A::N, RL = obs_rec_len<N>();
   __shared__ T rec[RL * kBlock];
@@ -847,25 +778,21 @@ struct Launch {
   }
   template <int KM, bool UC, int FEAT>
   static hipError_t osc_launch(const LaunchArgs& la, const OscArgs& a) {
-    // workgroups of `waves` wavefronts (the x,y,z kernels of large launches; the six-row kernels: one), LDS to match
-    const int waves = (KM <= 3 && kOscMaxWaves > 1) ? osc_waves(la.B) : 1;
-    const size_t lds = kOscMaxWaves > 1 ? osc_lds_bytes<A, T, KM, UC>(waves) : 0;  // (default build: static LDS)
     auto go = [&](auto pass, dim3 grid, int mode) {
-      if (lds > 65536) {  // beyond the default dynamic-LDS limit: raise it for this instantiation, once
-        static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void*>(&osc_kernel<A, T, KM, UC, FEAT, pass()>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)once;
-      }
-      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass()>), grid, dim3(kBlock * waves), lds, la.stream, arm_of(la),
+      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass()>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
                          *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
                          (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl, (T*)a.rec);
     };
-    auto go_nots = [&](dim3 grid) {  // first pass, plain law, no training signal asked for
-      if constexpr (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0))
-        hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, 1, true>), grid, dim3(kBlock), lds, la.stream, arm_of(la),
+    // the plain six-row law when no training signal is asked for (NOTS: gravity joins the velocity term before the
+    // factorisations).  EVERY form of the law then runs that arithmetic - first pass, recompute pass, one-pass - so
+    // that a row's bits do not depend on the batch it arrives in.
+    auto go_nots = [&](auto pass, dim3 grid, int mode) {
+      if constexpr (KM == 6 && FEAT == 0)
+        hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass(), true>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
                            *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
-                           (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)nullptr, 1, a.wl, (T*)a.rec);
+                           (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)nullptr, mode, a.wl, (T*)a.rec);
     };
+    const bool nots = KM == 6 && FEAT == 0 && !a.ts;
     if constexpr (KM == 6) {
       if (a.wl) {
         // stale counters would let pass 1 append past its sub-lists: no launch without the memset (hand-over mode: no
@@ -875,14 +802,18 @@ struct Launch {
         dim3 g1 = grid_for(la.B);
         // (the persistent-grid form of the first pass: a multiple of kWlLists)
         constexpr bool plain = km6_first_pass_plain(KM, UC, FEAT, A::kOrtho, 1, A::kStatic);
-        if (!plain && ABRK_KM6_GRID_CAP && g1.x > (unsigned)ABRK_KM6_GRID_CAP) g1.x = ABRK_KM6_GRID_CAP;
-        if (KM == 6 && FEAT == 0 && (ABRK_KM6_LDS != 0) && !a.ts) go_nots(g1);
+        if (!plain && g1.x > kKm6GridCap) g1.x = kKm6GridCap;
+        if (nots) go_nots(ic<1>{}, g1, 1);
         else go(ic<1>{}, g1, 1);
-        if (!a.rec) go(ic<0>{}, dim3(8 * kWlLists), 2);  // a multiple of kWlLists: 8 blocks stride each sub-list
+        if (!a.rec) {  // a multiple of kWlLists: 8 blocks stride each sub-list
+          if (nots) go_nots(ic<0>{}, dim3(8 * kWlLists), 2);
+          else go(ic<0>{}, dim3(8 * kWlLists), 2);
+        }
         return hipSuccess;
       }
     }
-    go(ic<0>{}, dim3((unsigned)((la.B + (long)kBlock * waves - 1) / ((long)kBlock * waves))), 0);
+    if (nots) go_nots(ic<0>{}, grid_for(la.B), 0);
+    else go(ic<0>{}, grid_for(la.B), 0);
     return hipSuccess;
   }
   template <int KM, bool UC>
@@ -1019,7 +950,7 @@ struct OpsFor {
     const dim3 grid((unsigned)(blocks < kObstaclesMaxBlocks ? blocks : kObstaclesMaxBlocks));
     const ObsP<T>& P = *static_cast<const ObsP<T>*>(a.P);
     if constexpr (obstacles_use_lds<A, T>()) {
-      static const bool off = getenv("ABRK_OBS_PLAIN") != nullptr;  // measurement switch: the one-pass kernel
+      static const bool off = measurement_env("ABRK_OBS_PLAIN") != nullptr;  // measurement switch: the one-pass kernel
       if (!off && P.n * (A::N - 2) <= 64) {
         hipLaunchKernelGGL((obstacles_lds_kernel<A, T>), grid, dim3(kBlock), 0, la.stream, Launch<A, T>::arm_of(la), P, la.B,
                            (const T*)a.q, (T*)a.u, a.acc);

@@ -5,13 +5,6 @@
 #pragma once
 #include "abrk_ctrl.h"
 
-#ifndef ABRK_LATE_TARGET
-#define ABRK_LATE_TARGET 0
-#endif
-#ifndef ABRK_KM6_EARLY
-#define ABRK_KM6_EARLY 0  // measurement switch: EVERY six-row kernel requests its inputs up front (see osc_body)
-#endif
-
 namespace abrk {
 
 template <class T>
@@ -160,11 +153,10 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // (the six-row FIRST pass of orthogonal chains asks early too since round 4: its law was restructured to 224 - 246
   //  registers, and at two waves per SIMD one memory round trip fewer per wavefront is worth 2.7 % at 8 M rows - 740 / 746 /
   //  744 us against 760 / 765 / 767 us, same box; the one-wave six-row kernels keep asking late)
-  constexpr bool EARLY = FEAT < 2 && (KM <= 3 || (ABRK_KM6_EARLY != 0) ||
-                                      (std::remove_reference<Scr>::type::kDeferOnly && A::kOrtho && A::kStatic));
-  // (ABRK_LATE_TARGET = 1 requests the target after the kinematics in the use_C kernels; measured unnecessary once
-  //  the link wrenches of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
-  constexpr bool EARLY_T = EARLY && !(USE_C && ABRK_LATE_TARGET);
+  constexpr bool EARLY = FEAT < 2 && (KM <= 3 || (std::remove_reference<Scr>::type::kDeferOnly && A::kOrtho && A::kStatic));
+  // (requesting the target after the kinematics in the use_C kernels was measured unnecessary once the link wrenches
+  //  of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
+  constexpr bool EARLY_T = EARLY;
   if constexpr (USE_C || EARLY) load_row<N>(dqg, b, dq);
   if constexpr (EARLY_T) load_row<6>(tg, b, tgt);
   auto late = [&]() ABRK_LAMBDA {
@@ -177,7 +169,9 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
     if (have_ext) load_row<N>(uneg, b, une);
     else sfor<N>([&](auto i) ABRK_LAMBDA { une[i()] = T(0); });
   };
+  ABRK_STAMP(scr, 2, true);  // (timeline build) every input requested above has landed
   osc_row<A, T, KM, USE_C, FEAT>(arm, P, q, dq, tgt, tv_given, tv, have_ierr, ierr, have_ext, une, u, ts, late, scr);
+  ABRK_STAMP(scr, 4, false);
   if (scr.deferred) {
     // parked for the second pass: u / the training signal are not written yet.  A handed-over row is finished there from
     // its record, without its inputs: the integral state it advanced is stored here

@@ -20,7 +20,12 @@ enum {
   ABRK_ENODEV = -2,   /* no HIP device / HIP runtime error                              */
   ABRK_ENOMEM = -3,   /* device allocation failed                                       */
   ABRK_ENOARM = -4,   /* unknown arm id / name                                          */
-  ABRK_EFRAME = -5    /* invalid frame id ("Invalid transformation name", ur5/config.py:337) */
+  ABRK_EFRAME = -5,   /* invalid frame id ("Invalid transformation name", ur5/config.py:337) */
+  ABRK_ESINGULAR = -6 /* a row's joint-space inertia matrix M is not positive definite: where the reference's
+                         numpy.linalg.inv(M) raises LinAlgError (controllers/osc.py:136).  Host-array calls return
+                         it themselves (the outputs of the offending rows are unspecified, every other row is
+                         valid); device-pointer calls are asynchronous - the flag is sticky per device and is
+                         returned (once) by the next abrk_stream_sync on that device                          */
 };
 
 /* ---------------------------------------------------------------------------------

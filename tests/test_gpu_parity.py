@@ -228,6 +228,50 @@ def test_gpu_batch_edges_and_device_arrays():
         engine.osc_generate(be.arm_id, 6, p, q_, dq, t)
 
 
+def test_gpu_singular_inertia_matrix_is_reported():
+    """a joint-space inertia matrix that is not positive definite (a user arm whose last link has neither mass nor
+    inertia: M's last row and column are zero) - the reference's np.linalg.inv(M) raises LinAlgError (osc.py:136); here a
+    host-array call returns ABRK_ESINGULAR (a LinAlgError in Python), a device-pointer call leaves the flag for the next
+    abrk_stream_sync of its device, which reports it once.  Non-finite states are NOT singular (inv returns NaNs), and
+    nothing sticks to later calls."""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+    from abr_control_amd._lib import SingularMatrixError
+    from tests.synthetic_arms import make_arm
+
+    tab = make_arm(6, 77)
+    tab["mdiag"][6] = [0.0] * 6  # the last link: no mass, no inertia
+    bad = cases.GpuBackend(tab)
+    good = cases.GpuBackend(make_arm(6, 77))
+    q, dq, t = draw(5, 300, 6)
+    laws = (_abi.make_osc_params(6, kp=100), _abi.make_osc_params(6, kp=100, use_C=True),
+            _abi.make_osc_params(6, kp=100, ko=80, ctrlr_dof=[1] * 6),
+            _abi.make_osc_params(6, kp=100, null_controllers=[_abi.make_damping(5)]))
+    for p in laws:
+        for dtype in (np.float64, np.float32):
+            with pytest.raises(np.linalg.LinAlgError) as ei:
+                bad.osc(p, q, dq, t, dtype=dtype)
+            assert isinstance(ei.value, SingularMatrixError) and ei.value.code == _abi.ESINGULAR
+            assert "Singular matrix" in str(ei.value)
+            u, _ = good.osc(p, q, dq, t, dtype=dtype)  # the same thread's next call: nothing sticks
+            assert np.isfinite(u).all()
+    # non-finite inputs give non-finite outputs, not an error (numpy.linalg.inv does not raise on NaN either)
+    qn = q.copy()
+    qn[7, 1] = np.nan
+    u, _ = good.osc(laws[0], qn, dq, t)
+    assert np.isnan(u[7]).any() and np.isfinite(np.delete(u, 7, axis=0)).all()
+    # device pointers: the call is asynchronous, the flag is the device's and abrk_stream_sync reports it - once
+    s = a.Stream(0)
+    q_, dq_, t_ = (a.DeviceArray.from_numpy(x) for x in (q, dq, t))
+    engine.osc_generate(bad.arm_id, 6, laws[0], q_, dq_, t_, stream=s)
+    with pytest.raises(np.linalg.LinAlgError):
+        s.sync()
+    s.sync()
+    ud = engine.osc_generate(good.arm_id, 6, laws[0], q_, dq_, t_, stream=s)
+    s.sync()
+    assert np.array_equal(ud.numpy(), good.osc(laws[0], q, dq, t)[0])
+
+
 def test_gpu_python_api_drop_in():
     """robot_config / controller classes: reference shapes, dtypes and per-call state"""
     from abr_control_amd.arms import jaco2, threejoint, twojoint, ur5
@@ -1670,11 +1714,13 @@ def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
     np.savez(tmp_path / "in.npz", arm="ur5", q=q, dq=dq, t=t)
     (tmp_path / "run.py").write_text(_FORMS_SCRIPT)
     res = {}
-    forms = (("lane", dict(ABRK_FINISH_ROUNDS="0")),
-             ("wave", dict(ABRK_FINISH_ROUNDS="64", ABRK_FINISH_SLOTS="4")),
+    # (the switches are read only under ABRK_MEASUREMENT=1: csrc/abrk_kernels.h measurement_env)
+    forms = (("lane", dict(ABRK_MEASUREMENT="1", ABRK_FINISH_ROUNDS="0")),
+             ("wave", dict(ABRK_MEASUREMENT="1", ABRK_FINISH_ROUNDS="64", ABRK_FINISH_SLOTS="4")),
+             ("onepass", dict(ABRK_MEASUREMENT="1", ABRK_NO_DEFER="1")),  # the complete row program, no second pass at all
              ("default", {}))
     for name, sw in forms:
-        env = {k: v for k, v in os.environ.items() if not k.startswith("ABRK_FINISH_")}
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ABRK_FINISH_", "ABRK_MEASUREMENT", "ABRK_NO_"))}
         env.update(sw)
         r = subprocess.run([sys.executable, str(tmp_path / "run.py"), REPO, str(tmp_path / "in.npz"),
                             str(tmp_path / f"{name}.npz")], env=env, capture_output=True, text=True, timeout=900)
@@ -1683,6 +1729,8 @@ def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
     for k in res["lane"].files:
         assert np.array_equal(res["lane"][k], res["wave"][k], equal_nan=True), k
         assert np.array_equal(res["lane"][k], res["default"][k], equal_nan=True), k
+        # round 5: the complete row program hands its truncating rows to the same routine the finish kernel runs
+        assert np.array_equal(res["lane"][k], res["onepass"][k], equal_nan=True), k
     # ... and the truncating rows are there and right
     uo, _ = cases.OracleBackend("ur5").osc(_abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6), q[600:1100],
                                            dq[600:1100], t[600:1100])
@@ -1740,25 +1788,46 @@ def test_gpu_six_row_many_short_lived_streams():
     assert a.scratch_stats(0)["worklist_slots"] <= base["worklist_slots"] + 1
 
 
-def test_gpu_six_row_second_pass_forms_meet_at_the_batch_threshold():
-    """up to 65536 rows the six-row law hands records to the finish kernel, beyond it the second pass recomputes its
-    rows: a batch just above the threshold and its two halves (below it) agree to rounding on every row, and both meet
-    the oracle on a sample"""
+def test_gpu_six_row_bits_do_not_depend_on_the_batch_size():
+    """The six-row law runs one-pass below 64 rows, as first pass + finish kernel on hand-over records up to 65536 rows,
+    as first pass + recompute pass beyond.  Since round 5 every form hands a truncating row to ONE routine
+    (csrc/abrk_ctrl.h osc6_tail) and runs the same arithmetic around it (with and without a training signal among the
+    outputs): a batch just above the 65536-row threshold, its halves, 50-row slices of it (one-pass) and an uneven
+    sharded call return the same bits on every row - and meet the oracle on a sample."""
+    from abr_control_amd import engine
+
     be = cases.GpuBackend("ur5")
-    p = _abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6)
     B = 65536 + 128
     q, dq, t = draw(77, B, 6)
-    u_big, ts_big = be.osc(p, q, dq, t)
+    # near-singular postures among the first rows: truncating rows in every slice below
+    qs = cases.near_singular_postures("ur5", 200)
+    q[:len(qs)] = qs
     h = B // 2
-    u_a, ts_a = be.osc(p, q[:h], dq[:h], t[:h])
-    u_b, ts_b = be.osc(p, q[h:], dq[h:], t[h:])
-    u_h, ts_h = np.concatenate([u_a, u_b]), np.concatenate([ts_a, ts_b])
-    assert np.all(np.isfinite(u_big)) and np.all(np.isfinite(u_h))
-    # (different eigen-solver instantiations on the truncating rows: equal to rounding scaled by their conditioning)
-    assert np.median(cases.rel_err(u_big, u_h)) == 0.0
-    assert cases.rel_err(u_big, u_h).max() < 1e-7 and cases.rel_err(ts_big, ts_h).max() < 1e-7
-    uo, _ = cases.OracleBackend("ur5").osc(p, q[:1500], dq[:1500], t[:1500])
-    assert np.percentile(cases.rel_err(u_big[:1500], uo), 99) < 1e-9 and np.percentile(cases.rel_err(u_h[:1500], uo), 99) < 1e-9
+    for kw in (dict(kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6),
+               dict(kp=100, ko=60, kv=12, ctrlr_dof=[1, 1, 1, 1, 1, 0], use_C=True,
+                    null_controllers=[_abi.make_damping(5)])):
+        p = _abi.make_osc_params(6, **kw)
+        u_big, ts_big = be.osc(p, q, dq, t)                                    # recompute form
+        u_a, ts_a = be.osc(p, q[:h], dq[:h], t[:h])                            # hand-over form
+        u_b, ts_b = be.osc(p, q[h:], dq[h:], t[h:])
+        assert np.all(np.isfinite(u_big))
+        assert np.array_equal(u_big, np.concatenate([u_a, u_b])) and np.array_equal(ts_big, np.concatenate([ts_a, ts_b]))
+        for lo in (0, 50, 100, 150, h - 25, B - 50):                           # one-pass form (below one wavefront of rows)
+            u_s, ts_s = be.osc(p, q[lo:lo + 50], dq[lo:lo + 50], t[lo:lo + 50])
+            assert np.array_equal(u_s, u_big[lo:lo + 50]) and np.array_equal(ts_s, ts_big[lo:lo + 50]), lo
+        # no training signal among the outputs (the NOTS instantiations): the same u, bit for bit, in every form
+        u_nots = be.e.osc_generate(be.arm_id, 6, p, q, dq, t)
+        u_nots_h = np.concatenate([be.e.osc_generate(be.arm_id, 6, p, q[:h], dq[:h], t[:h]),
+                                   be.e.osc_generate(be.arm_id, 6, p, q[h:], dq[h:], t[h:])])
+        assert np.array_equal(u_nots, u_nots_h)
+        assert np.array_equal(be.e.osc_generate(be.arm_id, 6, p, q[:50], dq[:50], t[:50]), u_nots[:50])
+        # one call cut into uneven shards: 16 shards of ~4100 rows (hand-over), 1500 shards of ~43 rows (one-pass)
+        for n_sh in (16, 1500):
+            u_sh, ts_sh = engine.osc_generate_sharded(be.arm_id, 6, p, q, dq, t, [0] * n_sh, training_signal=True)
+            assert np.array_equal(u_sh, u_big) and np.array_equal(ts_sh, ts_big), n_sh
+        # (random rows: the near-singular postures in front are conditioned up to 1e13 - their own tests gate on that)
+        uo, _ = cases.OracleBackend("ur5").osc(p, q[300:1800], dq[300:1800], t[300:1800])
+        assert np.percentile(cases.rel_err(u_big[300:1800], uo), 99) < 1e-9
 
 
 _OBS_SCRIPT = r"""
@@ -1801,8 +1870,8 @@ def test_gpu_obstacles_redistributed_pairs_equal_one_pass_kernel(tmp_path):
     np.savez(tmp_path / "in.npz", **data)
     (tmp_path / "run.py").write_text(_OBS_SCRIPT)
     res = {}
-    for name, sw in (("lds", {}), ("plain", dict(ABRK_OBS_PLAIN="1"))):
-        env = {k: v for k, v in os.environ.items() if k != "ABRK_OBS_PLAIN"}
+    for name, sw in (("lds", {}), ("plain", dict(ABRK_MEASUREMENT="1", ABRK_OBS_PLAIN="1"))):
+        env = {k: v for k, v in os.environ.items() if k not in ("ABRK_OBS_PLAIN", "ABRK_MEASUREMENT")}
         env.update(sw)
         r = subprocess.run([sys.executable, str(tmp_path / "run.py"), REPO, str(tmp_path / "in.npz"),
                             str(tmp_path / f"{name}.npz")], env=env, capture_output=True, text=True, timeout=900)
