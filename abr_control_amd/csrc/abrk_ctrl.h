@@ -46,6 +46,9 @@ ABRK_INL void flag_singular(const OscP<T>& P, bool ok, const T (&Ms)[N * (N + 1)
   if (!ok && P.status) {
     T sum = Ms[0];
     sfor<N*(N + 1) / 2 - 1>([&](auto e) ABRK_LAMBDA { sum += Ms[e() + 1]; });
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(sum));  // (what the optimiser knows of a finite-math sum - "never NaN" - must not fold the test)
+#endif
     bool finite;
     if constexpr (sizeof(T) == 8) finite = ((__builtin_bit_cast(unsigned long long, sum) >> 52) & 0x7ffull) != 0x7ffull;
     else finite = ((__builtin_bit_cast(unsigned, sum) >> 23) & 0xffu) != 0xffu;
@@ -993,7 +996,13 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
     if (truncates) {
       T S[KM * (KM + 1) / 2], V[KM][KM], lam[KM];
       sfor<KM*(KM + 1) / 2>([&](auto e) ABRK_LAMBDA { S[e()] = Am[e()]; });
-      jacobi_eig<KM>(S, V, lam);
+      // x,y,z in fp64: the direct 3 x 3 decomposition (no sweeps, ~250 instructions).  The rows that really truncate are
+      // < 0.01 % of random states, but each runs on a lone lane while its wavefront waits: with the Jacobi sweeps such a
+      // wavefront lived 4.4 us instead of 2.5 (UR5, 4096 rows) and 9.2 instead of <= 7.9 us in the 131072-row shard of
+      // BASELINE config 4, where the ~13 of them ARE the kernel's tail (profiles/round5/shard_step_timeline.md).
+      // (No row is masked in the FAST forms, so the order sym3_eig leaves the pairs in does not matter.)
+      if constexpr (FAST && KM == 3 && sizeof(T) == 8) sym3_eig(S, V, lam);
+      else jacobi_eig<KM>(S, V, lam);
       T smax = T(0);
       sfor<KM>([&](auto r) ABRK_LAMBDA {
         // a masked row r is an isolated unit diagonal: Jacobi never rotates it, so eigenpair r

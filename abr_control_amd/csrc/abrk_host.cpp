@@ -855,6 +855,14 @@ int finish_slots_for(int64_t B) {
   static const int forced = env_int("ABRK_FINISH_SLOTS", 0);
   return forced >= 1 && forced <= kBlock ? forced : finish_slots((long)B);
 }
+// chunks per group of the grouped finish kernel (abrk_law.hip osc6_finish_group_kernel), 0 = the per-chunk kernel: the
+// 16384-row band, where the per-chunk grid doubles working wavefronts up on SIMDs
+int finish_group_for(int64_t B) {
+  static const int forced = env_int("ABRK_FINISH_GROUP", -1);  // measurement switch: 0 = never grouped, 1..16 = always
+  if (forced >= 0 && forced <= 16) return forced;
+  const int64_t nchunk = (B + kBlock - 1) / kBlock;
+  return nchunk > 128 && nchunk <= 256 ? 16 : 0;
+}
 int finish_rounds_for(int64_t B) {
   static const int forced = env_int("ABRK_FINISH_ROUNDS", -1);  // (0: every chunk goes one record per lane)
   return forced >= 0 ? (forced > kBlock ? kBlock : forced) : finish_rounds((long)B);
@@ -1021,7 +1029,7 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
   const hipStream_t hs = (hipStream_t)stream;
   // hand-over mode: the arm's first pass, then the arm-independent finish kernel on the records it left
   FinishArgs fa{oa.wl, oa.rec, (P->n_null > 0 || u_null_ext) ? 1 : 0, finish_slots_for(B), finish_rounds_for(B),
-                oa.u, oa.ts};
+                oa.u, oa.ts, finish_group_for(B)};
   const int rc = dispatch(st, a, dtype, [=](const void* rt) {
     OscArgs o = oa;
     o.P = dtype == ABRK_F64 ? (const void*)&p64 : (const void*)&p32;

@@ -360,7 +360,7 @@ __device__ __forceinline__ void pin_loaded(T& v) {
 template <int N, class T>
 __global__ void __launch_bounds__(kBlock)
 osc6_finish_kernel(const unsigned long long* __restrict__ masks, const T* __restrict__ recs, int nulls, int coop_rounds,
-                   T* __restrict__ ug, T* __restrict__ tsg) {
+                   long B, T* __restrict__ ug, T* __restrict__ tsg) {
   const int lane = (int)threadIdx.x;
   const long j = blockIdx.x;
   const int s0 = (int)blockIdx.y, slots = (int)gridDim.y;
@@ -392,7 +392,9 @@ osc6_finish_kernel(const unsigned long long* __restrict__ masks, const T* __rest
   if (s0 >= cnt) return;  // nothing in this slot
   if (cnt <= coop_rounds * slots) {
     for (int s = s0;;) {
-      const long b = (long)ridx;
+      // (a record's row index is data: whatever a slot holds, nothing is stored outside [0, B))
+      const bool row_ok = ridx >= T(0) && ridx < T(B);
+      const long b = row_ok ? (long)ridx : 0;
       {
 #pragma clang fp contract(off)  // the same bits as osc6_finish_row
         T wv[6];
@@ -403,7 +405,7 @@ osc6_finish_kernel(const unsigned long long* __restrict__ masks, const T* __rest
           a1 = Rm<T>::fma(G[0][i()], wv[i()] * gu, a1);
           a2 = Rm<T>::fma(G[0][i()], wv[i()] * gw, a2);
         });
-        if (lane < N) {
+        if (lane < N && row_ok) {
           const T ts = b1 - a1;
           ug[b * N + lane] = ts + b2 - (nulls ? a2 : T(0));
           if (tsg) tsg[b * N + lane] = ts;
@@ -416,11 +418,14 @@ osc6_finish_kernel(const unsigned long long* __restrict__ masks, const T* __rest
     }
   } else if (s0 == 0 && lane < cnt) {
     rec = recs + (j * kBlock + lane) * rec_len(N);
-    const long b = (long)rec[21];
-    T u[N], ts[N];
-    osc6_finish_row<N, T>(rec, nulls != 0, u, ts);
-    store_row<N>(ug, b, u);
-    if (tsg) store_row<N>(tsg, b, ts);
+    const T rix = rec[21];
+    if (rix >= T(0) && rix < T(B)) {
+      const long b = (long)rix;
+      T u[N], ts[N];
+      osc6_finish_row<N, T>(rec, nulls != 0, u, ts);
+      store_row<N>(ug, b, u);
+      if (tsg) store_row<N>(tsg, b, ts);
+    }
   }
 }
 // Wavefronts per chunk and records a wavefront takes at most, by batch size (random UR5 states with all six task rows:
@@ -517,6 +522,7 @@ struct FinishArgs {
   int slots;        // wavefronts per 64-row chunk (finish_slots)
   int coop_rounds;  // records a wavefront takes at most; a chunk with more than slots x coop_rounds goes one record per lane
   void *u, *ts;
+  int group = 0;    // > 0: the grouped form - `group` chunks share 4 x group wavefronts (abrk_law.hip osc6_finish_group_kernel)
 };
 // (abrk_law.hip; arm-independent: the record holds everything)
 hipError_t launch_osc6_finish(int n_joints, int dtype, const LaunchArgs& la, const FinishArgs& a);
@@ -605,6 +611,7 @@ obstacles_lds_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __re
     const int total = __builtin_amdgcn_readlane(incl, kBlock - 1);
     const int pre = incl - cnt;
     const int shared = total < kObsPairCap ? total : kObsPairCap;  // pairs [0, shared) are redistributed
+    unsigned long long overflow = 0ull;
     {
       int p = pre;
       unsigned long long bits = heavy;
@@ -613,14 +620,7 @@ obstacles_lds_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __re
         bits &= bits - 1;
         pairs[p++] = (unsigned short)(lane | (slot << 6));
       }
-      // (what does not fit the list - a wavefront with more than 32 heavy pairs per row on average - stays with its row)
-      while (bits) {
-        const int slot = __builtin_ctzll(bits);
-        bits &= bits - 1;
-        T c[N];
-        obstacles_pair<N, T>(P, slot, [&](int f) ABRK_LAMBDA { return rec[f * kBlock + lane]; }, c);
-        sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += c[i()]; });
-      }
+      overflow = bits;
     }
     __syncthreads();
     for (int r0 = 0; r0 < shared; r0 += kBlock) {
@@ -636,6 +636,16 @@ obstacles_lds_kernel(A arm, ObsP<T> P, long B, const T* __restrict__ qg, T* __re
       const int lo = pre > r0 ? pre : r0, hi = (pre + cnt < r0 + kBlock ? pre + cnt : r0 + kBlock) < shared ? (pre + cnt < r0 + kBlock ? pre + cnt : r0 + kBlock) : shared;
       for (int pp = lo; pp < hi; pp++) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += contrib[(pp - r0) * N + i()]; });
       __syncthreads();
+    }
+    // what did not fit the list (a wavefront with more than 32 heavy pairs per row on average) stays with its row - its
+    // HIGH slots, added after the redistributed low ones: the slot order of the one-pass kernel (the records in LDS are
+    // untouched until the next block of rows)
+    while (overflow) {
+      const int slot = __builtin_ctzll(overflow);
+      overflow &= overflow - 1;
+      T c[N];
+      obstacles_pair<N, T>(P, slot, [&](int f) ABRK_LAMBDA { return rec[f * kBlock + lane]; }, c);
+      sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] += c[i()]; });
     }
     if (in) {
       obstacles_finish<N, T>(P, u);

@@ -19,15 +19,97 @@ hipError_t launch_osc_law(int n, int dtype, const LaunchArgs& la, const LawArgs&
 #undef ABRK_CASE
   return hipErrorInvalidValue;
 }
+// ---- finish kernel, grouped form (round 5): the batch sizes where the per-chunk grid (chunks x slots) puts two WORKING
+// wavefronts on one SIMD.  At 16384 rows 256 chunks x 4 slots fill the 1024 SIMDs, and the wavefront of slot s >= 4 lands
+// on the SIMD of slot s - 4 of the same chunk - busy whenever the chunk holds five records or more (17 % of the chunks of
+// random UR5 states): the kernel then lasts 12.0 us instead of 8.2 (profiles/round4/finish_per_chunk).  Here a GROUP of
+// `gc` consecutive chunks shares 4 gc wavefronts: every wavefront reads the group's masks (one 8-byte value per lane,
+// one coalesced request), numbers the group's records through - a pure function of the masks: no atomics, no counters -
+// and wavefront i takes records i, i + 4 gc, ...: 46 +- 7 records on 64 wavefronts for gc = 16, so a second round is
+// rare (0.6 % of the groups) where the per-chunk rule needed a fifth slot for every sixth chunk.  The price is the
+// dependent chain mask -> record (one more memory round trip, ~0.8 us), which is why the smaller batches - every
+// (chunk, slot) has a SIMD of its own there - keep the per-chunk form.  Same arithmetic, same bits.
+// A group with more records than `coop_max`: one record per lane, wavefront i < gc takes chunk i of the group.
+template <int N, class T>
+__global__ void __launch_bounds__(kBlock)
+osc6_finish_group_kernel(const unsigned long long* __restrict__ masks, const T* __restrict__ recs, int nulls, int gc,
+                         long nchunk, int coop_max, long B, T* __restrict__ ug, T* __restrict__ tsg) {
+  const int lane = (int)threadIdx.x;
+  const long c0 = (long)blockIdx.x * gc;
+  const int wi = (int)blockIdx.y, wg = (int)gridDim.y;
+  unsigned long long m = 0ull;
+  if (lane < gc && c0 + lane < nchunk) m = masks[c0 + lane];
+  const int cnt = __popcll(m);
+  int incl = cnt;
+  for (int d = 1; d < kBlock; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if (lane >= d) incl += v;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, kBlock - 1);
+  if (wi >= total) return;
+  const int c = lane < N + 2 ? lane : N + 1;  // (idle lanes shadow the last column)
+  const int jc = lane < N ? lane : 0;
+  if (total <= coop_max) {
+    for (int r = wi; r < total; r += wg) {
+      const unsigned long long above = __ballot(incl > r);  // the chunk that holds record r: the first lane whose count passes it
+      const int ch = __builtin_ctzll(above);
+      const int k = r - (__builtin_amdgcn_readlane(incl, ch) - __builtin_amdgcn_readlane(cnt, ch));
+      const T* rec = recs + ((c0 + ch) * kBlock + k) * rec_len(N);
+      T S[21], G[1][6];
+      osc6_rec_load<N, T, 1>(rec, c, S, G);
+      const T rix = rec[21];
+      const bool row_ok = rix >= T(0) && rix < T(B);  // (a record's row index is data: nothing is stored outside [0, B))
+      const long b = row_ok ? (long)rix : 0;
+      const T b1 = rec[rec_off_b1(N) + jc], b2 = rec[rec_off_b1(N) + N + jc];
+      {
+#pragma clang fp contract(off)  // the same bits as osc6_tail / osc6_finish_kernel
+        T wv[6];
+        osc6_rec_solve<N, T, 1, true>(rec, c, S, G, wv);
+        T a1 = T(-0.0), a2 = T(-0.0);
+        sfor<6>([&](auto i) ABRK_LAMBDA {
+          const T gu = lane_bcast(G[0][i()], N), gw = lane_bcast(G[0][i()], N + 1);
+          a1 = Rm<T>::fma(G[0][i()], wv[i()] * gu, a1);
+          a2 = Rm<T>::fma(G[0][i()], wv[i()] * gw, a2);
+        });
+        if (lane < N && row_ok) {
+          const T ts = b1 - a1;
+          ug[b * N + lane] = ts + b2 - (nulls ? a2 : T(0));
+          if (tsg) tsg[b * N + lane] = ts;
+        }
+      }
+    }
+  } else if (wi < gc && c0 + wi < nchunk) {
+    const int mine = __builtin_amdgcn_readlane(cnt, wi);
+    if (lane < mine) {
+      const T* rec = recs + ((c0 + wi) * kBlock + lane) * rec_len(N);
+      const T rix = rec[21];
+      if (rix >= T(0) && rix < T(B)) {
+        T u[N], ts[N];
+        osc6_finish_row<N, T>(rec, nulls != 0, u, ts);
+        store_row<N>(ug, (long)rix, u);
+        if (tsg) store_row<N>(tsg, (long)rix, ts);
+      }
+    }
+  }
+}
 template <int N, class T>
 static hipError_t finish_launch(const LaunchArgs& la, const FinishArgs& a) {
   const unsigned nchunk = (unsigned)((la.B + kBlock - 1) / kBlock);
+  if (a.group > 0) {
+    // grouped form: four wavefronts per chunk; a group with more than coop_rounds x its wavefronts goes one record per lane
+    const int gc = a.group, wg = 4 * gc;
+    hipLaunchKernelGGL((osc6_finish_group_kernel<N, T>), dim3((nchunk + gc - 1) / gc, (unsigned)wg), dim3(kBlock), 0,
+                       la.stream, (const unsigned long long*)a.masks, (const T*)a.rec, a.nulls, gc, (long)nchunk,
+                       a.coop_rounds * wg, la.B, (T*)a.u, (T*)a.ts);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((osc6_finish_kernel<N, T>), dim3(nchunk, (unsigned)a.slots), dim3(kBlock), 0, la.stream,
-                     (const unsigned long long*)a.masks, (const T*)a.rec, a.nulls, a.coop_rounds, (T*)a.u, (T*)a.ts);
+                     (const unsigned long long*)a.masks, (const T*)a.rec, a.nulls, a.coop_rounds, la.B, (T*)a.u, (T*)a.ts);
   return hipGetLastError();
 }
 hipError_t launch_osc6_finish(int n, int dtype, const LaunchArgs& la, const FinishArgs& a) {
-  if (a.slots < 1 || a.slots > kBlock || la.B < 1 || la.B > kHandoverMaxRows) return hipErrorInvalidValue;
+  // (group: at most 16 chunks - four wavefronts per chunk - so that one lane per chunk holds the group's masks)
+  if (a.slots < 1 || a.slots > kBlock || a.group < 0 || a.group > 16 || la.B < 1 || la.B > kHandoverMaxRows) return hipErrorInvalidValue;
 #define ABRK_CASE(NN) \
   case NN:            \
     return dtype == 0 ? finish_launch<NN, double>(la, a) : finish_launch<NN, float>(la, a);

@@ -226,8 +226,10 @@ class Runner:
             b = lambda v: "true" if v else "false"
             # six task rows: first pass (PASS = 1, the dominant kernel) + a second pass for the rows whose pseudo-inverse
             # truncates - 64 ... 65536 rows the finish kernel on hand-over records (osc6_finish_kernel), beyond that the
-            # complete row program once more (PASS = 0); ABRK_NO_HANDOVER=1: the round-3 scheme (inline below 16 k rows)
-            six_two_pass = (not fast) and (self.B >= 16384 or not os.environ.get("ABRK_NO_HANDOVER"))
+            # complete row program once more (PASS = 0); ABRK_MEASUREMENT=1 ABRK_NO_HANDOVER=1: the round-3 scheme (inline
+            # below 16 k rows)
+            no_handover = os.environ.get("ABRK_MEASUREMENT") == "1" and os.environ.get("ABRK_NO_HANDOVER")
+            six_two_pass = (not fast) and (self.B >= 16384 or not no_handover)
             km = 3 if fast else (2 if dof == [1, 1, 0, 0, 0, 0] and self.n <= 3 and p.ref_frame == 2 * self.n + 1 else 6)
             # ... and, the bench never asking for the training signal, the plain law's first pass is the NOTS variant
             nots = six_two_pass and not p.n_null and not os.environ.get("ABRK_BENCH_TS")
@@ -243,23 +245,22 @@ class Runner:
             return f"limits_kernel<{self.n}, {t}>"
         if k == "rollout":
             return f"rollout_kernel<{arm}, {t}, {'true' if self.params.use_C else 'false'}>"
-        if k == "obstacles" and self.arm in ("ur5", "threejoint") and not os.environ.get("ABRK_OBS_PLAIN"):
+        obs_plain = os.environ.get("ABRK_MEASUREMENT") == "1" and os.environ.get("ABRK_OBS_PLAIN")
+        if k == "obstacles" and self.arm in ("ur5", "threejoint") and not obs_plain:
             return f"obstacles_lds_kernel<{arm}, {t}>"  # orthogonal chains: heavy pairs redistributed through LDS
         return f"{k}_kernel<{arm}, {t}>"
 
     def grid_threads(self):
         """threads of the dominant kernel's launch (grid x 64), as rocprofv3's Grid_Size prints it: the grid-stride
         kernels cap their grid, so rows != threads for them (abrk_kernels.h: kSlidingMaxBlocks, kObstaclesMaxBlocks,
-        ABRK_KM6_GRID_CAP) - tools/summarize_profiles.py maps (kernel, Grid_Size) back to rows through this"""
+        kKm6GridCap) - tools/summarize_profiles.py maps (kernel, Grid_Size) back to rows through this"""
         blocks = (self.B + 63) // 64
         if self.kind == "sliding":
             blocks = min(blocks, 256 * 32 * 4)
         elif self.kind == "obstacles":
             blocks = min(blocks, 4096)
-        elif (self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name()
-              and (self.arm == "jaco2" or (self.B >= 16384 and os.environ.get("ABRK_BENCH_KM6_P1_LOOP")))):
-            # the six-row first pass of a general chain (Jaco2: one wave per SIMD) is a persistent grid; so is every
-            # first pass of a library built with -DABRK_KM6_P1_LOOP=1
+        elif self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name() and self.arm == "jaco2":
+            # the six-row first pass of a general chain (Jaco2: one wave per SIMD) is a persistent grid
             blocks = min(blocks, 4096)
         return blocks * 64
 

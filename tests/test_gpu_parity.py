@@ -1718,9 +1718,12 @@ def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
     forms = (("lane", dict(ABRK_MEASUREMENT="1", ABRK_FINISH_ROUNDS="0")),
              ("wave", dict(ABRK_MEASUREMENT="1", ABRK_FINISH_ROUNDS="64", ABRK_FINISH_SLOTS="4")),
              ("onepass", dict(ABRK_MEASUREMENT="1", ABRK_NO_DEFER="1")),  # the complete row program, no second pass at all
+             # the grouped finish kernel (the 16384-row band's default): 16 and 3 chunks per group
+             ("group16", dict(ABRK_MEASUREMENT="1", ABRK_FINISH_GROUP="16")),
+             ("group3", dict(ABRK_MEASUREMENT="1", ABRK_FINISH_GROUP="3", ABRK_FINISH_ROUNDS="64")),
              ("default", {}))
     for name, sw in forms:
-        env = {k: v for k, v in os.environ.items() if not k.startswith(("ABRK_FINISH_", "ABRK_MEASUREMENT", "ABRK_NO_"))}
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ABRK_FINISH_", "ABRK_MEASUREMENT", "ABRK_NO_"))}  # noqa: E501
         env.update(sw)
         r = subprocess.run([sys.executable, str(tmp_path / "run.py"), REPO, str(tmp_path / "in.npz"),
                             str(tmp_path / f"{name}.npz")], env=env, capture_output=True, text=True, timeout=900)
@@ -1731,6 +1734,8 @@ def test_gpu_six_row_finish_forms_agree_bitwise(tmp_path):
         assert np.array_equal(res["lane"][k], res["default"][k], equal_nan=True), k
         # round 5: the complete row program hands its truncating rows to the same routine the finish kernel runs
         assert np.array_equal(res["lane"][k], res["onepass"][k], equal_nan=True), k
+        assert np.array_equal(res["lane"][k], res["group16"][k], equal_nan=True), k
+        assert np.array_equal(res["lane"][k], res["group3"][k], equal_nan=True), k
     # ... and the truncating rows are there and right
     uo, _ = cases.OracleBackend("ur5").osc(_abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6), q[600:1100],
                                            dq[600:1100], t[600:1100])
@@ -1812,6 +1817,10 @@ def test_gpu_six_row_bits_do_not_depend_on_the_batch_size():
         u_b, ts_b = be.osc(p, q[h:], dq[h:], t[h:])
         assert np.all(np.isfinite(u_big))
         assert np.array_equal(u_big, np.concatenate([u_a, u_b])) and np.array_equal(ts_big, np.concatenate([ts_a, ts_b]))
+        # 16384 rows: the grouped finish kernel (16 chunks share 64 wavefronts); 12000 rows: a partial last group
+        for nb in (16384, 12000):
+            u_g, ts_g = be.osc(p, q[:nb], dq[:nb], t[:nb])
+            assert np.array_equal(u_g, u_big[:nb]) and np.array_equal(ts_g, ts_big[:nb]), nb
         for lo in (0, 50, 100, 150, h - 25, B - 50):                           # one-pass form (below one wavefront of rows)
             u_s, ts_s = be.osc(p, q[lo:lo + 50], dq[lo:lo + 50], t[lo:lo + 50])
             assert np.array_equal(u_s, u_big[lo:lo + 50]) and np.array_equal(ts_s, ts_big[lo:lo + 50]), lo
