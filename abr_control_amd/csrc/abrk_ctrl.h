@@ -46,12 +46,23 @@ ABRK_INL void flag_singular(const OscP<T>& P, bool ok, const T (&Ms)[N * (N + 1)
   if (!ok && P.status) {
     T sum = Ms[0];
     sfor<N*(N + 1) / 2 - 1>([&](auto e) ABRK_LAMBDA { sum += Ms[e() + 1]; });
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(sum));  // (what the optimiser knows of a finite-math sum - "never NaN" - must not fold the test)
-#endif
+    // (the bit pattern goes through an opaque INTEGER: under -ffinite-math-only every floating-point value of the
+    //  function counts as "never NaN / Inf" - an exponent test on the sum itself, even on one that came out of an asm
+    //  statement, is folded to "finite")
     bool finite;
-    if constexpr (sizeof(T) == 8) finite = ((__builtin_bit_cast(unsigned long long, sum) >> 52) & 0x7ffull) != 0x7ffull;
-    else finite = ((__builtin_bit_cast(unsigned, sum) >> 23) & 0xffu) != 0xffu;
+    if constexpr (sizeof(T) == 8) {
+      unsigned long long bits = __builtin_bit_cast(unsigned long long, sum);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(bits));
+#endif
+      finite = ((bits >> 52) & 0x7ffull) != 0x7ffull;
+    } else {
+      unsigned bits = __builtin_bit_cast(unsigned, sum);
+#if defined(__HIP_DEVICE_COMPILE__)
+      asm volatile("" : "+v"(bits));
+#endif
+      finite = ((bits >> 23) & 0xffu) != 0xffu;
+    }
     if (finite) *P.status = 1;
   }
 }

@@ -216,6 +216,14 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 #endif
   __shared__ T sctab[2 * kSinCosN];
   const int lane = (int)threadIdx.x;
+  // x,y,z kernels: the row's inputs are requested BEFORE the table fill - table and inputs come back in one memory round
+  // trip instead of two in a row (profiles/round5/shard_step_timeline.md: 0.13 us + 0.2 us of a 2.5 us wavefront at 4096
+  // rows, where one wavefront per SIMD hides nothing)
+  OscPre<T, A::N> pre;
+  const long b_xyz = (long)blockIdx.x * kBlock + threadIdx.x;
+  if constexpr (KM <= 3) {
+    if (b_xyz < B) osc_prefetch<A, T, KM, USE_C, FEAT>(b_xyz, qg, dqg, tg, pre);
+  }
   load_sincos_table(sctab, lane);  // every lane takes part: before any exit
 #if defined(ABRK_TIMELINE)
   const unsigned long long tl_tab = __builtin_amdgcn_s_memrealtime();
@@ -226,7 +234,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
     auto go = [&](auto& scr) ABRK_LAMBDA {
 #if defined(ABRK_TIMELINE)
       if constexpr (KM <= 3) {  // stamps 0 .. 7 of this wavefront leave through `wl` (unused by the x,y,z kernels)
-        osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+        osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr, &pre);
         ABRK_STAMP(scr, 5, false);
         ABRK_STAMP(scr, 6, true);
         scr.tl[0] = tl_entry;
@@ -239,6 +247,10 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
         return false;
       }
 #endif
+      if constexpr (KM <= 3) {  // (inputs requested ahead of the table fill, above)
+        osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr, &pre);
+        return false;
+      }
       scr.allow_defer = allow_defer;
       if (allow_defer) {  // where a deferring row parks itself (ScratchBase::claim, called by the law)
         scr.wl = wl;
@@ -311,9 +323,8 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       if (mode == 1) note(i - threadIdx.x, deferred);
     }
   } else {
-    const long b = (long)blockIdx.x * kBlock + threadIdx.x;
-    if (b >= B) return;
-    row(b, false);
+    if (b_xyz >= B) return;
+    row(b_xyz, false);
   }
 }
 

@@ -137,15 +137,33 @@ ABRK_INL void dyn_body(long b, bool active, St& st, const A& arm, int frame, int
 
 // ---- OSC.generate for B states (osc.py:217-320)
 // `scr`: per-lane scratch of the Coriolis recursion (RegScratch, or the wavefront's LDS slab on the GPU)
+// the inputs a kernel may request AHEAD of osc_body (before its sin/cos table fill: the x,y,z kernels - one memory round
+// trip for table and inputs together instead of two in a row, which a lone wavefront per SIMD cannot hide)
+template <class T, int N>
+struct OscPre {
+  T q[N], dq[N], tgt[6];
+};
+// which of them osc_body would itself request up front (the rest it asks for after the kinematics)
+template <int KM, int FEAT>
+constexpr bool osc_pre_all() { return FEAT < 2 && KM <= 3; }
+template <class A, class T, int KM, bool USE_C, int FEAT>
+ABRK_INL void osc_prefetch(long b, const T* __restrict__ qg, const T* __restrict__ dqg, const T* __restrict__ tg,
+                           OscPre<T, A::N>& pre) {
+  load_row<A::N>(qg, b, pre.q);
+  if constexpr (USE_C || osc_pre_all<KM, FEAT>()) load_row<A::N>(dqg, b, pre.dq);
+  if constexpr (osc_pre_all<KM, FEAT>()) load_row<6>(tg, b, pre.tgt);
+}
 template <class A, class T, int KM, bool USE_C, int FEAT, class Scr>
 ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
-           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, Scr& scr) {
+           const T* __restrict__ uneg, T* __restrict__ ug, T* __restrict__ tsg, Scr& scr,
+           const OscPre<T, A::N>* pre = nullptr) {
   constexpr int N = A::N;
   T q[N], dq[N], tgt[6], tv[6], ierr[6], une[N], u[N], ts[N];
   const bool tv_given = FEAT >= 2 && tvg != nullptr, have_ierr = FEAT >= 2 && ierrg != nullptr,
              have_ext = FEAT >= 2 && uneg != nullptr;
-  load_row<N>(qg, b, q);
+  if (pre) sfor<N>([&](auto i) ABRK_LAMBDA { q[i()] = pre->q[i()]; });
+  else load_row<N>(qg, b, q);
   // FEAT=false: every input is requested up front (one HBM round trip; 36 extra registers still
   // fit the two-waves-per-SIMD budget).  FEAT=true: the optional inputs are requested after the
   // kinematics to keep that kernel's register peak down.
@@ -157,8 +175,14 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // (requesting the target after the kinematics in the use_C kernels was measured unnecessary once the link wrenches
   //  of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
   constexpr bool EARLY_T = EARLY;
-  if constexpr (USE_C || EARLY) load_row<N>(dqg, b, dq);
-  if constexpr (EARLY_T) load_row<6>(tg, b, tgt);
+  if (pre) {
+    static_assert(KM > 3 || EARLY == osc_pre_all<KM, FEAT>(), "osc_prefetch requests what osc_body would");
+    if constexpr (USE_C || EARLY) sfor<N>([&](auto i) ABRK_LAMBDA { dq[i()] = pre->dq[i()]; });
+    if constexpr (EARLY_T) sfor<6>([&](auto r) ABRK_LAMBDA { tgt[r()] = pre->tgt[r()]; });
+  } else {
+    if constexpr (USE_C || EARLY) load_row<N>(dqg, b, dq);
+    if constexpr (EARLY_T) load_row<6>(tg, b, tgt);
+  }
   auto late = [&]() ABRK_LAMBDA {
     if constexpr (!USE_C && !EARLY) load_row<N>(dqg, b, dq);
     if constexpr (!EARLY_T) load_row<6>(tg, b, tgt);
