@@ -42,9 +42,9 @@ FP64_VALU_PEAK_TF = 78.6   # = 1/2 of the 157.3 TF fp32 vector peak
 ISSUE_PEAK_NOMINAL = {"f64": 1024 * 16 * 2.4e9, "f32": 1024 * 32 * 2.4e9}
 # committed rocprofv3 evidence.  (Earlier rounds are not consulted: kernel names changed - a template parameter was added -
 # and round 2's traffic.json keyed the grid-stride kernels by grid threads instead of rows.)
-PROFILE_DIRS = ("round4", "round3")
+PROFILE_DIRS = ("round5", "round4", "round3")
 # the reference's own Cython path timed on a GPU box's host (cpu_baseline fallback where no staged reference travels)
-BASELINE_DIRS = ("round4", "round3", "round2")
+BASELINE_DIRS = ("round5", "round4", "round3", "round2")
 
 WORKLOADS = {
     # name: (arm, batch per GPU, dtype, kind, params kwargs, algorithmic flops per eval)

@@ -58,14 +58,15 @@ def rows_for(kernel, grid):
         return ROWS[(kn, int(grid))]
     # the six-row law's second pass (PASS = 0 at a fixed 2048-block grid) belongs to the leg of its first pass
     # (PASS = 1, with or without the training-signal output)
-    if kn.startswith("osc_kernel<") and kn.endswith(",0,false>") and int(grid) == 8 * 256 * 64:
-        stem = kn[: -len(",0,false>")]
+    # (since round 5 the second pass carries the first pass's NOTS flag: <.., 1, true> goes with <.., 0, true>)
+    if kn.startswith("osc_kernel<") and kn.endswith((",0,false>", ",0,true>")) and int(grid) == 8 * 256 * 64:
+        stem = kn[: kn.rindex(",0,")]
         big = [b for (k, g), b in ROWS.items() if k in (stem + ",1,true>", stem + ",1,false>")]
         if big:
             return max(big)
     return int(grid)
 lines = ["# rocprofv3 evidence (MI355X, ROCm 7.2)", "",
-         f"Commands: `{os.environ.get('ABRK_PROFILE_SCRIPT', 'tools/gpu_profiles_r4.sh')}` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
+         f"Commands: `{os.environ.get('ABRK_PROFILE_SCRIPT', 'tools/gpu_profiles_r5.sh')}` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
          "`--pmc` passes as MI355X_MICROARCH.md prescribes).  `FETCH_SIZE`/`WRITE_SIZE` are in KiB; on gfx950 "
          "FETCH_SIZE counts 64 B per 128-B request, so read bytes = FETCH_SIZE x 1024 x 2.", ""]
 for f in ("pytest_gpu.log", "smoke.log", "coop_ab.md", "rt_ab.md", "valu_rates.txt", "host.txt", "osc6_step_trace.txt"):
@@ -115,8 +116,9 @@ if os.path.exists(ks):
             mean_us = sel["dur"].mean() / 1e3
             extra = 0.0
             if kn.startswith("osc_kernel<") and kn.endswith((",1,true>", ",1,false>")):  # + the dense second pass of the same calls
-                stem = kn[: kn.rindex(",1,")]
-                s2 = kt[(kt["kernel"].str.replace(" ", "") == (stem + ",0,false>")[:90]) & (kt["Grid_Size_X"] == 8 * 256 * 64)]
+                stem, tail = kn[: kn.rindex(",1,")], kn[kn.rindex(",1,") + 3:]  # tail: "true>" / "false>" (NOTS)
+                s2 = kt[(kt["kernel"].str.replace(" ", "").isin([(stem + ",0," + tail)[:90], (stem + ",0,false>")[:90]]))
+                        & (kt["Grid_Size_X"] == 8 * 256 * 64)]
                 if not s2.empty:
                     extra = s2["dur"].mean() / 1e3
             frac = leg["batch"] * leg["bytes_per_eval"] / ((mean_us + extra) * 1e-6) / 8e12
