@@ -830,7 +830,9 @@ def main():
     if world > 1:
         from abr_control_amd.sharding import HostGroup
 
-        group = HostGroup(rank, world)
+        # (generous: rank 0 runs its single-GPU legs - HBM-sized roofline, six-row law, shard sweep - alone while the
+        #  other ranks already wait at the closing barrier)
+        group = HostGroup(rank, world, timeout=1800.0)
         group.barrier()
 
     if args.dry_run:

@@ -239,3 +239,16 @@ def test_config_copies_take_their_own_registry_handle(L):
         assert L.abrk_arm_get_desc(first, C.byref(back)) == 0 and back.n_joints == 3  # ... the original's is not
     rc.close()
     assert L.abrk_arm_get_desc(first, C.byref(back)) == -4
+
+
+def test_error_codes_match_the_header_and_singular_is_a_linalg_error():
+    """include/abrk_types.h's error enum against the Python table; ABRK_ESINGULAR surfaces as numpy.linalg.LinAlgError -
+    what the reference's np.linalg.inv(M) raises (controllers/osc.py:136) - and still as an AbrkError"""
+    from abr_control_amd._lib import AbrkError, SingularMatrixError
+
+    txt = open(os.path.join(REPO, "include", "abrk_types.h")).read()
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"ABRK_(E[A-Z]+)\s*=\s*(-\d+)", txt)}
+    assert codes == {v: k for k, v in _abi.ERRORS.items()}
+    assert codes["ESINGULAR"] == _abi.ESINGULAR == -6
+    e = SingularMatrixError(_abi.ESINGULAR, "Singular matrix")
+    assert isinstance(e, np.linalg.LinAlgError) and isinstance(e, AbrkError) and e.code == -6 and "ESINGULAR" in str(e)
