@@ -39,34 +39,14 @@ struct OscP {
   int* status;
 };
 // (a plain store of 1 by however many rows: benign race, rare branch).  A non-finite M - NaN / Inf joint angles - is not
-// "singular": numpy.linalg.inv returns NaNs for it without raising, and so do the kernels.  The test reads the bit
-// pattern of the entries' sum (non-finite as soon as one entry is): -ffinite-math-only leaves integer compares alone.
-template <int N, class T>
-ABRK_INL void flag_singular(const OscP<T>& P, bool ok, const T (&Ms)[N * (N + 1) / 2]) {
-  if (!ok && P.status) {
-    T sum = Ms[0];
-    sfor<N*(N + 1) / 2 - 1>([&](auto e) ABRK_LAMBDA { sum += Ms[e() + 1]; });
-    // (the bit pattern goes through an opaque INTEGER: under -ffinite-math-only every floating-point value of the
-    //  function counts as "never NaN / Inf" - an exponent test on the sum itself, even on one that came out of an asm
-    //  statement, is folded to "finite")
-    bool finite;
-    if constexpr (sizeof(T) == 8) {
-      unsigned long long bits = __builtin_bit_cast(unsigned long long, sum);
-#if defined(__HIP_DEVICE_COMPILE__)
-      asm volatile("" : "+v"(bits));
-#endif
-      finite = ((bits >> 52) & 0x7ffull) != 0x7ffull;
-    } else {
-      unsigned bits = __builtin_bit_cast(unsigned, sum);
-#if defined(__HIP_DEVICE_COMPILE__)
-      asm volatile("" : "+v"(bits));
-#endif
-      finite = ((bits >> 23) & 0xffu) != 0xffu;
-    }
-    if (finite) *P.status = 1;
-  }
+// "singular": numpy.linalg.inv returns NaNs for it without raising, and so do the kernels.  `minpiv`: the smallest
+// Cholesky pivot of M that is a number (chol above): NaN pivots never enter it, so the test needs no look at M itself
+// (summing M's entries in the cold branch kept all 21 of them alive across the factorisation: +6 .. 14 registers on the
+// kernels that sit at the 256-register line - Jaco2's x,y,z law with secondary controllers spilled 44 B and lost 8 %).
+template <class T>
+ABRK_INL void flag_singular(const OscP<T>& P, T minpiv) {
+  if (!(minpiv > T(0)) && P.status) *P.status = 1;
 }
-
 template <class T>
 struct SlidingP {
   T kd, lamb;
@@ -119,13 +99,16 @@ ABRK_INL T rcp(T x) {
 // matrix is positive definite by construction (the joint-space inertia matrix of an arm with mass - a singular one gives
 // non-finite torques where the reference raises LinAlgError).  The first failing pivot is a real number <= 0, so the
 // flag does not depend on how comparisons treat the NaNs that follow it (-ffinite-math-only).
+// minpiv (optional): receives the smallest pivot that is a NUMBER (fmin discards NaNs: v_min_f64 is IEEE minNum) - <= 0
+// exactly when a real pivot is not positive, untouched by the NaN pivots of a non-finite matrix.
 template <int K, class T, bool GUARD = true>
-ABRK_INL bool chol(const T (&S)[K * (K + 1) / 2], T (&L)[K * (K + 1) / 2], T (&il)[K]) {
+ABRK_INL bool chol(const T (&S)[K * (K + 1) / 2], T (&L)[K * (K + 1) / 2], T (&il)[K], T* minpiv = nullptr) {
   constexpr bool kGuard = GUARD || sizeof(T) < 8;  // fp32: a pivot of an ill-conditioned M can round to <= 0
   bool ok = true;
   sfor<K>([&](auto j) ABRK_LAMBDA {
     T dgn = S[tri(j(), j())];
     sfor<j()>([&](auto k) ABRK_LAMBDA { dgn = Rm<T>::fma(-L[tri(j(), k())], L[tri(j(), k())], dgn); });
+    if (minpiv) *minpiv = Rm<T>::fmin(*minpiv, dgn);
     const bool pos = dgn > T(0);
     ok = ok && pos;
     const T dsafe = kGuard ? (pos ? dgn : T(1)) : dgn;
@@ -913,7 +896,7 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
                       const T (&cvec)[N], const T (&Jv)[N][3], const T (&Jw)[N][3], const T (&p)[3],
                       const T (&RF)[9], const T (&q)[N], const T (&dq)[N], const T (&tgt)[6], bool tv_given,
                       const T (&tvin)[6], bool have_ierr, T (&ierr)[6], bool have_ext, const T (&une)[N],
-                      T (&u)[N], T (&ts)[N], bool* defer = nullptr) {
+                      T (&u)[N], T (&ts)[N], bool* defer = nullptr, bool* singular = nullptr) {
   constexpr bool FAST = (KM <= 3);
   T Jr[N][KM];
   bool sel[KM];
@@ -928,7 +911,13 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   ABRK_MARK("law3:chol_M");
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T through the Cholesky factor of M
   T L[N * (N + 1) / 2], il[N];
-  flag_singular<N>(P, chol<N, T, false>(Ms, L, il), Ms);
+  T minpiv = T(1);
+  chol<N, T, false>(Ms, L, il, &minpiv);
+  // (kernels at the register line take the verdict along as a lane mask and store the flag after the row's outputs: a
+  //  store behind a branch HERE splits the law's one scheduling region - +14 registers on Jaco2's x,y,z kernels, 44 B
+  //  of scratch and 8 % on BASELINE config 3)
+  if (singular) *singular = !(minpiv > T(0));
+  else flag_singular(P, minpiv);
   ABRK_MARK("law3:Y");
   T Y[N][KM];
   sfor<KM>([&](auto r) ABRK_LAMBDA {
@@ -1298,7 +1287,8 @@ template <int N, class T, bool USE_C, int FEAT, class Rows, int QSTEPS = 3>
 ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T (&gz)[N], T gscale,
                        const T (&cvec)[N], Rows& js, const T (&p)[3], const T (&RF)[9], const T (&q)[N],
                        const T (&dq)[N], const T (&tgt)[6], bool tv_given, const T (&tvin)[6], bool have_ierr,
-                       T (&ierr)[6], bool have_ext, const T (&une)[N], T (&u)[N], T (&ts)[N], bool* defer = nullptr) {
+                       T (&ierr)[6], bool have_ext, const T (&une)[N], T (&u)[N], T (&ts)[N], bool* defer = nullptr,
+                       bool* singular = nullptr) {
   constexpr int KM = 6;
   static_assert(rec_len(N) >= rec_off_b1(N) + 2 * N, "hand-over record layout");
   // ctrlr_dof is uniform over the launch.  With all six rows selected (the reference benchmark's UR5 setting) nothing
@@ -1395,7 +1385,13 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   ABRK_MARK("law6:chol_M");
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T = Y Y^T, Y = J L^-T (rows y_r = L^-1 j_r)
   T L[N * (N + 1) / 2], il[N];
-  flag_singular<N>(P, chol<N, T, false>(Ms, L, il), Ms);
+  T minpiv = T(1);
+  chol<N, T, false>(Ms, L, il, &minpiv);
+  // (kernels at the register line take the verdict along as a lane mask and store the flag after the row's outputs: a
+  //  store behind a branch HERE splits the law's one scheduling region - +14 registers on Jaco2's x,y,z kernels, 44 B
+  //  of scratch and 8 % on BASELINE config 3)
+  if (singular) *singular = !(minpiv > T(0));
+  else flag_singular(P, minpiv);
   if constexpr (FEAT >= 2) {
     if (have_ext) {  // caller-evaluated u_null: v_ext = M^-1 u_ext
       T y[N], w[N];
@@ -1742,16 +1738,16 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     ABRK_STAMP(scr, 3, false);  // (timeline build) kinematics, dynamics, Coriolis sweep and Jacobian done
     if constexpr (MAT && USE_C)
       osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cvm, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
-                                    ierr, have_ext, une, u, ts, scr.defer_ptr());
+                                    ierr, have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
     else if constexpr (TWO_PASS)
       osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), cv2, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
-                                    ierr, have_ext, une, u, ts, scr.defer_ptr());
+                                    ierr, have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
     else if constexpr (USE_C)
       osc_law<N, T, KM, true, FEAT>(P, d.Ms, d.gz, T(9.81), d.cv, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin, have_ierr,
-                                    ierr, have_ext, une, u, ts, scr.defer_ptr());
+                                    ierr, have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
     else  // no Coriolis vector: the slot is not read (d.gz stands in for the array type)
       osc_law<N, T, KM, false, FEAT>(P, d.Ms, d.gz, T(9.81), d.gz, Jv, Jw, p, RF, q, dq, tgt, tv_given, tvin,
-                                     have_ierr, ierr, have_ext, une, u, ts, scr.defer_ptr());
+                                     have_ierr, ierr, have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
   } else {
     {
       // the six rows go to the row store (the LDS slab on the GPU - free again: rne_backward has read the wrenches)
@@ -1785,16 +1781,16 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     late();
     if constexpr (MAT && USE_C)
       osc_law6<N, T, true, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), cvm, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
-                                 have_ext, une, u, ts, scr.defer_ptr());
+                                 have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
     else if constexpr (TWO_PASS)
       osc_law6<N, T, true, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), cv2, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
-                                 have_ext, une, u, ts, scr.defer_ptr());
+                                 have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
     else if constexpr (USE_C)
       osc_law6<N, T, true, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), d.cv, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
-                                 have_ext, une, u, ts, scr.defer_ptr());
+                                 have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
     else
       osc_law6<N, T, false, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), d.gz, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
-                                  have_ext, une, u, ts, scr.defer_ptr());
+                                  have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);
   }
 }
 

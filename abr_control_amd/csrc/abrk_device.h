@@ -943,6 +943,7 @@ struct ScratchBase {
   // pass's 256-register budget was short of (it spilled them: 86 B per row of scratch writes, PMC)
   static constexpr bool kNoTs = false;
   bool allow_defer = false, deferred = false;
+  bool singular = false;  // the row's M has a non-positive pivot (the law's verdict; the flag is stored after the outputs)
 #if defined(ABRK_TIMELINE)
   unsigned long long tl[8] = {};
 #endif

@@ -200,11 +200,13 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
     // parked for the second pass: u / the training signal are not written yet.  A handed-over row is finished there from
     // its record, without its inputs: the integral state it advanced is stored here
     if (scr.handed_over && have_ierr) store_row<6>(ierrg, b, ierr);
+    if (scr.singular && P.status) *P.status = 1;
     return;
   }
   store_row<N>(ug, b, u);
   if (tsg) store_row<N>(tsg, b, ts);
   if (have_ierr) store_row<6>(ierrg, b, ierr);
+  if (scr.singular && P.status) *P.status = 1;  // ABRK_ESINGULAR (abrk_ctrl.h flag_singular)
 }
 template <class A, class T, int KM, bool USE_C, int FEAT>
 ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
@@ -293,6 +295,7 @@ ABRK_INL void osc_full_body(long b, bool active, St& st, const A& arm, const Osc
     store_row<N>(ug, b, u);
     if (tsg) store_row<N>(tsg, b, ts);
     if (have_ierr) store_row<6>(ierrg, b, ierr);
+    if (scr.singular && P.status) *P.status = 1;  // ABRK_ESINGULAR (abrk_ctrl.h flag_singular)
   }
 }
 
@@ -459,8 +462,10 @@ ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLink
   const int n_chk = every > 0 ? n_steps / every : 0;
   int chk = 0, until = every;
   RegScratch<T, 2> scr;
+  bool singular = false;
   for (int t = 0; t < n_steps; t++) {
     osc_row<A, T, KM, USE_C, 2>(arm, P, q, dq, tgt, false, tv, have_ierr, ierr, false, une, u, ts, []() {}, scr);
+    singular = singular || scr.singular;
     twolink_step(K, q, dq, u);
     if (every > 0 && --until == 0) {
       until = every;
@@ -476,6 +481,7 @@ ABRK_INL void rollout_body(long b, const A& arm, const OscP<T>& P, const TwoLink
   store_row<2>(qg, b, q);
   store_row<2>(dqg, b, dq);
   if (have_ierr) store_row<6>(ierrg, b, ierr);
+  if (singular && P.status) *P.status = 1;
 }
 
 // ---- InverseKinematics.generate_path for B independent paths (inverse_kinematics.py:28-135)
