@@ -43,6 +43,14 @@ struct OscP {
 // Cholesky pivot of M that is a number (chol above): NaN pivots never enter it, so the test needs no look at M itself
 // (summing M's entries in the cold branch kept all 21 of them alive across the factorisation: +6 .. 14 registers on the
 // kernels that sit at the 256-register line - Jaco2's x,y,z law with secondary controllers spilled 44 B and lost 8 %).
+// true on every lane of the wavefront if the condition holds on any of them (a scalar on the GPU)
+ABRK_INL bool any_lane(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ballot_w64(c) != 0;
+#else
+  return c;
+#endif
+}
 template <class T>
 ABRK_INL void flag_singular(const OscP<T>& P, T minpiv) {
   if (!(minpiv > T(0)) && P.status) *P.status = 1;
@@ -913,10 +921,11 @@ ABRK_INL void osc_law(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T 
   T L[N * (N + 1) / 2], il[N];
   T minpiv = T(1);
   chol<N, T, false>(Ms, L, il, &minpiv);
-  // (kernels at the register line take the verdict along as a lane mask and store the flag after the row's outputs: a
-  //  store behind a branch HERE splits the law's one scheduling region - +14 registers on Jaco2's x,y,z kernels, 44 B
-  //  of scratch and 8 % on BASELINE config 3)
-  if (singular) *singular = !(minpiv > T(0));
+  // (the kernels take the verdict along and store the flag after the row's outputs: a store behind a branch HERE
+  //  splits the law's one scheduling region - +14 registers on Jaco2's x,y,z kernels, 44 B of scratch and 8 % on
+  //  BASELINE config 3.  And they take it along as a WAVE-level scalar - "some row of this wavefront": the flag says no
+  //  more than that anyway - because a per-lane bool rides in vector registers: +10 .. 12 on the six-row kernels)
+  if (singular) *singular = any_lane(!(minpiv > T(0)));
   else flag_singular(P, minpiv);
   ABRK_MARK("law3:Y");
   T Y[N][KM];
@@ -1387,10 +1396,11 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   T L[N * (N + 1) / 2], il[N];
   T minpiv = T(1);
   chol<N, T, false>(Ms, L, il, &minpiv);
-  // (kernels at the register line take the verdict along as a lane mask and store the flag after the row's outputs: a
-  //  store behind a branch HERE splits the law's one scheduling region - +14 registers on Jaco2's x,y,z kernels, 44 B
-  //  of scratch and 8 % on BASELINE config 3)
-  if (singular) *singular = !(minpiv > T(0));
+  // (the kernels take the verdict along and store the flag after the row's outputs: a store behind a branch HERE
+  //  splits the law's one scheduling region - +14 registers on Jaco2's x,y,z kernels, 44 B of scratch and 8 % on
+  //  BASELINE config 3.  And they take it along as a WAVE-level scalar - "some row of this wavefront": the flag says no
+  //  more than that anyway - because a per-lane bool rides in vector registers: +10 .. 12 on the six-row kernels)
+  if (singular) *singular = any_lane(!(minpiv > T(0)));
   else flag_singular(P, minpiv);
   if constexpr (FEAT >= 2) {
     if (have_ext) {  // caller-evaluated u_null: v_ext = M^-1 u_ext
