@@ -54,7 +54,7 @@ for mode in ("handover", "round3"):
 PY
 cat $O/osc6_step_trace.txt
 # 5. soak: seeded fuzz of every kernel family against the oracle on this build (new seeds)
-timeout 420 python tools/gpu_soak.py 300 130000 > $O/soak.log 2>&1; tail -4 $O/soak.log
+timeout 900 python tools/gpu_soak.py 300 130000 > $O/soak.log 2>&1; tail -4 $O/soak.log
 find $O -name "*.db" -delete 2>/dev/null
 # the summary of everything (kernel stats, trace means per leg, PMC means per launch, bench lines), made HERE: what comes
 # back is capped at 64 MiB, and the raw counter files of the PMC passes alone exceed that
