@@ -1392,6 +1392,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   }
 
   ABRK_MARK("law6:chol_M");
+  ABRK_STAMP(js, 8, false);
   // _Mx (osc.py:120-147): Mx_inv = J M^-1 J^T = Y Y^T, Y = J L^-T (rows y_r = L^-1 j_r)
   T L[N * (N + 1) / 2], il[N];
   T minpiv = T(1);
@@ -1414,6 +1415,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     }
   }
   ABRK_MARK("law6:Y_Am");
+  ABRK_STAMP(js, 9, false);
   T Am[KM * (KM + 1) / 2];
   auto yrow = [&](auto r, T(&y)[N]) ABRK_LAMBDA {
     T b[N];
@@ -1458,6 +1460,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
       });
     });
   }
+  ABRK_STAMP(js, 10, false);
   T trace = T(0);
   // a masked row of J is zero: so is its diagonal entry, which becomes the unit diagonal.  (Selects on purpose: a block
   // behind a scalar branch at this spot - the register peak of the law - makes the allocator spill 70 values.)
@@ -1516,6 +1519,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
         if constexpr (FEAT != 0) mx_explicit = true;
       }
     }
+    ABRK_STAMP(js, 11, false);
     if (truncates && (Rows::kDeferOnly || defer)) {
       if (defer) *defer = true;  // worked off in the second pass; u / the training signal of this row are not written yet
       // the row joins its wavefront's sub-list; in hand-over mode it also leaves everything the second pass needs -
@@ -1555,6 +1559,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
         });
         store_pairs<2 * N>(rec + rec_off_b1(N), bb);
       }
+      ABRK_STAMP(js, 12, false);
       return;
     }
     if constexpr (!Rows::kDeferOnly) if (truncates) {
@@ -1583,6 +1588,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   }
 
   ABRK_MARK("law6:f");
+  ABRK_STAMP(js, 13, false);
   // f = Mx u_task[ctrlr_dof] (osc.py:285-288); f2 = Mx (J v) for the null-space filter
   if (mx_explicit) {
     symv<KM>(Mx, uts, f);
@@ -1629,6 +1635,7 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
     }
   });
   }
+  ABRK_STAMP(js, 14, false);
   sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] = u0[i()] - a1[i()]; });
   if constexpr (USE_C) sfor<N>([&](auto i) ABRK_LAMBDA { u[i()] -= cvec[i()]; });  // osc.py:291-292
   sfor<N>([&](auto i) ABRK_LAMBDA { ts[i()] = u[i()]; });                          // osc.py:297 (kNoTs: not stored)
@@ -1789,6 +1796,7 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     }
     ABRK_SCHED_FENCE();
     late();
+    ABRK_STAMP(scr, 3, false);  // (timeline build) kinematics, dynamics, Jacobian done, task rows in the row store
     if constexpr (MAT && USE_C)
       osc_law6<N, T, true, FEAT, typename std::decay<Scr>::type, kQSteps>(P, d.Ms, d.gz, T(9.81), cvm, scr, p, RF, q, dq, tgt, tv_given, tvin, have_ierr, ierr,
                                  have_ext, une, u, ts, scr.defer_ptr(), &scr.singular);

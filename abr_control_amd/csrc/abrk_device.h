@@ -945,7 +945,7 @@ struct ScratchBase {
   bool allow_defer = false, deferred = false;
   bool singular = false;  // the row's M has a non-positive pivot (the law's verdict; the flag is stored after the outputs)
 #if defined(ABRK_TIMELINE)
-  unsigned long long tl[8] = {};
+  unsigned long long tl[16] = {};
 #endif
   ABRK_INL bool* defer_ptr() { return allow_defer ? &deferred : nullptr; }
   // where a deferring row parks itself (set by the kernel; the host check build passes plain arrays).

@@ -261,6 +261,21 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
         scr.row = b;
       }
       osc_body<A, T, KM, USE_C, FEAT>(b, arm, P, B, qg, dqg, tg, tvg, ierrg, uneg, ug, tsg, scr);
+#if defined(ABRK_TIMELINE)
+      // (timeline build, six-row first pass: stamps 0 .. 15 of this wavefront leave through the kernel's `uneg` pointer -
+      //  the caller-evaluated null signal, which FEAT < 2 kernels never read)
+      if constexpr (KM == 6 && PASS == 1 && FEAT < 2) {
+        ABRK_STAMP(scr, 5, false);
+        ABRK_STAMP(scr, 6, true);
+        scr.tl[0] = tl_entry;
+        scr.tl[1] = tl_tab;
+        scr.tl[7] = __builtin_amdgcn_s_memtime() - tl_clk0;
+        if (uneg && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+          unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<T*>(uneg)) + (size_t)blockIdx.x * 16;
+          for (int k = 0; k < 16; k++) o[k] = scr.tl[k];
+        }
+      }
+#endif
       return scr.deferred;
     };
     if constexpr (kLds && NOTS) {

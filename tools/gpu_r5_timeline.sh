@@ -10,6 +10,14 @@ build)
   /opt/rocm/bin/hipcc $FLAGS -DABRK_TIMELINE -DABRK_TIMELINE_LIGHT tools/microbench/shard_step_timeline.hip -o tools/microbench/shard_step_timeline_light.bin &
   wait
   ;;
+build6)
+  /opt/rocm/bin/hipcc $FLAGS -DABRK_TIMELINE -DABRK_TIMELINE_LIGHT tools/microbench/osc6_step_timeline.hip -o tools/microbench/osc6_step_timeline.bin
+  ;;
+run6)
+  O=gpurun_out/r5_timeline6; mkdir -p $O
+  for rep in 1 2; do timeout 120 tools/microbench/osc6_step_timeline.bin $O/osc6_$rep.json; done
+  ls -la $O
+  ;;
 run)
   O=gpurun_out/r5_timeline
   mkdir -p $O
