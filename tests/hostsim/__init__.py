@@ -251,6 +251,17 @@ def sym6_eig(A, method):
     return lam, V
 
 
+def osc6_tail(A, G, b):
+    """the device code's truncating pseudo-inverse + tail of the six-row law (abrk_ctrl.h `osc6_tail`: Householder, the
+    early-exit QL iteration, a tridiagonal solve): A [B,6,6], G [B,8,6], b [B,12] -> (u [B,6], ts [B,6], lexit [B], cut [B])"""
+    A, G, b = (_in(x, np.dtype(np.float64)) for x in (A, G, b))
+    B = A.shape[0]
+    out, info = np.full((B, 12), np.nan), np.full((B, 2), np.nan)
+    rc = _lib_for(law=True).hostsim_osc6_tail(C.c_int64(B), _p(A), _p(G), _p(b), _p(out), _p(info))
+    assert rc == 0, rc
+    return out[:, :6], out[:, 6:], info[:, 0].astype(int), info[:, 1]
+
+
 def spd_inverse_small(A):
     """the device code's cofactor inverse of a symmetric 2 x 2 / 3 x 3 matrix (abrk_ctrl.h `spd_inverse_small`, the
     task-space inertia of the x,y,z / x,y law): A [B,K,K] -> (inv [B,K,K], det [B], ok [B] bool)"""

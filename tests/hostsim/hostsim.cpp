@@ -387,6 +387,36 @@ extern "C" int hostsim_sym6_eig(int method, int64_t B, const double* A, double* 
   }
   return 0;
 }
+// the truncating pseudo-inverse + tail of the six-row law on its own (abrk_ctrl.h osc6_tail: early-exit QL + tridiagonal
+// solve): A [B,6,6] symmetric, G [B,8,6] (columns of [J | u_task | J v], six joints), b [B,12] (b1, b2) -> out [B,12]
+// (u, ts), info [B,2] (index of the last eigenvalue the iteration isolated: -1 none ... 5 all; the cut-off it used)
+extern "C" int hostsim_osc6_tail(int64_t B, const double* A, const double* G, const double* b, double* out, double* info) {
+  for (long k = 0; k < B; k++) {
+    double S[21], Gm[8][6], b1[6], b2[6], u[6], ts[6];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j <= i; j++) S[tri(i, j)] = A[k * 36 + i * 6 + j];
+    for (int c = 0; c < 8; c++)
+      for (int r = 0; r < 6; r++) Gm[c][r] = G[k * 48 + c * 6 + r];
+    for (int i = 0; i < 6; i++) {
+      b1[i] = b[k * 12 + i];
+      b2[i] = b[k * 12 + 6 + i];
+    }
+    {
+      double G2[1][6] = {{0, 0, 0, 0, 0, 0}}, lam[6];
+      QlTail<6, double> t;
+      t.rcond = 1e-4;
+      ql_core<6, double, 1, false, false, true>(S, G2, lam, &t);
+      info[k * 2] = t.lexit;
+      info[k * 2 + 1] = t.cut;
+    }
+    osc6_tail<6, double>(S, Gm, b1, b2, true, u, ts);
+    for (int i = 0; i < 6; i++) {
+      out[k * 12 + i] = u[i];
+      out[k * 12 + 6 + i] = ts[i];
+    }
+  }
+  return 0;
+}
 // the cofactor inverse of the x,y,z / x,y law (abrk_ctrl.h `spd_inverse_small`): A [B,K,K] symmetric -> inv [B,K,K],
 // det [B], ok [B]
 extern "C" int hostsim_spd_inverse_small(int K, int64_t B, const double* A, double* inv, double* det, int* ok) {

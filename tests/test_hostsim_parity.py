@@ -564,6 +564,86 @@ def test_rows_six_by_six_eigensolvers():
         assert err[off_band].max() < 1e-9, (method, err[off_band].max())
 
 
+def test_rows_six_row_tail_early_exit_is_the_exact_pseudo_inverse():
+    """abrk_ctrl.h `osc6_tail` (round 5): the truncating pseudo-inverse of the six-row law behind a QL iteration that STOPS
+    once the still-coupled part of the tridiagonal matrix is certainly kept (Sturm pivots against a Gershgorin-bounded
+    cut-off) and applies that part by a tridiagonal solve.  Against numpy.linalg.pinv(rcond=1e-4) on Mx_inv of truncating
+    UR5 states, Jaco2's five-row setting (a masked LAST task row: an exact zero row / column), spectra graded over 14
+    decades, eigenvalues just either side of the cut-off, clusters, rank deficiency, masked rows anywhere: exact to
+    rounding - and the iteration really does stop early (UR5: after the first or second eigenvalue; Jaco2 five rows:
+    mostly without isolating any)."""
+    from abr_control_amd import _abi
+    from oracle.oracle import Oracle
+    from tests import hostsim
+
+    rng = np.random.RandomState(11)
+    mats, kinds = [], []
+    for arm in ("ur5", "jaco2"):
+        o = Oracle(_abi.load_table(arm))
+        n = 0
+        while n < 120:
+            q = rng.uniform(0, 2 * np.pi, 6)
+            J, M = o.J("EE", q), o.M(q)
+            A = J @ np.linalg.inv(M) @ J.T
+            if arm == "jaco2":
+                A[5, :] = 0
+                A[:, 5] = 0
+            sv = np.linalg.eigvalsh(A)
+            if abs(np.linalg.det(A)) < 1e-3 and sv[0] < 1e-4 * sv[-1]:
+                mats.append(A)
+                kinds.append(arm)
+                n += 1
+    for k in range(900):
+        Q, _ = np.linalg.qr(rng.normal(size=(6, 6)))
+        kind = k % 9
+        if kind == 0:
+            lam = 10.0 ** rng.uniform(-12, 2, 6)
+        elif kind == 1:
+            lam = np.array([1, 0.5, 0.2, 2e-4, 0.9e-4, 1e-9]) * 10 ** rng.uniform(-3, 3)
+        elif kind == 2:
+            lam = np.array([1, 1, 1, 1e-6, 1e-6, 1e-6])
+        elif kind == 3:
+            lam = np.array([3.0, 1e-5, 1e-5, 1e-5, 1e-5, 0.0])
+        elif kind == 4:
+            lam = np.concatenate([[1.0], 10.0 ** rng.uniform(-4.5, -3.5, 5)])
+        elif kind == 5:
+            lam = np.array([1, 0.3, 0.1, 0.03, 0.01, 10.0 ** rng.uniform(-9, -4.2)])
+        else:
+            lam = 10.0 ** rng.uniform(-1, 1, 6) if k % 2 else np.concatenate([10.0 ** rng.uniform(-1, 1, 5), [10.0 ** rng.uniform(-9, -5)]])
+        A = (Q * lam) @ Q.T
+        A = (A + A.T) / 2
+        if kind >= 6:  # masked task rows: exact zero rows / columns
+            for r in [(5,), (4, 5), (1, 5), (0,), (2, 3, 4, 5), (1,)][(k // 9) % 6]:
+                A[r, :] = 0
+                A[:, r] = 0
+        mats.append(A)
+        kinds.append("masked" if kind >= 6 else "synthetic")
+    A = np.array(mats)
+    kinds = np.array(kinds)
+    n = len(A)
+    G, b = rng.normal(size=(n, 8, 6)), rng.normal(size=(n, 12))
+    u, ts, lexit, cut = hostsim.osc6_tail(A, G, b)
+    assert np.isfinite(u).all() and np.isfinite(ts).all()
+    worst = 0.0
+    for k in range(n):
+        sv = np.abs(np.linalg.eigvalsh(A[k]))
+        if np.any(np.abs(sv / sv.max() - 1e-4) < 1e-6 * 1e-4):
+            continue  # within 1e-6 of the cut-off: either answer is legitimate
+        P = np.linalg.pinv(A[k], rcond=1e-4, hermitian=True)
+        ts_ref = b[k, :6] - G[k, :6] @ (P @ G[k, 6])
+        u_ref = ts_ref + b[k, 6:] - G[k, :6] @ (P @ G[k, 7])
+        scale = np.abs(P).max() * np.abs(G[k]).max() ** 2 * 6
+        worst = max(worst, np.abs(u[k] - u_ref).max() / scale, np.abs(ts[k] - ts_ref).max() / scale)
+    assert worst < 1e-10, worst
+    # the iteration stops early where it can
+    ur5 = lexit[kinds == "ur5"]
+    assert (ur5 <= 1).mean() > 0.95 and (ur5 == 0).mean() > 0.6, np.bincount(ur5 + 1)
+    j2 = lexit[kinds == "jaco2"]
+    assert (j2 <= 1).mean() > 0.95 and (j2 == -1).mean() > 0.5, np.bincount(j2 + 1)
+    # ... and runs to the end where it must (eigenvalues all around the cut-off)
+    assert (lexit[kinds == "synthetic"] == 5).any()
+
+
 def test_rows_direct_sym3_eigensolver():
     """abrk_ctrl.h `sym3_eig` (the sweep-free eigen-decomposition behind AvoidObstacles' truncated pinv) against
     numpy.linalg.eigvalsh / pinv on the matrices that break closed forms: rank 1 and rank 2 (what the first two

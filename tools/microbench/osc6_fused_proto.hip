@@ -75,13 +75,14 @@ __device__ __forceinline__ void finish_role(long j, int s0, int slots, const uns
       const long b = row_ok ? (long)ridx : 0;
       {
 #pragma clang fp contract(off)
-        T wv[6];
-        osc6_rec_solve<N, T, 1, true>(rec, c, S, G, wv);
+        T li[6], iq[6], y[6];
+        osc6_rec_solve<N, T, 1, true>(rec, c, S, G, li, iq);
+        ql_pinv_solve<6>(li, iq, G[0], y);  // this lane's column through the pseudo-inverse
         T a1 = T(-0.0), a2 = T(-0.0);
         sfor<6>([&](auto i) ABRK_LAMBDA {
-          const T gu = lane_bcast(G[0][i()], N), gw = lane_bcast(G[0][i()], N + 1);
-          a1 = Rm<T>::fma(G[0][i()], wv[i()] * gu, a1);
-          a2 = Rm<T>::fma(G[0][i()], wv[i()] * gw, a2);
+          const T yu = lane_bcast(y[i()], N), yw = lane_bcast(y[i()], N + 1);
+          a1 = Rm<T>::fma(G[0][i()], yu, a1);
+          a2 = Rm<T>::fma(G[0][i()], yw, a2);
         });
         if (lane < N && row_ok) {
           const T ts = b1 - a1;
