@@ -504,8 +504,10 @@ ABRK_INL bool ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K],
         T dm = d[K - 1];
         sfor<K - 1 - l>([&](auto jj) ABRK_LAMBDA {
           constexpr int j = K - 2 - jj();  // K-2 .. l
+          // (with an absolute floor: rounding noise between two diagonal entries that are exactly 0 - masked task rows
+          //  after the reflectors, in fp32 - can be a denormal, which v_rcp / v_rsq read as 0: NaNs)
           const T dd = Rm<T>::fabs(d[j]) + Rm<T>::fabs(d[j + 1]);
-          const bool small = !(Rm<T>::fabs(e[j]) > Rm<T>::eps() * dd);
+          const bool small = !(Rm<T>::fabs(e[j]) > Rm<T>::fmax(Rm<T>::eps() * dd, Rm<T>::tiny()));
           m = small ? j : m;
           dm = small ? d[j] : dm;
         });
@@ -533,7 +535,7 @@ ABRK_INL bool ql_core(const T (&S)[K * (K + 1) / 2], T (&V)[NR][K], T (&lam)[K],
           const bool act = (i < m) && !stop;
           const T f = sn * e[i], b = cs * e[i];
           const T r2 = Rm<T>::fma(f, f, g * g);
-          const bool zero = !(r2 > T(0));
+          const bool zero = !(r2 > Rm<T>::tiny());  // (a denormal radius counts as zero: v_rsq would make it infinite)
           const bool go = act && !zero;
           d[i + 1] = (act && zero) ? d[i + 1] - pp : d[i + 1];
           stop = stop || (act && zero);
