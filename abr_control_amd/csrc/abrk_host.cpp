@@ -391,7 +391,15 @@ extern "C" int abrk_stream_sync(int device, void* stream) {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   }
   // the device's sticky "M not positive definite" flag of asynchronous (device-pointer) OSC calls: reported once
-  if (device < kMaxStatusDevices && g_dev_status[device].take()) return singular_error();
+  // (under the lock that guards the word's allocation: another thread may be making its first call on this device)
+  if (device < kMaxStatusDevices) {
+    bool raised;
+    {
+      std::lock_guard<std::mutex> lk(g_status_mu);
+      raised = g_dev_status[device].take();
+    }
+    if (raised) return singular_error();
+  }
   return 0;
 }
 extern "C" int abrk_device_sync(int device) {
