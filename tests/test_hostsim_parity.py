@@ -6,6 +6,7 @@ The `-m gpu` tests repeat the same checks through libabrk.so on the device."""
 import numpy as np
 import pytest
 
+from abr_control_amd import _abi
 from tests import cases
 from tests.conftest import golden
 
@@ -94,6 +95,36 @@ def test_rows_six_row_handover_form_near_singular_postures(arm):
     assert worst <= cases.TOL_D
 
 
+@pytest.mark.parametrize("arm", ["ur5", "jaco2", "threejoint"])
+def test_rows_six_row_handover_and_one_pass_forms_are_bit_equal(arm):
+    """since round 5 every form of the six-row law hands a truncating row to ONE routine (abrk_ctrl.h osc6_tail) fed with
+    the same values (osc6_jv / osc6_sums: contraction pinned off), from a record or from its registers: on the host
+    build of the row programs the two-pass form and the one-pass form return the same bits - u and the training signal,
+    random states and near-singular postures, plain law / Coriolis + secondary controllers / masked task rows, fp64 and
+    fp32.  (The GPU suite asserts the same across the batch-size thresholds:
+    G::test_gpu_six_row_bits_do_not_depend_on_the_batch_size.)"""
+    n = _abi.load_table(arm)["n_joints"]
+    rng = np.random.RandomState(17)
+    q = rng.uniform(0, 2 * np.pi, (400, n))
+    if arm != "threejoint":
+        qs = cases.near_singular_postures(arm, 120)
+        q[:len(qs)] = qs
+    dq, t = rng.uniform(0, 5, (400, n)), rng.uniform(-1, 1, (400, 6))
+    one, two = cases.HostsimBackend(arm, "static"), cases.HostsimBackend(arm, "static", handover=True)
+    laws = [dict(kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6),
+            dict(kp=100, ko=60, kv=12, ctrlr_dof=[1, 1, 1, 1, 1, 0], use_C=True,
+                 null_controllers=[_abi.make_damping(5), _abi.make_resting([0.3] * n, kp=20, kv=4)]),
+            dict(kp=80, ko=40, ctrlr_dof=[1, 0, 1, 1, 0, 1], orientation_algorithm=1)]
+    for kw in laws:
+        p = _abi.make_osc_params(n, **kw)
+        for dt in (np.float64, np.float32):
+            u1, ts1 = one.osc(p, q, dq, t, dtype=dt)
+            u2, ts2 = two.osc(p, q, dq, t, dtype=dt)
+            assert np.array_equal(u1, u2, equal_nan=True) and np.array_equal(ts1, ts2, equal_nan=True), (kw, dt)
+            assert np.isfinite(u1).all()
+    assert two.deferred > 0, "no row went through the hand-over records"
+
+
 def test_rows_six_row_handover_form_fuzz_on_user_arms():
     """random 1..7-joint user arms (runtime-table row programs), any ctrlr_dof mask / frame / optional input: the
     two-pass form against the oracle"""
@@ -116,7 +147,6 @@ def test_rows_obstacles_split_program_equals_one_pass(arm):
     heavy (obstacle, segment) pair at a time from the row's record + finish - on the GPU the pairs of a wavefront's 64
     rows are spread over its lanes through LDS (obstacles_lds_kernel).  Against the one-pass row program: the same
     contributions, summed in another order"""
-    from abr_control_amd import _abi
     from tests import hostsim
 
     n = _abi.load_table(arm)["n_joints"]
@@ -304,7 +334,6 @@ def test_rows_user_arms_all_joint_counts(n):
 
 
 def _abi_frame(name, n):
-    from abr_control_amd import _abi
 
     return _abi.frame_id(name, n)
 
@@ -312,7 +341,6 @@ def _abi_frame(name, n):
 @pytest.mark.parametrize("variant", ["static", "rt"])
 @pytest.mark.parametrize("arm", ["ur5", "jaco2"])
 def test_rows_inverse_kinematics(arm, variant):
-    from abr_control_amd import _abi
     from tests import hostsim
 
     g = golden(arm)
@@ -400,7 +428,6 @@ def test_rows_fuzz_sliding_joint_dynamics(seed):
 def test_rows_osc_helper_methods_vs_reference(arm):
     """the row programs behind OSC._Mx / ._velocity_limiting / ._calc_orientation_forces against the reference's own
     outputs (tests/golden/oschelpers_<arm>.npz; inputs and expectations of controllers/tests/test_osc.py)"""
-    from abr_control_amd import _abi
     from tests import hostsim
 
     g = golden(f"oschelpers_{arm}")
@@ -467,7 +494,6 @@ def test_rows_fused_full_outputs(arm, kw):
     program, the robot_config outputs equal to the dynamics row program of the same frame / offset, static and
     runtime-table arms"""
     from tests import hostsim
-    from abr_control_amd import _abi
 
     tab = _abi.load_table(arm)
     n = tab["n_joints"]
@@ -572,7 +598,6 @@ def test_rows_six_row_tail_early_exit_is_the_exact_pseudo_inverse():
     decades, eigenvalues just either side of the cut-off, clusters, rank deficiency, masked rows anywhere: exact to
     rounding - and the iteration really does stop early (UR5: after the first or second eigenvalue; Jaco2 five rows:
     mostly without isolating any)."""
-    from abr_control_amd import _abi
     from oracle.oracle import Oracle
     from tests import hostsim
 
