@@ -51,7 +51,13 @@ class DynOut(C.Structure):
 
 class ScratchInfo(C.Structure):  # abrk_scratch_info
     _fields_ = [(k, C.c_int64) for k in ("worklist_slots", "worklist_bytes", "inline_fallbacks", "evictions",
-                                          "device_free_bytes", "device_total_bytes")]
+                                          "device_free_bytes", "device_total_bytes", "status_words_out",
+                                          "status_blocks")]
+
+
+class ShardCut(C.Structure):  # abrk_shard_cut: how a resident batch is cut over the devices
+    _fields_ = [("n_shards", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("rows", C.POINTER(C.c_int64)),
+                ("streams", C.POINTER(C.c_void_p))]
 
 
 class NullCtrl(C.Structure):

@@ -63,6 +63,19 @@ def lib():
         L.abrk_dynamics_sharded.argtypes = [
             C.c_int, C.c_int, _i64, _vp, _vp, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.POINTER(_abi.DynOut),
             C.c_int, C.POINTER(C.c_int)]
+        _pp, _pi64, _pi32 = C.POINTER(_vp), C.POINTER(_i64), C.POINTER(C.c_int32)
+        L.abrk_shard_stream.restype = _vp
+        L.abrk_shard_stream.argtypes = [C.c_int, C.c_int]
+        L.abrk_osc_generate_resident.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.OSCParams),
+                                                 C.POINTER(_abi.ShardCut)] + [_pp] * 8
+        L.abrk_sliding_generate_resident.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.SlidingParams),
+                                                     C.POINTER(_abi.ShardCut)] + [_pp] * 7
+        L.abrk_joint_generate_resident.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.NullCtrl), C.c_int,
+                                                   C.POINTER(_abi.ShardCut)] + [_pp] * 5
+        L.abrk_dynamics_resident.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.ShardCut), _pp, _pp, C.c_int,
+                                             C.POINTER(C.c_double), C.c_uint32, C.POINTER(_abi.DynOut)]
+        L.abrk_shards_sync.argtypes = [C.POINTER(_abi.ShardCut)]
+        L.abrk_plans_launch.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int]
         L.abrk_osc_law_batch.argtypes = [C.c_int, C.c_int, C.POINTER(_abi.OSCParams), _i64] + [_vp] * 14 + [C.c_int, _vp]
         L.abrk_osc_mx_batch.argtypes = [C.c_int, C.c_int, C.c_int, _i64, _vp, _vp, C.c_double, _vp, _vp, C.c_int, _vp]
         L.abrk_osc_velocity_limiting_batch.argtypes = [C.c_int, C.POINTER(_abi.OSCParams), _i64, _vp, _vp, C.c_int, _vp]
@@ -169,12 +182,14 @@ class DeviceArray:
         return d
 
     def numpy(self, stream=None):
+        """copy to a new host array on `stream` (a Stream or a raw handle; None = the NULL stream) and wait for it.  The
+        copy drains that stream, so a singular batch enqueued on it earlier raises here (SingularMatrixError)"""
         out = np.empty(self.shape, self.dtype)
-        check(lib().abrk_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes, stream))
+        check(lib().abrk_memcpy_d2h(self.device, out.ctypes.data, self.ptr, self.nbytes, getattr(stream, "ptr", stream)))
         return out
 
     def zero_(self, stream=None):
-        check(lib().abrk_memset(self.device, self.ptr, 0, self.nbytes, stream))
+        check(lib().abrk_memset(self.device, self.ptr, 0, self.nbytes, getattr(stream, "ptr", stream)))
         return self
 
     def free(self):
@@ -205,6 +220,26 @@ class Stream:
                 lib().abrk_stream_destroy(self.device, self.ptr)
         except Exception:
             pass
+
+
+class BorrowedStream(Stream):
+    """a stream handle this object does not own (the library's per-(device, slot) shard streams, abrk_shard_stream):
+    usable wherever a Stream is, never destroyed from here"""
+
+    def __init__(self, device, ptr):
+        self.device, self.ptr = device, ptr
+
+    def __del__(self):
+        pass
+
+
+def shard_stream(device, slot):
+    """the library's own stream of the `slot`-th shard on `device` (what the *_resident entry points use when the caller
+    names no streams)"""
+    p = lib().abrk_shard_stream(int(device), int(slot))
+    if not p:
+        raise AbrkError(-2, lib().abrk_last_error().decode())
+    return BorrowedStream(int(device), p)
 
 
 class Event:

@@ -11,9 +11,11 @@
 #include <atomic>
 #include <cstring>
 #include <functional>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/abrk.h"
@@ -264,43 +266,100 @@ static int use_device(int device) {
 }
 
 // ---- the "M is not positive definite" flag (ABRK_ESINGULAR; the reference raises LinAlgError at osc.py:136).  The OSC
-// kernels store 1 through OscP::status where a row's Cholesky factor of M meets a non-positive pivot.  The word lives
-// in pinned, device-mapped host memory, so reading it costs the host nothing once the stream is drained:
+// kernels store 1 through OscP::status where a row's Cholesky factor of M meets a non-positive pivot.  A word lives in
+// pinned, device-mapped host memory, so reading it costs the host nothing once the stream is drained:
 //   * a call that hands over HOST arrays is synchronous - it uses the calling thread's own word and returns the code;
-//   * a call on DEVICE pointers is asynchronous - it uses its device's sticky word, which abrk_stream_sync reports once.
+//   * a call on DEVICE pointers is asynchronous - it uses the word of its (device, stream), which is reported ONCE by
+//     whatever drains that stream next: abrk_stream_sync, abrk_memcpy_d2h on it, abrk_device_sync (every stream of the
+//     device).  Several control loops on one GPU each hear of their own singular batch and of nobody else's.
+// Words come from a pool (64 of them per pinned 4 KiB block; blocks live as long as the process, words are recycled): a
+// thread's word goes back when the thread exits, a stream's word when abrk_stream_destroy is called.
 struct StatusWord {
   volatile int* host = nullptr;
   int* dev = nullptr;
-  bool alloc() {
-    if (host) return true;
-    void *h = nullptr, *d = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
-        hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      if (h) (void)hipHostFree(h);
-      return false;
-    }
-    *(volatile int*)h = 0;
-    host = (volatile int*)h;
-    dev = (int*)d;
-    return true;
-  }
   bool take() {  // -> was it raised?  (cleared)
     if (!host || !*host) return false;
     *host = 0;
     return true;
   }
 };
-static thread_local StatusWord t_status;
-static constexpr int kMaxStatusDevices = 64;
-static StatusWord g_dev_status[kMaxStatusDevices];
-static std::mutex g_status_mu;
-// the word a call's kernels report to (nullptr: the allocation failed - nobody listens, as before round 5)
-static StatusWord* status_word(bool synchronous, int device) {
-  if (synchronous) return t_status.alloc() ? &t_status : nullptr;
-  if (device < 0 || device >= kMaxStatusDevices) return nullptr;
+namespace {
+struct StatusPool {
+  std::mutex mu;
+  std::vector<StatusWord> free_;
+  int64_t blocks = 0, handed_out = 0;
+  static constexpr size_t kStride = 64, kBlock = 4096;
+  StatusWord get() {  // {nullptr, nullptr}: no pinned memory to be had - nobody listens, as before round 5
+    std::lock_guard<std::mutex> lk(mu);
+    if (free_.empty()) {
+      void *h = nullptr, *d = nullptr;
+      if (hipHostMalloc(&h, kBlock, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess ||
+          hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (h) (void)hipHostFree(h);
+        return {};
+      }
+      memset(h, 0, kBlock);
+      blocks++;
+      for (size_t o = 0; o < kBlock; o += kStride)
+        free_.push_back(StatusWord{(volatile int*)((char*)h + o), (int*)((char*)d + o)});
+    }
+    StatusWord w = free_.back();
+    free_.pop_back();
+    *w.host = 0;
+    handed_out++;
+    return w;
+  }
+  void put(StatusWord w) {
+    if (!w.host) return;
+    std::lock_guard<std::mutex> lk(mu);
+    free_.push_back(w);
+    handed_out--;
+  }
+};
+// (never destroyed: thread_local destructors of late-exiting threads may still hand words back during process exit)
+StatusPool& status_pool() {
+  static StatusPool* p = new StatusPool;
+  return *p;
+}
+struct ThreadStatus {
+  StatusWord w;
+  ~ThreadStatus() { status_pool().put(w); }
+};
+thread_local ThreadStatus t_status;
+std::mutex g_status_mu;
+std::map<std::pair<int, void*>, StatusWord> g_stream_status;  // (device, stream) -> the word of its asynchronous calls
+}  // namespace
+// the word a call's kernels report to (nullptr: the allocation failed)
+static StatusWord* status_word(bool synchronous, int device, void* stream = nullptr) {
+  if (synchronous) {
+    if (!t_status.w.host) t_status.w = status_pool().get();
+    return t_status.w.host ? &t_status.w : nullptr;
+  }
   std::lock_guard<std::mutex> lk(g_status_mu);
-  return g_dev_status[device].alloc() ? &g_dev_status[device] : nullptr;
+  StatusWord& w = g_stream_status[{device, stream}];  // (node addresses of a std::map are stable)
+  if (!w.host) w = status_pool().get();
+  return w.host ? &w : nullptr;
+}
+// was the flag of (device, stream) raised since it was last reported?  all_streams: any stream of the device
+static bool status_take(int device, void* stream, bool all_streams) {
+  std::lock_guard<std::mutex> lk(g_status_mu);
+  bool raised = false;
+  if (all_streams) {
+    for (auto it = g_stream_status.lower_bound({device, nullptr}); it != g_stream_status.end() && it->first.first == device; ++it)
+      raised = it->second.take() || raised;
+  } else {
+    auto it = g_stream_status.find({device, stream});
+    if (it != g_stream_status.end()) raised = it->second.take();
+  }
+  return raised;
+}
+static void status_forget_stream(int device, void* stream) {
+  std::lock_guard<std::mutex> lk(g_status_mu);
+  auto it = g_stream_status.find({device, stream});
+  if (it == g_stream_status.end()) return;
+  status_pool().put(it->second);
+  g_stream_status.erase(it);
 }
 static int singular_error() {
   return fail(ABRK_ESINGULAR, "Singular matrix: the joint-space inertia matrix M of at least one row is not positive "
@@ -350,6 +409,9 @@ extern "C" int abrk_memcpy_d2h(int device, void* dst, const void* src, size_t by
   if (int rc = use_device(device)) return rc;
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  // the stream is drained: a singular batch enqueued on it earlier is reported here (the bytes ARE copied; the torques of
+  // the offending rows are unspecified - a caller that reads results back this way must not get them silently)
+  if (status_take(device, stream, false)) return singular_error();
   return 0;
 }
 extern "C" int abrk_memset(int device, void* dst, int value, size_t bytes, void* stream) {
@@ -373,7 +435,8 @@ void wl_forget_stream(int device, hipStream_t stream);  // the six-row kernels' 
 extern "C" int abrk_stream_destroy(int device, void* stream) {
   if (int rc = use_device(device)) return rc;
   if (stream) wl_forget_stream(device, (hipStream_t)stream);
-  HIPCHK(hipStreamDestroy((hipStream_t)stream));
+  HIPCHK(hipStreamDestroy((hipStream_t)stream));  // (waits for the stream's work: nothing writes its word any more)
+  if (stream) status_forget_stream(device, stream);
   return 0;
 }
 extern "C" int abrk_stream_sync(int device, void* stream) {
@@ -390,21 +453,14 @@ extern "C" int abrk_stream_sync(int device, void* stream) {
   } else {
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   }
-  // the device's sticky "M not positive definite" flag of asynchronous (device-pointer) OSC calls: reported once
-  // (under the lock that guards the word's allocation: another thread may be making its first call on this device)
-  if (device < kMaxStatusDevices) {
-    bool raised;
-    {
-      std::lock_guard<std::mutex> lk(g_status_mu);
-      raised = g_dev_status[device].take();
-    }
-    if (raised) return singular_error();
-  }
+  // the "M not positive definite" flag of THIS stream's asynchronous (device-pointer) OSC calls: reported once
+  if (status_take(device, stream, false)) return singular_error();
   return 0;
 }
 extern "C" int abrk_device_sync(int device) {
   if (int rc = use_device(device)) return rc;
   HIPCHK(hipDeviceSynchronize());
+  if (status_take(device, nullptr, true)) return singular_error();  // every stream of the device is drained
   return 0;
 }
 extern "C" void* abrk_event_create(int device) {
@@ -896,6 +952,12 @@ extern "C" int abrk_scratch_stats(int device, abrk_scratch_info* out) {
   }
   out->inline_fallbacks = g_wl_inline_fallbacks.load();
   out->evictions = g_wl_evictions.load();
+  {
+    StatusPool& sp = status_pool();
+    std::lock_guard<std::mutex> lk(sp.mu);
+    out->status_words_out = sp.handed_out;
+    out->status_blocks = sp.blocks;
+  }
   if (int rc = use_device(device)) return rc;
   size_t fr = 0, tot = 0;
   HIPCHK(hipMemGetInfo(&fr, &tot));
@@ -1030,7 +1092,7 @@ static int osc_generate_impl(int arm_id, int dtype, const abrk_osc_params* P, in
     if (int rc = worklist_for(device, (hipStream_t)stream, B, n, dtype, &oa.wl, &oa.rec, wl_hold)) return rc;
   OscP<double> p64 = make_oscp<double>(*P, n);
   OscP<float> p32 = make_oscp<float>(*P, n);
-  StatusWord* sw = status_word(st.staged, device);
+  StatusWord* sw = status_word(st.staged, device, stream);
   p64.status = p32.status = sw ? sw->dev : nullptr;
   if (sw && st.staged) *sw->host = 0;  // (this thread's word: nothing of an earlier, failed call is left in it)
   const ArmOps* ops = a->ops;
@@ -1102,21 +1164,27 @@ extern "C" int abrk_osc_generate_coop_batch(int arm_id, int dtype, const abrk_os
 // One call, host arrays, all the devices the caller names: the batch is cut into contiguous row shards
 // (sizes differing by at most one row; BASELINE config 4: 2^20 rows over 8 GPUs), each shard staged to its device's scratch
 // arena, evaluated by the same kernel on that device's own stream, and copied back.  Rows are independent: there is no
-// exchange step and therefore no collective.  All kernels are in flight before the first result is waited for, so
-// the devices overlap; the staging copies themselves run on the calling thread (pageable host memory), which is
-// what bounds this entry point - callers that keep their shards resident use one abrk_osc_generate_batch / plan per
-// device instead (bench.py --gpus N: one process per GPU).
+// exchange step and therefore no collective.  Round 6: the shards of one DEVICE are one unit of work - staged in,
+// launched and collected by one host thread per device (the calling thread takes the first device, short-lived workers
+// the others), under that device's lock only: the staging copies (pageable host memory: synchronous on the thread that
+// issues them) of different devices run side by side, and calls on disjoint device sets do not wait for each other.
+// Callers that keep their shards RESIDENT use the abrk_*_resident entry points below (device pointer tables, enqueue
+// only) or one process per GPU (bench.py --gpus N).
 namespace {
 struct ShardCtx {
   hipStream_t stream = nullptr;
   char* base = nullptr;
   size_t cap = 0;
 };
-std::mutex g_shard_mu;
+constexpr int kMaxShardDevices = 64;
+std::mutex g_shard_mu;                       // the registry below (look-ups only)
+std::mutex g_shard_dev_mu[kMaxShardDevices];  // the scratch arenas of one device's contexts (held while a call uses them)
 // (device, slot on that device) -> context; heap-allocated: the pointers handed out stay valid as the table grows
 std::vector<std::pair<std::pair<int, int>, std::unique_ptr<ShardCtx>>> g_shard_ctx;
 
-ShardCtx* shard_ctx(int device, int slot, size_t need) {
+// the context of (device, slot), its stream created; the calling thread's current device must be `device`
+ShardCtx* shard_ctx_find(int device, int slot) {
+  std::lock_guard<std::mutex> lk(g_shard_mu);
   ShardCtx* c = nullptr;
   for (auto& e : g_shard_ctx)
     if (e.first.first == device && e.first.second == slot) c = e.second.get();
@@ -1125,8 +1193,17 @@ ShardCtx* shard_ctx(int device, int slot, size_t need) {
     c = g_shard_ctx.back().second.get();
   }
   if (!c->stream && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  return c;
+}
+// ... with at least `need` bytes of device scratch (caller holds g_shard_dev_mu[device])
+ShardCtx* shard_ctx(int device, int slot, size_t need) {
+  ShardCtx* c = shard_ctx_find(device, slot);
+  if (!c) return nullptr;
   if (c->cap < need) {
-    if (c->base) (void)hipFree(c->base);
+    if (c->base) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipFree(c->base);
+    }
     c->base = nullptr;
     c->cap = 0;
     const size_t cap = need + need / 4;
@@ -1141,7 +1218,8 @@ namespace {
 // One host batch over several devices: [0, B) is cut into n_shards contiguous row ranges (sizes differing by at most one
 // row - abr_control_amd/sharding.py shard_range), the pieces of shard g are staged to devices[g] on a stream of its own,
 // `launch(dev, rows, stream)` enqueues the kernel(s) on it (dev[k]: device address of piece k, null for an absent one),
-// and only when every shard is in flight are the results collected.  No collective: rows are independent.
+// and only when every shard of a device is in flight are that device's results collected.  No collective: rows are
+// independent.
 struct ShardPiece {
   const void* host_in;
   void* host_out;
@@ -1158,7 +1236,8 @@ int run_sharded(int64_t B, int n_shards, const int* devices, const ShardPiece* p
     for (const void* p : ptrs) {
       hipPointerAttribute_t at;
       if (p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice)
-        return fail(ABRK_EINVAL, "the sharded entry points take host arrays (a device pointer lives on one device)");
+        return fail(ABRK_EINVAL, "the *_sharded entry points take host arrays (a device pointer lives on one device); "
+                                 "shards that live on the devices go through the *_resident entry points");
       (void)hipGetLastError();  // plain malloc'ed memory is "invalid value" to HIP
     }
   }
@@ -1168,60 +1247,90 @@ int run_sharded(int64_t B, int n_shards, const int* devices, const ShardPiece* p
     return fail(ABRK_ENODEV, "no HIP device available; libabrk has no CPU fallback");
   }
   for (int g = 0; g < n_shards; g++)
-    if (devices[g] < 0 || devices[g] >= ndev) return fail(ABRK_EINVAL, "device %d outside 0..%d", devices[g], ndev - 1);
+    if (devices[g] < 0 || devices[g] >= ndev || devices[g] >= kMaxShardDevices)
+      return fail(ABRK_EINVAL, "device %d outside 0..%d", devices[g], ndev - 1);
   constexpr int kMaxPieces = 16;
   if (n_pieces > kMaxPieces) return fail(ABRK_EINVAL, "too many arrays for one sharded call");
-  std::lock_guard<std::mutex> lk(g_shard_mu);
   struct Shard {
     ShardCtx* c;
-    int device;
+    int device, slot, index;
     int64_t r0, rows;
     char* dev[kMaxPieces];
   };
   std::vector<Shard> shards;
-  std::vector<int> per_dev(ndev, 0);
+  std::vector<int> per_dev(ndev, 0), order;  // order: the distinct devices, as first named
   for (int g = 0; g < n_shards; g++) {
     const int64_t base = B / n_shards, extra = B % n_shards;
     const int64_t r0 = g * base + (g < extra ? g : extra), r1 = r0 + base + (g < extra ? 1 : 0);
     if (r1 == r0) continue;
     Shard sh{};
     sh.device = devices[g];
+    sh.index = g;
     sh.r0 = r0;
     sh.rows = r1 - r0;
-    size_t need = 0;
-    for (int k = 0; k < n_pieces; k++)
-      if (pieces[k].host_in || pieces[k].host_out) need += (sh.rows * pieces[k].per_row + 255) & ~size_t(255);
-    HIPCHK(hipSetDevice(sh.device));
-    t_current_device = sh.device;
-    sh.c = shard_ctx(sh.device, per_dev[sh.device]++, need);
-    if (!sh.c) {
-      (void)hipGetLastError();
-      return fail(ABRK_ENOMEM, "shard %d: stream / %zu bytes of scratch on device %d", g, need, sh.device);
-    }
-    size_t off = 0;
-    for (int k = 0; k < n_pieces; k++) {
-      const ShardPiece& pc = pieces[k];
-      sh.dev[k] = nullptr;
-      if (!pc.host_in && !pc.host_out) continue;
-      sh.dev[k] = sh.c->base + off;
-      off += (sh.rows * pc.per_row + 255) & ~size_t(255);
-      if (pc.host_in)
-        HIPCHK(hipMemcpyAsync(sh.dev[k], (const char*)pc.host_in + r0 * pc.per_row, sh.rows * pc.per_row,
-                              hipMemcpyHostToDevice, sh.c->stream));
-    }
-    HIPCHK(launch(sh.dev, sh.rows, sh.c->stream));
+    if (per_dev[sh.device] == 0) order.push_back(sh.device);
+    sh.slot = per_dev[sh.device]++;
     shards.push_back(sh);
   }
-  // every kernel is enqueued; now collect (a device-to-host copy into pageable memory waits for its shard)
-  for (Shard& sh : shards) {
-    HIPCHK(hipSetDevice(sh.device));
-    t_current_device = sh.device;
-    for (int k = 0; k < n_pieces; k++)
-      if (pieces[k].host_out && sh.dev[k])
-        HIPCHK(hipMemcpyAsync((char*)pieces[k].host_out + sh.r0 * pieces[k].per_row, sh.dev[k],
-                              sh.rows * pieces[k].per_row, hipMemcpyDeviceToHost, sh.c->stream));
-    HIPCHK(hipStreamSynchronize(sh.c->stream));
-  }
+  // everything one device has to do (its lock held throughout: the contexts' scratch arenas are per (device, slot))
+  auto device_work = [&](int device) -> int {
+    std::lock_guard<std::mutex> lk(g_shard_dev_mu[device]);
+    HIPCHK(hipSetDevice(device));
+    t_current_device = device;
+    for (Shard& sh : shards) {
+      if (sh.device != device) continue;
+      size_t need = 0;
+      for (int k = 0; k < n_pieces; k++)
+        if (pieces[k].host_in || pieces[k].host_out) need += (sh.rows * pieces[k].per_row + 255) & ~size_t(255);
+      sh.c = shard_ctx(device, sh.slot, need);
+      if (!sh.c) {
+        (void)hipGetLastError();
+        return fail(ABRK_ENOMEM, "shard %d: stream / %zu bytes of scratch on device %d", sh.index, need, device);
+      }
+      size_t off = 0;
+      for (int k = 0; k < n_pieces; k++) {
+        const ShardPiece& pc = pieces[k];
+        sh.dev[k] = nullptr;
+        if (!pc.host_in && !pc.host_out) continue;
+        sh.dev[k] = sh.c->base + off;
+        off += (sh.rows * pc.per_row + 255) & ~size_t(255);
+        if (pc.host_in)
+          HIPCHK(hipMemcpyAsync(sh.dev[k], (const char*)pc.host_in + sh.r0 * pc.per_row, sh.rows * pc.per_row,
+                                hipMemcpyHostToDevice, sh.c->stream));
+      }
+      HIPCHK(launch(sh.dev, sh.rows, sh.c->stream));
+    }
+    // every kernel of this device is enqueued; now collect (a device-to-host copy into pageable memory waits for its shard)
+    for (Shard& sh : shards) {
+      if (sh.device != device) continue;
+      for (int k = 0; k < n_pieces; k++)
+        if (pieces[k].host_out && sh.dev[k])
+          HIPCHK(hipMemcpyAsync((char*)pieces[k].host_out + sh.r0 * pieces[k].per_row, sh.dev[k],
+                                sh.rows * pieces[k].per_row, hipMemcpyDeviceToHost, sh.c->stream));
+      HIPCHK(hipStreamSynchronize(sh.c->stream));
+    }
+    return 0;
+  };
+  if (order.size() == 1) return device_work(order[0]);
+  // several devices: one host thread each (the caller's own for the first); a worker's error text travels back with its code
+  std::vector<int> rcs(order.size(), 0);
+  std::vector<std::string> msgs(order.size());
+  std::vector<std::thread> workers;
+  for (size_t i = 1; i < order.size(); i++)
+    workers.emplace_back([&, i] {
+      rcs[i] = device_work(order[i]);
+      if (rcs[i]) msgs[i] = g_err;
+    });
+  rcs[0] = device_work(order[0]);
+  if (rcs[0]) msgs[0] = g_err;
+  for (auto& w : workers) w.join();
+  (void)hipSetDevice(order[0]);
+  t_current_device = order[0];
+  for (size_t i = 0; i < order.size(); i++)
+    if (rcs[i]) {
+      g_err = msgs[i];
+      return rcs[i];
+    }
   return 0;
 }
 }  // namespace
@@ -1350,6 +1459,173 @@ extern "C" int abrk_dynamics_sharded(int arm_id, int dtype, int64_t B, const voi
     for (int i = 0; i < 10; i++) da.out[i] = dev[2 + i];
     return a->ops->dyn(dtype, LaunchArgs{arm_table(a, dtype), (long)rows, st}, da);
   });
+}
+
+// ------------------------------------------------------------------------------- resident shards
+// "Results remain in per-device buffers unless the caller asks for host arrays": a batch whose shards LIVE on the
+// devices.  Every array argument is a table of n_shards device pointers (shard g: rows[g] rows on devices[g]); a call
+// only ENQUEUES - shard g's kernels on shard g's stream, nothing is staged, nothing is waited for - by going through the
+// single-device entry point of the same name once per shard (so everything that holds there holds here: the six-row
+// law's (device, stream) scratch, the per-(device, stream) ABRK_ESINGULAR word, per-row state staying with its shard).
+// abrk_shards_sync drains the shards' streams.  One host thread, N GPUs, no collective.
+namespace {
+int check_cut(const abrk_shard_cut* cut) {
+  if (!cut || cut->n_shards < 1 || !cut->devices || !cut->rows)
+    return fail(ABRK_EINVAL, "shard cut: n_shards >= 1, devices and rows are required");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(ABRK_ENODEV, "no HIP device available; libabrk has no CPU fallback");
+  }
+  for (int g = 0; g < cut->n_shards; g++) {
+    if (cut->devices[g] < 0 || cut->devices[g] >= ndev || cut->devices[g] >= kMaxShardDevices)
+      return fail(ABRK_EINVAL, "shard %d: device %d outside 0..%d", g, cut->devices[g], ndev - 1);
+    if (cut->rows[g] < 0) return fail(ABRK_EINVAL, "shard %d: negative row count", g);
+  }
+  return 0;
+}
+// the stream shard g runs on: the caller's, or the library's stream of (device, k) for the k-th shard named on that device
+int cut_stream(const abrk_shard_cut* cut, int g, void** out) {
+  if (cut->streams) {
+    *out = cut->streams[g];
+    return 0;
+  }
+  int slot = 0;
+  for (int h = 0; h < g; h++) slot += cut->devices[h] == cut->devices[g] ? 1 : 0;
+  if (int rc = use_device(cut->devices[g])) return rc;
+  ShardCtx* c = shard_ctx_find(cut->devices[g], slot);
+  if (!c) {
+    (void)hipGetLastError();
+    return fail(ABRK_ENODEV, "shard %d: no stream on device %d", g, cut->devices[g]);
+  }
+  *out = c->stream;
+  return 0;
+}
+// entry g of a pointer table (a NULL table: the array is absent in every shard)
+template <class P>
+P tab_at(P const* tab, int g) {
+  return tab ? tab[g] : nullptr;
+}
+// a resident array must be memory the device reads in place: device memory or pinned host memory
+int check_resident(int g, const char* name, const void* p) {
+  if (!p) return 0;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ABRK_EINVAL, "shard %d: %s is a pageable host pointer - the *_resident entry points take device "
+                             "pointers (host arrays go through the *_sharded entry points)", g, name);
+  }
+  return 0;
+}
+template <class Call>
+int for_each_shard(const abrk_shard_cut* cut, Call&& call) {
+  if (int rc = check_cut(cut)) return rc;
+  for (int g = 0; g < cut->n_shards; g++) {
+    if (cut->rows[g] == 0) continue;
+    void* stream = nullptr;
+    if (int rc = cut_stream(cut, g, &stream)) return rc;
+    if (int rc = call(g, cut->devices[g], cut->rows[g], stream)) return rc;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" void* abrk_shard_stream(int device, int slot) {
+  if (slot < 0 || device >= kMaxShardDevices || use_device(device)) return nullptr;
+  ShardCtx* c = shard_ctx_find(device, slot);
+  if (!c) {
+    (void)hipGetLastError();
+    fail(ABRK_ENODEV, "no stream for (device %d, slot %d)", device, slot);
+    return nullptr;
+  }
+  return c->stream;
+}
+
+extern "C" int abrk_osc_generate_resident(int arm_id, int dtype, const abrk_osc_params* P, const abrk_shard_cut* cut,
+                                          const void* const* q, const void* const* dq, const void* const* target,
+                                          const void* const* target_velocity, void* const* integrated_error,
+                                          const void* const* u_null_ext, void* const* u, void* const* training_signal) {
+  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
+  return for_each_shard(cut, [&](int g, int device, int64_t rows, void* stream) -> int {
+    const struct { const char* name; const void* p; } arrs[] = {
+        {"q", q[g]}, {"dq", dq[g]}, {"target", target[g]}, {"target_velocity", tab_at(target_velocity, g)},
+        {"integrated_error", tab_at(integrated_error, g)}, {"u_null_ext", tab_at(u_null_ext, g)}, {"u", u[g]},
+        {"training_signal", tab_at(training_signal, g)}};
+    for (auto& a : arrs)
+      if (int rc = check_resident(g, a.name, a.p)) return rc;
+    return osc_generate_impl(arm_id, dtype, P, rows, q[g], dq[g], target[g], tab_at(target_velocity, g),
+                             tab_at(integrated_error, g), tab_at(u_null_ext, g), u[g], tab_at(training_signal, g), 0,
+                             nullptr, device, stream);
+  });
+}
+
+extern "C" int abrk_sliding_generate_resident(int arm_id, int dtype, const abrk_sliding_params* P,
+                                              const abrk_shard_cut* cut, const void* const* q, const void* const* dq,
+                                              const void* const* target, const void* const* target_velocity,
+                                              const void* const* target_acc, void* const* u, void* const* s_out) {
+  if (!q || !dq || !target || !u) return fail(ABRK_EINVAL, "q, dq, target and u are required");
+  return for_each_shard(cut, [&](int g, int device, int64_t rows, void* stream) -> int {
+    const struct { const char* name; const void* p; } arrs[] = {
+        {"q", q[g]}, {"dq", dq[g]}, {"target", target[g]}, {"target_velocity", tab_at(target_velocity, g)},
+        {"target_acc", tab_at(target_acc, g)}, {"u", u[g]}, {"s", tab_at(s_out, g)}};
+    for (auto& a : arrs)
+      if (int rc = check_resident(g, a.name, a.p)) return rc;
+    return abrk_sliding_generate_batch(arm_id, dtype, P, rows, q[g], dq[g], target[g], tab_at(target_velocity, g),
+                                       tab_at(target_acc, g), u[g], tab_at(s_out, g), device, stream);
+  });
+}
+
+extern "C" int abrk_joint_generate_resident(int arm_id, int dtype, const abrk_null_ctrl* ctrl, int account_for_gravity,
+                                            const abrk_shard_cut* cut, const void* const* q, const void* const* dq,
+                                            const void* const* target, const void* const* target_velocity,
+                                            void* const* u) {
+  if (!q || !dq || !u) return fail(ABRK_EINVAL, "q, dq and u are required");
+  return for_each_shard(cut, [&](int g, int device, int64_t rows, void* stream) -> int {
+    const struct { const char* name; const void* p; } arrs[] = {
+        {"q", q[g]}, {"dq", dq[g]}, {"target", tab_at(target, g)}, {"target_velocity", tab_at(target_velocity, g)},
+        {"u", u[g]}};
+    for (auto& a : arrs)
+      if (int rc = check_resident(g, a.name, a.p)) return rc;
+    return abrk_joint_generate_batch(arm_id, dtype, ctrl, account_for_gravity, rows, q[g], dq[g], tab_at(target, g),
+                                     tab_at(target_velocity, g), u[g], device, stream);
+  });
+}
+
+extern "C" int abrk_dynamics_resident(int arm_id, int dtype, const abrk_shard_cut* cut, const void* const* q,
+                                      const void* const* dq, int frame, const double* x_off, uint32_t want,
+                                      const abrk_dyn_out* out) {
+  if (!q || !out) return fail(ABRK_EINVAL, "q and out (one abrk_dyn_out per shard) are required");
+  return for_each_shard(cut, [&](int g, int device, int64_t rows, void* stream) -> int {
+    if (int rc = check_resident(g, "q", q[g])) return rc;
+    if (int rc = check_resident(g, "dq", tab_at(dq, g))) return rc;
+    void* const* outs = reinterpret_cast<void* const*>(&out[g]);
+    for (int i = 0; i < 10; i++)
+      if (want >> i & 1)
+        if (int rc = check_resident(g, "an output array", outs[i])) return rc;
+    return abrk_dynamics_batch(arm_id, dtype, rows, q[g], tab_at(dq, g), frame, x_off, want, &out[g], device, stream);
+  });
+}
+
+extern "C" int abrk_shards_sync(const abrk_shard_cut* cut) {
+  // every stream is drained before anything is reported: a singular shard does not leave its neighbours running
+  bool singular = false;
+  int first_rc = 0;
+  std::string first_msg;
+  const int rc = for_each_shard(cut, [&](int, int device, int64_t, void* stream) -> int {
+    const int r = abrk_stream_sync(device, stream);
+    if (r == ABRK_ESINGULAR) singular = true;
+    else if (r && !first_rc) {
+      first_rc = r;
+      first_msg = g_err;
+    }
+    return 0;
+  });
+  if (rc) return rc;
+  if (first_rc) {
+    g_err = first_msg;
+    return first_rc;
+  }
+  return singular ? singular_error() : 0;
 }
 
 // ------------------------------------------------------------------------------- Sliding
@@ -1591,7 +1867,7 @@ extern "C" int abrk_osc_law_batch(int n_joints, int dtype, const abrk_osc_params
   a.ts = st.fix(ts_, training_signal);
   OscP<double> p64 = make_oscp<double>(*P, n);
   OscP<float> p32 = make_oscp<float>(*P, n);
-  StatusWord* sw = status_word(st.staged, device);
+  StatusWord* sw = status_word(st.staged, device, stream);
   p64.status = p32.status = sw ? sw->dev : nullptr;
   if (sw && st.staged) *sw->host = 0;  // (this thread's word: nothing of an earlier, failed call is left in it)
   a.P = nullptr;
@@ -1783,7 +2059,7 @@ extern "C" int abrk_osc_rollout_twolink_batch(int arm_id, int dtype, const abrk_
   ra.ut = st.fix(ut_, u_traj);
   OscP<double> p64 = make_oscp<double>(*P, n);
   OscP<float> p32 = make_oscp<float>(*P, n);
-  StatusWord* sw = status_word(st.staged, device);
+  StatusWord* sw = status_word(st.staged, device, stream);
   p64.status = p32.status = sw ? sw->dev : nullptr;
   if (sw && st.staged) *sw->host = 0;  // (this thread's word: nothing of an earlier, failed call is left in it)
   const TwoLinkP<double> k64 = make_plant<double>(*plant);
@@ -1989,6 +2265,17 @@ extern "C" int abrk_plan_launch_graph(int plan, int repeat) {
     pl->graph_repeat = repeat;
   }
   HIPCHK(hipGraphLaunch(pl->graph_exec, pl->stream));
+  return 0;
+}
+
+// One tick (or `repeat` of them) of SEVERAL plans from one call - the plans of a sharded control loop, one per shard /
+// device: mode 0 = `repeat` plain launches of each plan, 1 = one hipGraph of `repeat` ticks per plan (captured on first use,
+// abrk_plan_launch_graph).  Every device has its work before the call returns; nothing is waited for.
+extern "C" int abrk_plans_launch(const int* plans, int n_plans, int repeat, int mode) {
+  if (!plans || n_plans < 1) return fail(ABRK_EINVAL, "plans / n_plans");
+  if (mode != 0 && mode != 1) return fail(ABRK_EINVAL, "mode must be 0 (plain launches) or 1 (graph replay)");
+  for (int i = 0; i < n_plans; i++)
+    if (int rc = mode ? abrk_plan_launch_graph(plans[i], repeat) : abrk_plan_launch_repeat(plans[i], repeat)) return rc;
   return 0;
 }
 

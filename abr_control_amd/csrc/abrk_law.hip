@@ -46,10 +46,12 @@ osc6_finish_group_kernel(const unsigned long long* __restrict__ masks, const T* 
     if (lane >= d) incl += v;
   }
   const int total = __builtin_amdgcn_readlane(incl, kBlock - 1);
-  if (wi >= total) return;
+  if (total == 0) return;
   const int c = lane < N + 2 ? lane : N + 1;  // (idle lanes shadow the last column)
   const int jc = lane < N ? lane : 0;
   if (total <= coop_max) {
+    // (a wavefront beyond the group's record count has nothing to do HERE; in the one-record-per-lane branch below
+    //  wavefront wi owns CHUNK wi, whatever `total` is - coop_max == 0, i.e. ABRK_FINISH_ROUNDS=0, sends every group there)
     for (int r = wi; r < total; r += wg) {
       const unsigned long long above = __ballot(incl > r);  // the chunk that holds record r: the first lane whose count passes it
       const int ch = __builtin_ctzll(above);

@@ -266,6 +266,118 @@ def dynamics_sharded(arm_id, n, q, devices, dq=None, frame=None, x_off=None, wan
     return res
 
 
+# ---------------------------------------------------------------------------- resident shards
+class _Cut:
+    """abrk_shard_cut + the pointer tables of one resident call (sharding.ShardedArray arguments)"""
+
+    def __init__(self, like, dtype, streams=None):
+        self.devices, self.rows = list(like.devices), list(like.rows)
+        self.G = len(self.devices)
+        self.np_dtype, self.code = np.dtype(dtype), _dtype_code(dtype)
+        self._dev = (C.c_int32 * self.G)(*self.devices)
+        self._rows = (C.c_int64 * self.G)(*self.rows)
+        self._streams = None
+        if streams is not None:
+            if len(streams) != self.G:
+                raise ValueError(f"{len(streams)} streams for {self.G} shards")
+            self._streams = (C.c_void_p * self.G)(*[_sp(st) for st in streams])
+        self.c = _abi.ShardCut(self.G, self._dev, self._rows, self._streams)
+
+    def tab(self, arr, tail, name):
+        """pointer table of a ShardedArray (None -> NULL), checked against the cut"""
+        if arr is None:
+            return None
+        if list(arr.devices) != self.devices or list(arr.rows) != self.rows:
+            raise ValueError(f"{name}: cut over other devices / rows than q")
+        if arr.dtype != self.np_dtype or tuple(arr.shape[1:]) != tuple(tail):
+            raise ValueError(f"{name}: expected {self.np_dtype}[B{tuple(tail)}], got {arr.dtype}{arr.shape}")
+        return (C.c_void_p * self.G)(*[p.ptr for p in arr.parts])
+
+    def out(self, given, tail, name):
+        from .sharding import ShardedArray
+
+        if given is None:
+            given = ShardedArray.empty((sum(self.rows),) + tuple(tail), self.np_dtype, self.devices, rows=self.rows)
+        return self.tab(given, tail, name), given
+
+
+def osc_generate_resident(arm_id, n, params, q, dq, target, target_velocity=None, integrated_error=None,
+                          u_null_ext=None, u=None, training_signal=False, dtype=np.float64, streams=None):
+    """OSC.generate on a batch whose shards LIVE on the devices (abrk_osc_generate_resident): every array a
+    sharding.ShardedArray cut the same way; the call only enqueues (shard g on streams[g], or on the library's own
+    stream of its (device, slot)).  integrated_error [B,6] stays with its shards.  Returns u, or (u, training_signal),
+    as ShardedArrays - not yet complete: sync with `shards_sync(u)` / MultiDevice.sync()."""
+    c = _Cut(q, dtype, streams)
+    qp, dqp, tp = c.tab(q, (n,), "q"), c.tab(dq, (n,), "dq"), c.tab(target, (6,), "target")
+    tvp, unp = c.tab(target_velocity, (6,), "target_velocity"), c.tab(u_null_ext, (n,), "u_null_ext")
+    iep = c.tab(integrated_error, (6,), "integrated_error")
+    up, uo = c.out(u, (n,), "u")
+    tsp, tso = None, None
+    if training_signal is not False and training_signal is not None:
+        tsp, tso = c.out(None if training_signal is True else training_signal, (n,), "training_signal")
+    check(lib().abrk_osc_generate_resident(arm_id, c.code, C.byref(params), C.byref(c.c), qp, dqp, tp, tvp, iep, unp, up,
+                                           tsp))
+    return (uo, tso) if tso is not None else uo
+
+
+def sliding_generate_resident(arm_id, n, params, q, dq, target, target_velocity=None, target_acc=None, u=None,
+                              want_s=False, dtype=np.float64, streams=None):
+    """Sliding.generate on resident shards (abrk_sliding_generate_resident)"""
+    c = _Cut(q, dtype, streams)
+    nt = 3 if params.cartesian else n
+    qp, dqp, tp = c.tab(q, (n,), "q"), c.tab(dq, (n,), "dq"), c.tab(target, (nt,), "target")
+    tvp, tap = c.tab(target_velocity, (nt,), "target_velocity"), c.tab(target_acc, (nt,), "target_acc")
+    up, uo = c.out(u, (n,), "u")
+    sp, so = c.out(None if want_s is True else want_s, (n,), "s") if want_s else (None, None)
+    check(lib().abrk_sliding_generate_resident(arm_id, c.code, C.byref(params), C.byref(c.c), qp, dqp, tp, tvp, tap, up, sp))
+    return (uo, so) if want_s else uo
+
+
+def joint_generate_resident(arm_id, n, ctrl, account_for_gravity, q, dq, target=None, target_velocity=None, u=None,
+                            dtype=np.float64, streams=None):
+    """Joint / Damping / RestingConfig.generate on resident shards (abrk_joint_generate_resident)"""
+    c = _Cut(q, dtype, streams)
+    qp, dqp = c.tab(q, (n,), "q"), c.tab(dq, (n,), "dq")
+    tp, tvp = c.tab(target, (n,), "target"), c.tab(target_velocity, (n,), "target_velocity")
+    up, uo = c.out(u, (n,), "u")
+    check(lib().abrk_joint_generate_resident(arm_id, c.code, C.byref(ctrl), int(bool(account_for_gravity)), C.byref(c.c),
+                                             qp, dqp, tp, tvp, up))
+    return uo
+
+
+def dynamics_resident(arm_id, n, q, dq=None, frame=None, x_off=None, want=("M",), dtype=np.float64, streams=None,
+                      out=None):
+    """robot_config.{Tx,J,M,g,C,dJ,R,T,T_inv,quaternion} on resident shards (abrk_dynamics_resident):
+    {name: ShardedArray}"""
+    c = _Cut(q, dtype, streams)
+    frame = 2 * n + 1 if frame is None else frame
+    qp, dqp = c.tab(q, (n,), "q"), c.tab(dq, (n,), "dq")
+    bits, res = 0, {}
+    dos = (_abi.DynOut * c.G)()
+    for name in want:
+        bits |= _WANT_BITS[name]
+        _, obj = c.out(None if out is None else out.get(name), _OUT_SHAPES[name](n), name)
+        for g in range(c.G):
+            setattr(dos[g], name, obj.parts[g].ptr)
+        res[name] = obj
+    xo = None if x_off is None else (C.c_double * 3)(*[float(v) for v in x_off])
+    check(lib().abrk_dynamics_resident(arm_id, c.code, C.byref(c.c), qp, dqp, frame, xo, bits, dos))
+    return res
+
+
+def shards_sync(like, streams=None):
+    """drain the streams of a resident batch (abrk_shards_sync): raises SingularMatrixError once if any shard met a
+    singular M"""
+    c = _Cut(like, like.dtype, streams)
+    check(lib().abrk_shards_sync(C.byref(c.c)))
+
+
+def plans_launch(plans, repeat=1, graph=False):
+    """`repeat` ticks of several recorded plans (one per shard / device) from ONE call (abrk_plans_launch)"""
+    ids = (C.c_int * len(plans))(*[p.id for p in plans])
+    check(lib().abrk_plans_launch(ids, len(plans), int(repeat), 1 if graph else 0))
+
+
 def osc_law(n, params, J, M, dq, target, g=None, Cdq=None, xyz=None, R=None, q=None, target_velocity=None,
             integrated_error=None, u_null_ext=None, training_signal=False, dtype=np.float64, device=0, stream=None):
     """The OSC control law on caller-supplied dynamics (abrk_osc_law_batch): J [B,6,n], M [B,n,n] and,

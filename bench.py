@@ -786,6 +786,99 @@ def dry_run_rank(args, rank, world, group):
         group.close()
 
 
+def single_process(args):
+    """`python bench.py --gpus N --single-process`: ONE process, one host thread, N devices (the reference's usage
+    model - one process owning the whole control loop - scaled out).  Every device holds its shard resident and its own
+    recorded plan; a step is enqueued on all of them by one abrk_plans_launch (hipGraph replay of K ticks per device), then
+    every stream is drained.  Same blocks as the one-process-per-GPU line: `value` (weak scaling, the workload's batch per
+    device), `strong_scaling_cfg4` (global batch 2^20 cut over the devices), plus `resident_shard_step_cfg4`: the step of
+    config 4 as 8 resident shards against eight plain launches of one shard's size (one-GPU boxes: all shards on device 0
+    with --allow-shared-device)."""
+    import abr_control_amd as a
+    from abr_control_amd import engine
+    from abr_control_amd.sharding import shard_range
+
+    seen = a.device_count()
+    if seen < 1:
+        raise SystemExit("bench.py needs a HIP device: abr_control_amd has no CPU fallback")
+    N = args.gpus
+    if seen < N and not args.allow_shared_device:
+        print(json.dumps({"error": f"--gpus {N} --single-process but {seen} HIP device(s) enumerated; nothing was run "
+                                   f"(--allow-shared-device maps shard g to device g mod devices: a test flag, not a "
+                                   f"measurement)", "devices_seen": seen, "n_gpus": N}), flush=True)
+        return 1
+    devices = [g % seen for g in range(N)]
+    arm, B0, dts, kind, kw, _ = WORKLOADS[args.workload]
+    if kind in ("rollout", "ik"):
+        raise SystemExit("--single-process times recorded plans; the rollout / ik workloads have none")
+    B = args.batch or B0
+
+    def sync(runs):
+        for r in runs:
+            r.stream.sync()
+
+    def timed(runs, K, warm):
+        """K ticks on every device as ONE call (hipGraph of K nodes per device), wall clock around enqueue + drain"""
+        plans = [r.plan for r in runs]
+        if warm:
+            engine.plans_launch(plans, warm, graph=False)
+        engine.plans_launch(plans, K, graph=True)  # captures + instantiates every device's graph (untimed)
+        sync(runs)
+        t0 = time.perf_counter()
+        engine.plans_launch(plans, K, graph=True)
+        t_enq = time.perf_counter() - t0
+        sync(runs)
+        return time.perf_counter() - t0, t_enq
+
+    runs = [Runner(args.workload, B, d, a.Stream(d)) for d in devices]
+    wall, t_enq = timed(runs, args.steps, args.warmup)
+    out = {
+        "metric": "OSC control steps/sec (batched UR5 6-DOF)" if args.workload == "cfg2" else f"control steps/sec ({args.workload})",
+        "value": round(N * B * args.steps / wall, 1), "unit": "control steps/s", "n_gpus": N, "n_devices_seen": seen,
+        "devices": devices, "shared_device": len(set(devices)) < N, "process_model": "ONE process, one host thread, "
+        "a resident shard + recorded plan per device, K ticks per device enqueued by one abrk_plans_launch",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall / args.steps * 1e3, 6),
+        "host_enqueue_us_all_devices": round(t_enq * 1e6, 1), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dts, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {arm} {kind} batch={B} per GPU, inputs resident in HBM, "
+                               f"q~U(0,2pi) dq~U(0,5) target~U(-1,1) seed 1", "arm": arm, "batch_per_gpu": B,
+                   "global_batch": B * N, "parallelism": f"batch-shard x{N}, no collective, single process",
+                   "device": a.device_name(devices[0]), "launch": f"hipGraph replay, {args.steps} kernel nodes per device"},
+    }
+    del runs
+    if not args.no_strong_leg:
+        G = 1 << 20
+        r4 = [Runner("cfg4", shard_range(G, g, N)[1] - shard_range(G, g, N)[0], d, a.Stream(d),
+                     global_rows=(shard_range(G, g, N)[0], G)) for g, d in enumerate(devices)]
+        k4 = max(min(args.steps, 400), 8)
+        wall4, _ = timed(r4, k4, min(args.warmup, 50))
+        out["strong_scaling_cfg4"] = {
+            "workload": "cfg4: ur5 OSC + g + C, global batch 2^20 sharded by contiguous rows, no collective, one process",
+            "global_batch": G, "n_gpus": N, "n_devices_seen": seen, "rows_per_gpu": r4[0].B, "steps": k4,
+            "us_per_step": round(wall4 / k4 * 1e6, 3), "evals_per_s": round(G * k4 / wall4, 1), "scaling": "strong"}
+        del r4
+        # the resident 8-shard step of config 4 against eight plain launches of one shard's size on one stream
+        S = 8
+        rows = G // S
+        rs = [Runner("cfg4", rows, devices[g % N], a.Stream(devices[g % N]), global_rows=(g * rows, G)) for g in range(S)]
+        w8, enq8 = timed(rs, 200, 20)
+        del rs
+        one = Runner("cfg4", rows, devices[0], a.Stream(devices[0]), global_rows=(0, G))
+        _, ms1 = one.timed(400, 20)
+        same_dev = len(set(devices)) == 1
+        out["resident_shard_step_cfg4"] = {
+            "what": f"config 4's 2^20 rows as {S} resident shards of {rows} rows (one stream + one recorded plan each, "
+                    f"{'all on device ' + str(devices[0]) if same_dev else 'over devices ' + str(sorted(set(devices)))}), "
+                    f"200 ticks replayed by one abrk_plans_launch, wall clock per tick; beside it one shard's launch "
+                    f"(HIP events, one stream)", "shards": S, "rows_per_shard": rows,
+            "us_per_tick_all_shards": round(w8 / 200 * 1e6, 3), "host_enqueue_us": round(enq8 * 1e6, 1),
+            "us_per_plain_launch_one_shard": round(ms1 * 1e3, 3),
+            "ratio_to_eight_plain_launches": round((w8 / 200 * 1e6) / (S * ms1 * 1e3), 4) if same_dev else None}
+        del one
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -812,6 +905,9 @@ def main():
                     help="TEST flag: no device is touched; the ranks only meet (barrier, max, gather) and rank 0 prints "
                          "a stub line - drives the spawn / collect / failure logic of the self-launch on a CPU box")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="TEST flag: this rank exits 3 after the barrier")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives all --gpus N devices (resident shards, one recorded plan per device, "
+                         "abrk_plans_launch) instead of one process per GPU")
     ap.add_argument("--also", default="", help="comma-separated extra workloads: one HBM-sized roofline leg each "
                                                "(same process, so one rocprofv3 session sees every kernel)")
     args = ap.parse_args()
@@ -819,6 +915,10 @@ def main():
     from abr_control_amd.sharding import dist_env
 
     rank, local_rank, world = dist_env()
+    if args.single_process:
+        if world > 1:
+            raise SystemExit("--single-process under a one-process-per-GPU launcher makes no sense")
+        raise SystemExit(single_process(args))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:

@@ -148,7 +148,15 @@ typedef struct abrk_osc_params {
  *   u_null_ext [B,n] or NULL: extra secondary control signal already evaluated by the
  *     caller (any Python null controller), projected into the null space with the same
  *     filter as osc.py:315-318;
- *   u [B,n] out; training_signal [B,n] out or NULL (osc.py:297).                      */
+ *   u [B,n] out; training_signal [B,n] out or NULL (osc.py:297).
+ * training_signal == NULL changes the LAST BITS of u on one family of laws: the six-row law (any ctrlr_dof beyond x,y,z
+ * of the end effector) without optional inputs (no target_velocity / integrated_error / u_null_ext / null_ctrl) then
+ * runs kernels that never form the training signal (`osc_kernel<.., NOTS = true>`: the gravity term joins the velocity
+ * term before the factorisations instead of being subtracted from the finished sum).  Same law, same accuracy against
+ * the reference (both forms are held to the same 1e-6 against its outputs: tests/test_gpu_parity.py
+ * test_gpu_six_row_cases_without_training_signal), a different rounding order: u differs by ~1e-16 of its scale times
+ * cond(Mx_inv).  For a given choice of NULL / non-NULL a row's bits depend on nothing else (batch size, position in the
+ * batch, sharding).  Every other law returns the same bits either way.                                             */
 int abrk_osc_generate_batch(int arm_id, int dtype, const abrk_osc_params* params, int64_t B,
                             const void* q, const void* dq, const void* target,
                             const void* target_velocity, void* integrated_error,
@@ -345,7 +353,10 @@ int abrk_joint_generate_batch(int arm_id, int dtype, const abrk_null_ctrl* ctrl,
 /* The same for Sliding.generate (sliding.py:34-99; BASELINE config 5), Joint / Damping / RestingConfig.generate
  * (joint.py:104-131, damping.py:21-32, resting_config.py:18-42) and the robot_config functions (base_config.py:210-415):
  * arguments as the *_batch entry point of the same name, host arrays only, n_shards contiguous row ranges on
- * devices[0..n_shards-1], every kernel in flight before the first result is collected, no collective.              */
+ * devices[0..n_shards-1], no collective.  The shards of one device are staged in, launched and collected by one host
+ * thread per device (the caller's own for the first device named), under that device's lock only: staging copies of
+ * different devices overlap, and calls on disjoint device sets do not wait for each other.  Shards that should STAY
+ * on the devices: the *_resident entry points below.                                                              */
 int abrk_sliding_generate_sharded(int arm_id, int dtype, const abrk_sliding_params* params, int64_t B, const void* q,
                                   const void* dq, const void* target, const void* target_velocity,
                                   const void* target_acc, void* u, void* s_out, int n_shards, const int* devices);
@@ -355,6 +366,46 @@ int abrk_joint_generate_sharded(int arm_id, int dtype, const abrk_null_ctrl* ctr
 int abrk_dynamics_sharded(int arm_id, int dtype, int64_t B, const void* q, const void* dq, int frame,
                           const double* x_off, uint32_t want, const abrk_dyn_out* out, int n_shards,
                           const int* devices);
+
+/* ---- RESIDENT SHARDS ("results remain in per-device buffers unless the caller asks for host arrays";
+ * north_star: "the batch shards trivially across the 8 GPUs of one node").  A batch whose shards LIVE on the devices, driven
+ * by ONE host thread: every array argument is a table of n_shards DEVICE pointers - shard g holds rows[g] rows of every
+ * array on devices[g] (a device may appear more than once; a NULL table = the array is absent).  A call only ENQUEUES:
+ * shard g's kernels go to streams[g] (streams == NULL: the library's own stream of (device, k) for the k-th shard on
+ * that device, abrk_shard_stream), nothing is staged, nothing is waited for; per-row state (integrated_error) stays
+ * with its shard.  Semantics per shard are those of the *_batch entry point of the same name on (devices[g],
+ * streams[g]) - the call IS that entry point, once per shard - so results are bit-identical to the unsharded call on
+ * the same rows.  abrk_shards_sync drains every shard's stream and reports (once) ABRK_ESINGULAR of any of them.
+ * Control loops record one plan per shard (abrk_plan_begin(devices[g], streams[g]) ... abrk_plan_end) and replay all of
+ * them with one abrk_plans_launch per tick / per K ticks.  No collective, no exchange step: rows are independent.
+ * Replaces: the reference evaluates one state per Python call (controllers/osc.py:217-320); its usage model - one
+ * process owning the whole control loop, examples/PyGame/force_osc_xy.py:57-78 - scaled to N GPUs.               */
+typedef struct abrk_shard_cut {
+  int32_t n_shards;
+  const int32_t* devices; /* [n_shards] */
+  const int64_t* rows;    /* [n_shards]; 0 = the shard is skipped */
+  void* const* streams;   /* [n_shards] or NULL */
+} abrk_shard_cut;
+void* abrk_shard_stream(int device, int slot); /* the stream a NULL `streams` stands for; NULL on failure */
+int abrk_osc_generate_resident(int arm_id, int dtype, const abrk_osc_params* params, const abrk_shard_cut* cut,
+                               const void* const* q, const void* const* dq, const void* const* target,
+                               const void* const* target_velocity, void* const* integrated_error,
+                               const void* const* u_null_ext, void* const* u, void* const* training_signal);
+int abrk_sliding_generate_resident(int arm_id, int dtype, const abrk_sliding_params* params, const abrk_shard_cut* cut,
+                                   const void* const* q, const void* const* dq, const void* const* target,
+                                   const void* const* target_velocity, const void* const* target_acc, void* const* u,
+                                   void* const* s_out);
+int abrk_joint_generate_resident(int arm_id, int dtype, const abrk_null_ctrl* ctrl, int account_for_gravity,
+                                 const abrk_shard_cut* cut, const void* const* q, const void* const* dq,
+                                 const void* const* target, const void* const* target_velocity, void* const* u);
+/* out: [n_shards] abrk_dyn_out, one per shard (only the fields selected by `want` are read) */
+int abrk_dynamics_resident(int arm_id, int dtype, const abrk_shard_cut* cut, const void* const* q,
+                           const void* const* dq, int frame, const double* x_off, uint32_t want,
+                           const abrk_dyn_out* out);
+int abrk_shards_sync(const abrk_shard_cut* cut);
+/* `repeat` ticks of SEVERAL plans (one per shard) from one call: mode 0 = plain launches, 1 = one hipGraph of `repeat`
+ * ticks per plan (abrk_plan_launch_graph).  Returns when every plan's work is enqueued.                          */
+int abrk_plans_launch(const int* plans, int n_plans, int repeat, int mode);
 
 /* ---------------------------------------------------------------------------------
  * The remaining secondary controllers.  Each writes u [B,n]; with accumulate != 0 it
@@ -429,6 +480,9 @@ typedef struct abrk_scratch_info {
   int64_t evictions;           /* slots of idle / vanished streams that were recycled */
   int64_t device_free_bytes;   /* hipMemGetInfo of `device` */
   int64_t device_total_bytes;
+  int64_t status_words_out;    /* ABRK_ESINGULAR words in use: one per live thread that made a host-array OSC call, one
+                                  per (device, stream) that took a device-pointer OSC call and was not destroyed      */
+  int64_t status_blocks;       /* pinned 4 KiB blocks (64 words each) the pool holds; never shrinks                  */
 } abrk_scratch_info;
 int abrk_scratch_stats(int device, abrk_scratch_info* out);
 

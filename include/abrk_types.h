@@ -24,8 +24,17 @@ enum {
   ABRK_ESINGULAR = -6 /* a row's joint-space inertia matrix M is not positive definite: where the reference's
                          numpy.linalg.inv(M) raises LinAlgError (controllers/osc.py:136).  Host-array calls return
                          it themselves (the outputs of the offending rows are unspecified, every other row is
-                         valid); device-pointer calls are asynchronous - the flag is sticky per device and is
-                         returned (once) by the next abrk_stream_sync on that device                          */
+                         valid); device-pointer calls are asynchronous - the flag is kept per (device, stream) and is
+                         returned (once) by whatever drains THAT stream next: abrk_stream_sync, abrk_memcpy_d2h on
+                         it, or abrk_device_sync (any stream of the device).  Another stream's sync never reports it.
+                         Raised by abrk_osc_generate_batch / _full_batch / _sharded, abrk_osc_law_batch and the fused
+                         rollout; NOT by the helper abrk_osc_mx_batch (a singular M gives non-finite Mx / M_inv there)
+                         nor by the measurement variant abrk_osc_generate_coop_batch.
+                         Difference to the reference: the test is "a Cholesky pivot of M is a real number <= 0", the
+                         reference's is LAPACK's "exactly singular" (getrf hits a zero pivot).  In fp64 the two agree
+                         on every M a rigid-body model produces; in fp32 (dtype ABRK_F32) a valid but ill-conditioned
+                         M (cond ~1e7 and beyond) can round a pivot to <= 0 and raise here where the reference - which
+                         inverts a float32 M too, osc.py:136 - returns finite values of no accuracy.               */
 };
 
 /* ---------------------------------------------------------------------------------

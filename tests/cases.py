@@ -76,6 +76,21 @@ _osc("jaco2", "osc_rest", lambda n: P(n, kp=200, ctrlr_dof=XYZ, null_controllers
 _jt("jaco2", "damping", make_damping(10), False, no_target=True)
 
 
+def takes_plain_six_row_law(case_id):
+    """True where the case runs the six-row kernels with no optional input (`osc_kernel<.., 6, .., FEAT = 0, ..>`: not the
+    x,y,z / x,y fast paths of abrk_params.h osc_fast_rows, no target velocity, no integral state, no fused secondary
+    controller) - the law that has a `NOTS = true` twin for callers who ask for no training signal"""
+    case = CASES[case_id]
+    if case["kind"] != "osc" or case["tv"] or case["steps"] > 1:
+        return False
+    n = _abi.load_table(case["arm"])["n_joints"]
+    p = case["params"](n)
+    dof = [int(bool(v)) for v in p.ctrlr_dof]
+    ee = p.ref_frame == 2 * n + 1
+    fast = ee and (dof == XYZ or (dof == XY and n <= 3))
+    return not fast and p.n_null == 0 and p.ki == 0
+
+
 def run_case(backend, case, g, dtype=np.float64, rows=None):
     """Evaluate one case on a backend.  Returns (u, extra) with u shaped like `<key>_uD`."""
     key = case["key"]
@@ -188,9 +203,11 @@ class OracleBackend:
 class HostsimBackend:
     """the GPU row programs compiled for the CPU (tests/hostsim) - static or runtime-table arm"""
 
-    def __init__(self, arm, variant="static", handover=False):
+    def __init__(self, arm, variant="static", handover=False, training_signal=True):
         """handover: six-row laws run in the two-pass form libabrk launches up to 262144 rows (first pass without the
-        eigen-decomposition, deferred rows finished from their hand-over records); `deferred` counts those rows"""
+        eigen-decomposition, deferred rows finished from their hand-over records); `deferred` counts those rows.
+        training_signal=False: the call asks for no training signal, as bench.py and any C-ABI caller without that
+        buffer do - the plain six-row law then runs its NoTs arithmetic (osc() returns (u, None))"""
         from tests import hostsim
 
         self.h = hostsim
@@ -200,17 +217,20 @@ class HostsimBackend:
             self.tab = _abi.load_table(arm)
         self.n = self.tab["n_joints"]
         self.arm = arm if variant == "static" else self.tab
-        self.name = f"hostsim-{variant}" + ("-handover" if handover else "")
+        self.name = f"hostsim-{variant}" + ("-handover" if handover else "") + ("" if training_signal else "-nots")
         self.handover = handover
+        self.training_signal = training_signal
         self.deferred = 0
 
     def osc(self, params, q, dq, t, tv=None, ie=None, une=None, dtype=np.float64):
+        want = bool(self.training_signal)
         if self.handover:
-            u, ts, nd = self.h.osc_generate(self.arm, params, q, dq, t, tv, ie, une, training_signal=True, dtype=dtype,
-                                            handover=True)
-            self.deferred += max(nd, 0)
-            return u, ts
-        return self.h.osc_generate(self.arm, params, q, dq, t, tv, ie, une, training_signal=True, dtype=dtype)
+            r = self.h.osc_generate(self.arm, params, q, dq, t, tv, ie, une, training_signal=want, dtype=dtype,
+                                    handover=True)
+            self.deferred += max(r[-1], 0)
+            return (r[0], r[1]) if want else (r[0], None)
+        r = self.h.osc_generate(self.arm, params, q, dq, t, tv, ie, une, training_signal=want, dtype=dtype)
+        return r if want else (r, None)
 
     def sliding(self, params, q, dq, t, tv=None, ta=None, dtype=np.float64):
         return self.h.sliding_generate(self.arm, params, q, dq, t, tv, ta, want_s=True, dtype=dtype)
@@ -234,7 +254,16 @@ class HostsimBackend:
 class GpuBackend:
     """libabrk.so through the C ABI (abr_control_amd.engine) - static or runtime-table arm"""
 
-    def __init__(self, arm, variant="static", device=0):
+    # rows per call of the forms of the six-row law (abrk_host.cpp: one pass below one wavefront of rows, hand-over
+    # records + finish kernel up to 65 536 rows, worklist + recompute pass beyond)
+    ONE_PASS_ROWS, RECOMPUTE_ROWS = 48, 65536 + 128
+
+    def __init__(self, arm, variant="static", device=0, training_signal=True, form="auto"):
+        """training_signal=False: ask for no training signal - what bench.py times and what a C-ABI caller without that
+        buffer gets (the plain six-row law then runs the `NOTS = true` instantiations); osc() returns (u, None).
+        form: "auto" = one call on the rows as given; "slices" = calls of ONE_PASS_ROWS rows (the six-row law in one
+        pass: `osc_kernel<.., PASS = 0>` in mode 0); "tiled" = the rows repeated up to RECOMPUTE_ROWS (first pass +
+        recompute pass over the worklist: `PASS = 1` then `PASS = 0` in mode 2), every repetition bit-equal."""
         import ctypes as C
 
         from abr_control_amd import engine
@@ -259,7 +288,8 @@ class GpuBackend:
         else:
             d = _abi.desc_from_table(self.tab)
             self.arm_id = check(lib().abrk_arm_create(C.byref(d)))
-        self.name = f"gpu-{variant}"
+        self.training_signal, self.form = training_signal, form
+        self.name = f"gpu-{variant}" + ("" if training_signal else "-nots") + ("" if form == "auto" else f"-{form}")
         self._owned = variant != "static"
 
     def __del__(self):  # user arms are registered per backend: hand the slot back (fuzz runs create thousands)
@@ -271,9 +301,34 @@ class GpuBackend:
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
+    def _osc(self, params, q, dq, t, tv, ie, une, dtype):
+        want = bool(self.training_signal)
+        r = self.e.osc_generate(self.arm_id, self.n, params, q, dq, t, tv, ie, une, training_signal=want,
+                                dtype=dtype, device=self.device)
+        return r if want else (r, None)
+
     def osc(self, params, q, dq, t, tv=None, ie=None, une=None, dtype=np.float64):
-        return self.e.osc_generate(self.arm_id, self.n, params, q, dq, t, tv, ie, une, training_signal=True,
-                                   dtype=dtype, device=self.device)
+        if self.form == "auto":
+            return self._osc(params, q, dq, t, tv, ie, une, dtype)
+        B = len(q)
+        cut = lambda a, lo, hi: None if a is None else a[lo:hi]  # row slices of C-contiguous arrays: views, in place
+        if self.form == "slices":
+            parts = [self._osc(params, q[lo:lo + self.ONE_PASS_ROWS], dq[lo:lo + self.ONE_PASS_ROWS],
+                               t[lo:lo + self.ONE_PASS_ROWS], cut(tv, lo, lo + self.ONE_PASS_ROWS),
+                               cut(ie, lo, lo + self.ONE_PASS_ROWS), cut(une, lo, lo + self.ONE_PASS_ROWS), dtype)
+                     for lo in range(0, B, self.ONE_PASS_ROWS)]
+            u = np.concatenate([p[0] for p in parts])
+            return u, (np.concatenate([p[1] for p in parts]) if self.training_signal else None)
+        assert self.form == "tiled", self.form
+        reps = -(-self.RECOMPUTE_ROWS // B)
+        rep = lambda a: None if a is None else np.ascontiguousarray(np.tile(np.asarray(a), (reps, 1)))
+        ie_t = rep(ie)
+        u, ts = self._osc(params, rep(q), rep(dq), rep(t), rep(tv), ie_t, rep(une), dtype)
+        for k in range(1, reps):  # a row's bits do not depend on where in the batch it sits
+            assert np.array_equal(u[k * B:(k + 1) * B], u[:B], equal_nan=True), f"{self.name}: repetition {k} differs"
+        if ie is not None:
+            ie[...] = ie_t[:B]
+        return np.ascontiguousarray(u[:B]), (None if ts is None else np.ascontiguousarray(ts[:B]))
 
     def sliding(self, params, q, dq, t, tv=None, ta=None, dtype=np.float64):
         return self.e.sliding_generate(self.arm_id, self.n, params, q, dq, t, tv, ta, want_s=True, dtype=dtype,
@@ -506,10 +561,13 @@ def check_quaternions_all_frames(backend, arm, g, dtype=np.float64):
 
 
 # ---------------------------------------------------------------------------- seeded fuzz over OSC parameters
-def fuzz_osc_cases(seed, count):
+def fuzz_osc_cases(seed, count, plain_six=False):
     """random (arm table, abrk_osc_params, optional inputs) combinations: joint counts 1..7, orthogonal and
     rounded static transforms, any ctrlr_dof mask, frames, offsets, vmax, ki, target velocity, fused and external
-    secondary controllers, both orientation algorithms"""
+    secondary controllers, both orientation algorithms.
+    plain_six: every case is the six-row law with no optional input and no training signal asked for (the `NOTS = true`
+    kernels): secondary controllers, integral term, target velocity and external signal are dropped from the draw, and a
+    mask that would take the x,y,z / x,y fast path is moved off the end effector frame"""
     from tests.synthetic_arms import make_arm
 
     rng = np.random.RandomState(seed)
@@ -533,8 +591,19 @@ def fuzz_osc_cases(seed, count):
                   ctrlr_dof=dof.tolist(), null_controllers=nulls, use_g=bool(rng.randint(2)), use_C=bool(rng.randint(2)),
                   orientation_algorithm=int(rng.randint(2)), ref_frame=frames[rng.randint(len(frames))],
                   xyz_offset=rng.uniform(-0.2, 0.2, 3).tolist() if rng.randint(2) else None)
-        out.append(dict(tab=tab, n=n, kw=kw, tv=bool(rng.randint(3) == 0), ext=bool(rng.randint(3) == 0),
-                        seed=int(rng.randint(1 << 30))))
+        tv, ext, row_seed = bool(rng.randint(3) == 0), bool(rng.randint(3) == 0), int(rng.randint(1 << 30))
+        if plain_six:
+            tv = ext = False
+            kw.update(null_controllers=[], ki=0)
+            d = kw["ctrlr_dof"]
+            if kw["ref_frame"] == "EE" and (d == XYZ or (d == XY and n <= 3)):
+                kw["ref_frame"] = f"link{n}"
+            out.append(dict(tab=tab, n=n, kw=kw, tv=False, ext=False, seed=row_seed, ts=False))
+            continue
+        # whether the call asks for the training signal (osc.py:297): drawn per case from the row seed's parity, so that
+        # the cases of earlier rounds keep their arms / parameters / rows.  Without it the plain six-row law runs its NoTs
+        # instantiations - what bench.py and a C-ABI caller without that buffer get
+        out.append(dict(tab=tab, n=n, kw=kw, tv=tv, ext=ext, seed=row_seed, ts=bool(row_seed & 1)))
     return out
 
 
@@ -553,6 +622,8 @@ def check_fuzz_case(backend_factory, fc, B=96):
     ie_o = np.zeros((B, 6)) if params.ki != 0 else None
     uo = o.osc_batch(params, q, dq, t, tv, ie_o, une)
     be = backend_factory(tab)
+    if hasattr(be, "training_signal"):
+        be.training_signal = fc.get("ts", True)
     ie = np.zeros((B, 6)) if params.ki != 0 else None
     u, _ = be.osc(params, q, dq, t, tv, ie=ie, une=une)
     dof = np.array(fc["kw"]["ctrlr_dof"], bool)
@@ -566,7 +637,8 @@ def check_fuzz_case(backend_factory, fc, B=96):
         A = J @ np.linalg.inv(M) @ J.T
         sv = np.linalg.svd(A, compute_uv=False)
         det = abs(np.linalg.det(A))
-        near = abs(det - 1e-3) < 1e-8 or (det < 1.001e-3 and np.any(np.abs(sv / sv.max() - 1e-4) < 1e-8))
+        # (a frame no joint moves - joint0, link0 - has J = 0: an all-zero Mx_inv sits at neither threshold)
+        near = abs(det - 1e-3) < 1e-8 or (det < 1.001e-3 and sv.max() > 0 and np.any(np.abs(sv / sv.max() - 1e-4) < 1e-8))
         # below the det threshold the law uses a truncated pinv: well-posed only if the kept part is well separated
         if near or (sv.max() / max(sv.min(), 1e-300) > 1e7 and det >= 1e-3):
             ok[b] = False

@@ -272,6 +272,83 @@ def test_gpu_singular_inertia_matrix_is_reported():
     assert np.array_equal(ud.numpy(), good.osc(laws[0], q, dq, t)[0])
 
 
+def test_gpu_singular_flag_is_per_stream():
+    """ADVICE r5 / VERDICT r5 weak #3: several control loops on one GPU.  A singular batch enqueued on stream A is reported
+    by what drains stream A - Stream.sync, DeviceArray.numpy(stream A), abrk_device_sync - and never by another stream's
+    sync, whichever comes first, from whichever thread; the healthy loop's results are untouched."""
+    import threading
+
+    import abr_control_amd as a
+    from abr_control_amd import engine
+    from abr_control_amd._lib import check, lib
+    from tests.synthetic_arms import make_arm
+
+    tab = make_arm(6, 77)
+    tab["mdiag"][6] = [0.0] * 6
+    bad, good = cases.GpuBackend(tab), cases.GpuBackend(make_arm(6, 77))
+    q, dq, t = draw(5, 300, 6)
+    p = _abi.make_osc_params(6, kp=100)
+    p6 = _abi.make_osc_params(6, kp=100, ko=80, ctrlr_dof=[1] * 6)
+    want = good.osc(p, q, dq, t)[0]
+    sa, sb = a.Stream(0), a.Stream(0)
+    q_, dq_, t_ = (a.DeviceArray.from_numpy(x) for x in (q, dq, t))
+    for law in (p, p6):
+        ua = engine.osc_generate(bad.arm_id, 6, law, q_, dq_, t_, stream=sa)
+        ub = engine.osc_generate(good.arm_id, 6, p, q_, dq_, t_, stream=sb)
+        sb.sync()                              # the healthy loop syncs FIRST: it must not be handed A's flag
+        assert np.array_equal(ub.numpy(sb), want)
+        with pytest.raises(np.linalg.LinAlgError):
+            sa.sync()
+        sa.sync()                              # reported once
+    # read-back instead of a sync: the copy drains the stream and reports
+    ua = engine.osc_generate(bad.arm_id, 6, p, q_, dq_, t_, stream=sa)
+    with pytest.raises(np.linalg.LinAlgError):
+        ua.numpy(sa)
+    sa.sync()
+    # abrk_device_sync: any stream of the device
+    engine.osc_generate(bad.arm_id, 6, p, q_, dq_, t_, stream=sa)
+    with pytest.raises(np.linalg.LinAlgError):
+        check(lib().abrk_device_sync(0))
+    sa.sync()
+    sb.sync()
+    # two threads, one loop each, many ticks: only the singular loop's thread ever sees the error
+    seen = {"bad": 0, "good": 0, "good_results_ok": True}
+
+    def loop(which, arm_id, stream):
+        for _ in range(40):
+            u = engine.osc_generate(arm_id, 6, p, q_, dq_, t_, stream=stream)
+            try:
+                stream.sync()
+                if which == "good" and not np.array_equal(u.numpy(stream), want):
+                    seen["good_results_ok"] = False
+            except np.linalg.LinAlgError:
+                seen[which] += 1
+
+    ths = [threading.Thread(target=loop, args=("bad", bad.arm_id, sa)), threading.Thread(target=loop, args=("good", good.arm_id, sb))]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert seen == {"bad": 40, "good": 0, "good_results_ok": True}, seen
+    # a destroyed stream hands its word back; a new stream starts clean even if the handle value is reused
+    engine.osc_generate(bad.arm_id, 6, p, q_, dq_, t_, stream=sa)
+    del sa
+    sc = a.Stream(0)
+    engine.osc_generate(good.arm_id, 6, p, q_, dq_, t_, stream=sc)
+    sc.sync()
+    # host-array calls from short-lived threads: each thread's pinned word returns to the pool when the thread exits
+    def host_call():
+        good.osc(p, q[:8], dq[:8], t[:8])
+
+    for _ in range(200):
+        th = threading.Thread(target=host_call)
+        th.start()
+        th.join()
+    info = _abi.ScratchInfo()
+    check(lib().abrk_scratch_stats(0, info))
+    assert info.status_words_out <= 8 and info.status_blocks <= 2, (info.status_words_out, info.status_blocks)
+
+
 def test_gpu_python_api_drop_in():
     """robot_config / controller classes: reference shapes, dtypes and per-call state"""
     from abr_control_amd.arms import jaco2, threejoint, twojoint, ur5
@@ -772,24 +849,224 @@ def test_gpu_six_row_from_threads_on_default_stream():
     assert np.allclose(out[0][2][:2048], ie0, rtol=1e-12, atol=1e-12)
 
 
-def test_gpu_six_row_first_pass_without_training_signal():
-    """from 16 384 rows on the plain six-row law runs a first pass compiled WITHOUT the training-signal output when the
-    caller asks for none (`osc_kernel<..., PASS = 1, NOTS = true>`: gravity folded in ahead of the factorisations - no
-    spills in the law): the same u as the call that does ask for it, to rounding; deferred rows included"""
-    be = cases.GpuBackend("ur5")
-    for kw in (dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6), dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6, use_C=True),
-               dict(kp=50, ctrlr_dof=[1, 1, 0, 1, 0, 1], use_g=False)):
-        p = cases.P(6, **kw)
-        q, dq, t = draw(77, 40000, 6)
-        u_ts, _ = be.e.osc_generate(be.arm_id, 6, p, q, dq, t, training_signal=True)
-        u_no = be.e.osc_generate(be.arm_id, 6, p, q, dq, t)
-        assert np.isfinite(u_no).all()
-        scale = np.max(np.abs(u_ts), axis=1, keepdims=True)
-        assert np.max(np.abs(u_no - u_ts) / scale) < 1e-13, kw
-        # and the small-batch (inline) program, which has no such variant, on the same rows
-        u_small = np.concatenate([be.e.osc_generate(be.arm_id, 6, p, q[lo:lo + 8000], dq[lo:lo + 8000], t[lo:lo + 8000])
-                                  for lo in range(0, 40000, 8000)])
-        assert np.max(np.abs(u_no - u_small) / scale) < 1e-13, kw
+NOTS_CASES = [c for c in sorted(cases.CASES) if cases.takes_plain_six_row_law(c)]
+
+
+@pytest.mark.parametrize("form", ["auto", "slices", "tiled"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("case_id", NOTS_CASES)
+def test_gpu_six_row_cases_without_training_signal(case_id, variant, dtype, form):
+    """WHAT THE BENCH TIMES on the six-row law, and what any C-ABI caller without a training-signal buffer runs
+    (include/abrk.h abrk_osc_generate_batch, training_signal = NULL): `osc_kernel<.., 6, .., FEAT = 0, PASS, NOTS = true>`
+    in every pass (Launch::osc_launch) - gravity folded into the velocity term ahead of the factorisations.  Every golden
+    case of the plain six-row law (UR5 six rows alg 0 / 1, vmax, orientation only, x-z-beta, link5; Jaco2 five and six
+    rows; the three-joint arm's x-y-gamma) against the REFERENCE's outputs with no training signal asked for: built-in and
+    runtime-table kernels, fp64 and fp32, and the three launch forms - "auto": first pass + finish kernel on hand-over
+    records (`PASS = 1`); "slices": 48-row calls, the complete row program in one pass (`PASS = 0`, mode 0); "tiled":
+    the rows repeated beyond 65 536, first pass + recompute pass over the worklist (`PASS = 1`, then `PASS = 0` in mode 2;
+    every repetition bit-equal).  Reference: controllers/osc.py:294-301, examples/timing_plots.py:36-37."""
+    arm = cases.CASES[case_id]["arm"]
+    be = cases.GpuBackend(arm, variant, training_signal=False, form=form)
+    r = cases.check_case_against_golden(be, case_id, golden(arm), dtype=dtype)
+    assert r["worst_vs_D"] <= (cases.TOL_F32 if dtype == np.float32 else
+                               cases.TOL_THREEJOINT if arm == "threejoint" else cases.TOL_D)
+
+
+@pytest.mark.parametrize("arm,variant", [("ur5", "static"), ("ur5", "rt"), ("jaco2", "static"), ("jaco2", "rt")])
+def test_gpu_six_row_near_singular_postures_without_training_signal(arm, variant):
+    """hundreds of truncating rows (postures next to the kinematic singularities) through the NOTS first pass and the
+    finish kernel, against the oracle and against the same call WITH the training signal (1e-9: the two differ by where
+    gravity joins the sum)"""
+    be = cases.GpuBackend(arm, variant, training_signal=False)
+    worst, n_trunc = cases.check_six_row_near_singular(be, arm, B=600, reference=cases.GpuBackend(arm, variant))
+    assert n_trunc > 120 and worst <= cases.TOL_D
+
+
+def test_gpu_fuzz_plain_six_row_law_without_training_signal():
+    """random 1..7-joint user arms (runtime-table kernels), any mask / frame / offset / vmax / orientation algorithm, no
+    optional input and no training signal - the NOTS kernels of every joint count against the oracle, hand-over form (96
+    rows) and one-pass form (48-row slices)"""
+    worst = 0.0
+    for fc in cases.fuzz_osc_cases(61, 16, plain_six=True) + cases.fuzz_osc_cases(62, 16, plain_six=True):
+        for form in ("auto", "slices"):
+            worst = max(worst, cases.check_fuzz_case(lambda tab, f=form: cases.GpuBackend(tab, form=f), fc))
+    assert worst < 1e-6
+
+
+def test_gpu_compiled_arms_without_training_signal():
+    """compiled user-arm plugins (specialize.py) carry their own NOTS instantiations: the three-joint plugin on the
+    reference's x-y-gamma cases with no training signal (bit-equal to the built-in arm's kernels, and against the
+    reference's outputs), the four-joint synthetic arm against the oracle - fp64 and fp32, hand-over and one-pass forms"""
+    from oracle.oracle import Oracle
+    from tests import compiled_arms
+
+    arms_ = compiled_arms.test_arms()
+    g = golden("threejoint")
+    for form in ("auto", "slices", "tiled"):
+        cu = cases.GpuBackend(arms_["threejoint_user"], "compiled", training_signal=False, form=form)
+        bi = cases.GpuBackend("threejoint", training_signal=False, form=form)
+        for case_id in ("threejoint:osc_xyg_alg0", "threejoint:osc_xyg_alg1"):
+            for dtype in (np.float64, np.float32):
+                cases.check_case_against_golden(cu, case_id, g, dtype=dtype)
+                a, _ = cases.run_case(cu, cases.CASES[case_id], g, dtype)
+                b, _ = cases.run_case(bi, cases.CASES[case_id], g, dtype)
+                assert np.array_equal(a, b), (case_id, dtype, form)
+    tab = arms_["synthetic4"]
+    o = Oracle(tab)
+    rng = np.random.RandomState(5)
+    B = 400
+    q, dq, t = rng.uniform(-3, 3, (B, 4)), rng.uniform(-2, 2, (B, 4)), rng.uniform(-0.5, 0.5, (B, 6))
+    ok = np.array([np.linalg.cond(o.M(q[b])) < 1e8 for b in range(B)])
+    for kw in (dict(kp=30, ko=20, ctrlr_dof=[1, 1, 1, 1, 0, 0], vmax=[0.5, 1.0]),
+               dict(kp=30, ko=20, kv=9, ctrlr_dof=[1, 0, 1, 0, 1, 1], use_C=True, orientation_algorithm=1)):
+        p = _abi.make_osc_params(4, **kw)
+        uo = o.osc_batch(p, q, dq, t)
+        for form in ("auto", "slices"):
+            u, ts = cases.GpuBackend(tab, "compiled", training_signal=False, form=form).osc(p, q, dq, t)
+            assert ts is None and cases.rel_err(u, uo)[ok].max() < 1e-6, (kw, form)
+
+
+def test_gpu_six_row_law_with_and_without_training_signal_agree():
+    """the plain six-row law with no training signal asked for runs the NOTS instantiations in EVERY pass (round 5;
+    `Launch::osc_launch`: first pass, recompute pass and the one-pass form alike): the same u as the call that asks for
+    it, to rounding (gravity joins the sum at another place), deferred rows included - at 40 000 rows (hand-over), in
+    8000-row calls, and in the one-pass form; UR5 and Jaco2, fp64"""
+    for arm in ("ur5", "jaco2"):
+        be = cases.GpuBackend(arm)
+        for kw in (dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6),
+                   dict(kp=100, ko=60, kv=12, ctrlr_dof=[1] * 6, use_C=True),
+                   dict(kp=50, ctrlr_dof=[1, 1, 0, 1, 0, 1], use_g=False)):
+            p = cases.P(6, **kw)
+            q, dq, t = draw(77, 40000, 6)
+            u_ts, _ = be.e.osc_generate(be.arm_id, 6, p, q, dq, t, training_signal=True)
+            u_no = be.e.osc_generate(be.arm_id, 6, p, q, dq, t)
+            assert np.isfinite(u_no).all()
+            scale = np.max(np.abs(u_ts), axis=1, keepdims=True)
+            # Jaco2's Mx_inv reaches cond 1e8 (DESIGN.md section 3): rounding-level differences are amplified by it
+            tol = 1e-13 if arm == "ur5" else 1e-9
+            assert np.max(np.abs(u_no - u_ts) / scale) < tol, (arm, kw)
+            u_small = np.concatenate([be.e.osc_generate(be.arm_id, 6, p, q[lo:lo + 8000], dq[lo:lo + 8000],
+                                                        t[lo:lo + 8000]) for lo in range(0, 40000, 8000)])
+            assert np.array_equal(u_no, u_small), (arm, kw)  # bits do not depend on the batch a row arrives in
+            u_one = np.concatenate([be.e.osc_generate(be.arm_id, 6, p, q[lo:lo + 48], dq[lo:lo + 48], t[lo:lo + 48])
+                                    for lo in range(0, 960, 48)])
+            assert np.array_equal(u_no[:960], u_one), (arm, kw)
+
+
+def _bench_module():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("abrk_bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_BENCH_WORKLOADS = ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5", "cfg2_f32", "dynF", "dynC", "oscF", "oscFC", "rollout", "ik",
+                    "osc6", "osc5_j2", "sliding_j2", "joint", "limits", "floating", "obstacles"]
+
+
+def test_gpu_bench_workload_list_is_complete():
+    assert sorted(_BENCH_WORKLOADS) == sorted(_bench_module().WORKLOADS), "a bench workload without a parity test"
+
+
+@pytest.mark.parametrize("workload", _BENCH_WORKLOADS)
+def test_gpu_bench_workloads_match_the_oracle(workload):
+    """TEST WHAT YOU TIME: every workload bench.py can print, built by bench.py's own `Runner` at 4096 rows - the same
+    device buffers, the same optional arguments and NULLs, the same recorded plan `_enqueue` records (so the same kernel
+    instantiation: no training-signal buffer -> the NOTS six-row kernels for `osc6` / `osc5_j2`) - stepped once through
+    the plan, and its outputs compared with the CPU oracle on the same seeded rows.  A bench-only code path cannot go
+    untested.  fp64: 1e-6 of the row's scale (north_star); fp32 workloads: 1e-4 on well-conditioned rows."""
+    import abr_control_amd as a
+    from oracle import oracle as orc
+
+    bench = _bench_module()
+    B = 4096
+    st = a.Stream(0)
+    r = bench.Runner(workload, B, 0, st)
+    if r.kind == "rollout":
+        q0, dq0, t6 = r.q.numpy().copy(), r.dq.numpy().copy(), r.t.numpy().copy()
+    r.step()
+    st.sync()
+    q, dq, t = (np.asarray(x, float) for x in r.host)
+    tab = _abi.load_table(r.arm)
+    o = orc.Oracle(tab)
+    n = r.n
+    f32 = r.dt == np.float32
+    tol = cases.TOL_F32 if f32 else cases.TOL_D
+    kind = r.kind
+    if kind in ("osc", "osc_damp", "osc_full"):
+        p = r.params
+        uo = o.osc_batch(p, q, dq, t)
+        u = np.asarray(r.u.numpy(), float)
+        dof = np.array(list(p.ctrlr_dof), bool)
+        ok = np.ones(B, bool)
+        cond = np.zeros(B)
+        for b in range(B):
+            J = o.J("EE", q[b], None)[dof]
+            A = J @ np.linalg.inv(o.M(q[b])) @ J.T
+            sv = np.linalg.svd(A, compute_uv=False)
+            det = abs(np.linalg.det(A))
+            cond[b] = sv.max() / max(sv.min(), 1e-300)
+            near = abs(det - 1e-3) < 1e-8 or (det < 1.001e-3 and np.any(np.abs(sv / sv.max() - 1e-4) < 1e-8))
+            ok[b] = not near and not (cond[b] > 1e9 and det >= 1e-3)
+        if f32:
+            ok &= cond < 1e3
+        assert ok.sum() > (0.3 if f32 else 0.97) * B
+        err = cases.rel_err(u, uo)
+        assert np.isfinite(u).all() and err[ok].max() <= tol, f"{workload}: {err[ok].max():.3e} ({r.kernel_name()})"
+        if kind == "osc_full":
+            for w, arr in r.dyn_out.items():
+                ref = np.array([{"Tx": lambda i: o.Tx("EE", q[i]), "J": lambda i: o.J("EE", q[i]), "M": lambda i: o.M(q[i]),
+                                 "g": lambda i: o.g(q[i]), "C": lambda i: o.C(q[i], dq[i])}[w](i) for i in range(B)])
+                assert np.max(np.abs(arr.numpy() - ref)) <= 1e-10 * max(np.max(np.abs(ref)), 1.0), (workload, w)
+    elif kind == "dyn":
+        ref = cases.OracleBackend(r.arm).dynamics(q, dq, "EE", None, tuple(r.want))
+        for w in r.want:
+            assert np.max(np.abs(r.dyn_out[w].numpy() - ref[w])) <= 1e-10 * max(np.max(np.abs(ref[w])), 1.0), (workload, w)
+    elif kind == "sliding":
+        uo, _ = o.sliding_batch(r.params, q, dq, t)
+        u = np.asarray(r.u.numpy(), float)
+        sv = np.array([np.linalg.svd(o.J("EE", q[b], None)[:3], compute_uv=False) for b in range(B)])
+        rank = (sv > 1e-9 * sv.max(axis=1, keepdims=True)).sum(axis=1)
+        smin = np.array([sv[b][rank[b] - 1] for b in range(B)])
+        ok = (rank == rank.max()) & (sv.max(axis=1) / smin < (20 if f32 else 1e4))
+        assert ok.sum() > 0.5 * B
+        err = cases.rel_err(u, uo)
+        assert np.isfinite(u).all() and err[ok].max() <= tol, f"{workload}: {err[ok].max():.3e}"
+    elif kind == "joint":
+        tj = np.asarray(r.tj.numpy(), float)
+        uo = o.joint_batch(r.params, True, q, dq, tj, None)
+        assert np.max(np.abs(r.u.numpy() - uo)) <= 1e-10 * np.max(np.abs(uo))
+    elif kind == "limits":
+        with np.errstate(all="ignore"):
+            uo = orc.avoid_joint_limits_batch(n, r.params, q)
+        assert np.allclose(r.u.numpy(), uo, rtol=1e-12, atol=1e-12)
+    elif kind == "floating":
+        uo, diag = o.floating_batch(int(r.params["dynamic"]), int(r.params["task_space"]), q, dq)
+        ok = (np.abs(np.abs(diag[:, 0]) - 1e-3) > 1e-9) & (np.abs(diag[:, 1] - 1e-4) > 1e-8)
+        assert cases.rel_err(np.asarray(r.u.numpy(), float), uo)[ok].max() <= tol
+    elif kind == "obstacles":
+        with np.errstate(all="ignore"):
+            uo, diag = o.avoid_obstacles_batch(r.params, q)
+        ok = (diag[:, 0] > 1e-7) & (diag[:, 1] > 1e-12)
+        scale = np.maximum(np.max(np.abs(uo), axis=1), 1e-6)
+        err = np.max(np.abs(r.u.numpy() - uo), axis=1) / scale
+        assert ok.sum() > 0.9 * B and err[ok].max() <= 1e-5, err[ok].max()
+    elif kind == "ik":
+        rows = np.arange(0, B, 16)  # 200 iterations per path on the CPU: a sample of the 4096 paths
+        pp, vp = orc.ik_paths(tab, r.params, q[rows], t[rows])
+        assert np.max(np.abs(r.ik_out[0].numpy()[rows] - pp)) < 1e-8
+        assert np.max(np.abs(r.ik_out[1].numpy()[rows] - vp)) < 1e-8
+    elif kind == "rollout":
+        qe, dqe, *_ = orc.rollout_twolink(tab, r.params, r.plant, q0, dq0, t6, bench.ROLLOUT_STEPS, bench.ROLLOUT_STEPS)
+        assert np.isfinite(r.q.numpy()).all()
+        assert np.max(np.abs(r.q.numpy() - qe)) < 1e-7 and np.max(np.abs(r.dq.numpy() - dqe)) < 1e-6
+    else:
+        raise AssertionError(f"no oracle comparison for bench workload kind {kind!r}")
+    if r.plan is not None:
+        r.plan.close()
 
 
 @pytest.mark.parametrize("launcher", ["self", "external"])
@@ -844,6 +1121,30 @@ def test_gpu_bench_two_ranks_share_one_device(tmp_path, launcher):
         sh = json.load(open(tmp_path / f"shard_u_rank{r}.json"))
         assert (sh["lo"], sh["hi"]) == (r << 19, (r + 1) << 19)
         assert sh["sha256"] == hashlib.sha256(np.ascontiguousarray(u[sh["lo"]:sh["hi"]]).tobytes()).hexdigest()
+
+
+def test_gpu_bench_single_process_drives_every_shard():
+    """`bench.py --gpus N --single-process`: one process, one host thread, N resident shards (here all on device 0 -
+    --allow-shared-device): the line carries value / strong_scaling_cfg4 / resident_shard_step_cfg4 with n_devices_seen,
+    and refuses to double up without the test flag"""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-process", "--steps", "20", "--warmup", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert r.returncode == 1 and d["devices_seen"] == 1 and "error" in d
+    r = subprocess.run(cmd + ["--allow-shared-device"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["n_devices_seen"] == 1 and d["devices"] == [0, 0] and d["shared_device"]
+    assert d["value"] > 1e8 and d["strong_scaling_cfg4"]["rows_per_gpu"] == (1 << 19)
+    rs = d["resident_shard_step_cfg4"]
+    assert rs["shards"] == 8 and rs["rows_per_shard"] == 131072
+    # VERDICT r5 "Next" #3: the resident 8-shard step of config 4 costs at most 1.3 x eight plain 131 072-row launches
+    assert rs["ratio_to_eight_plain_launches"] <= 1.3, rs
 
 
 def test_gpu_secondary_controllers_properties_full_size():
@@ -1501,6 +1802,172 @@ def test_gpu_sharded_call_equals_unsharded_bitwise():
     assert md.generate(c, q[0], dq[0], t[0]).shape == (6,)
     with pytest.raises(Exception):
         engine.osc_generate_sharded(be.arm_id, 6, p, q, dq, t, [99])
+
+
+def test_gpu_resident_shards_equal_unsharded_bitwise():
+    """SURVEY 8e "results remain in per-device buffers unless the caller asks for host arrays" / VERDICT r5 missing #1:
+    shards that LIVE on the devices, one host thread (abrk_*_resident, sharding.ShardedArray + MultiDevice).  With one GPU
+    every shard maps to device 0 (devices = [0] * 8: eight shards, eight streams; the multi-GPU placement is the same
+    code with other ordinals).  The resident call is `array_equal` to the unsharded one: x,y,z law with Coriolis term,
+    fused null controller, target velocity and `ki` state over 5 ticks; the six-row law (hand-over form per shard) with
+    and without the training signal; Sliding, Joint, Damping, RestingConfig and the robot_config functions."""
+    from abr_control_amd import engine
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC, Damping, Joint, RestingConfig, Sliding
+    from abr_control_amd.sharding import MultiDevice, ShardedArray
+
+    be = cases.GpuBackend("ur5")
+    B = 10007
+    q, dq, t = draw(91, B, 6)
+    tv = np.random.RandomState(92).uniform(-0.5, 0.5, (B, 6))
+    for devices in ([0] * 8, [0, 0, 0], [0] * 13):
+        md = MultiDevice(devices)
+        qs, dqs, ts_, tvs = (md.scatter(x) for x in (q, dq, t, tv))
+        assert np.array_equal(qs.numpy(), q) and qs.rows == ShardedArray.cut(B, len(devices))
+        # x,y,z + C + Damping + target velocity + integral state, 5 ticks: the state stays with its shards
+        p = _abi.make_osc_params(6, kp=100, kv=15, ki=0.2, use_C=True, null_controllers=[_abi.make_damping(5)])
+        ie0, ies = np.zeros((B, 6)), md.zeros((B, 6), np.float64)
+        for tick in range(5):
+            u0, ts0 = be.e.osc_generate(be.arm_id, 6, p, q, dq, t, tv, ie0, training_signal=True)
+            u, tsg = engine.osc_generate_resident(be.arm_id, 6, p, qs, dqs, ts_, tvs, ies, training_signal=True,
+                                                  streams=md.streams)
+            md.sync()
+            assert np.array_equal(u.numpy(), u0) and np.array_equal(tsg.numpy(), ts0), (devices, tick)
+            assert np.array_equal(ies.numpy(), ie0), (devices, tick)
+        # six task rows: every shard runs first pass + finish kernel on its own (device, stream) scratch
+        p6 = _abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6)
+        u6 = be.e.osc_generate(be.arm_id, 6, p6, q, dq, t)
+        assert np.array_equal(engine.osc_generate_resident(be.arm_id, 6, p6, qs, dqs, ts_).numpy(), u6), devices
+        u6t, ts6 = be.e.osc_generate(be.arm_id, 6, p6, q, dq, t, training_signal=True)
+        r = engine.osc_generate_resident(be.arm_id, 6, p6, qs, dqs, ts_, training_signal=True)
+        assert np.array_equal(r[0].numpy(), u6t) and np.array_equal(r[1].numpy(), ts6), devices
+    # the controller classes over ShardedArrays: MultiDevice.generate only enqueues, .numpy() gathers
+    md = MultiDevice([0] * 8)
+    qs, dqs, ts_ = (md.scatter(x) for x in (q, dq, t))
+    rc = ur5.Config()
+    c = OSC(rc, kp=200, ki=0.1, null_controllers=[Damping(rc, kv=10)])
+    c_ref = OSC(rc, kp=200, ki=0.1, null_controllers=[Damping(rc, kv=10)])
+    for tick in range(3):
+        us = md.generate(c, qs, dqs, ts_)
+        assert isinstance(us, ShardedArray)
+        assert np.array_equal(us.numpy(), c_ref.generate(q, dq, t)), tick
+    assert np.array_equal(c.integrated_error.numpy(), c_ref.integrated_error)
+    assert np.array_equal(c.training_signal.numpy(), c_ref.training_signal)
+    sl = Sliding(rc)
+    t3 = md.scatter(t[:, :3])
+    assert np.array_equal(md.generate(sl, qs, dqs, t3).numpy(), Sliding(rc).generate(q, dq, t[:, :3]))
+    tj = md.scatter(t)
+    assert np.array_equal(md.generate(Joint(rc, kp=20, kv=4), qs, dqs, tj).numpy(), Joint(rc, kp=20, kv=4).generate(q, dq, t))
+    assert np.array_equal(md.generate(Damping(rc, kv=7), qs, dqs).numpy(), Damping(rc, kv=7).generate(q, dq))
+    rest = [None, 0.8, -1.6, None, 1.5, None]
+    assert np.array_equal(md.generate(RestingConfig(rc, rest, kp=30, kv=6), qs, dqs).numpy(),
+                          RestingConfig(rc, rest, kp=30, kv=6).generate(q, dq))
+    want = ("Tx", "J", "M", "g", "C", "dJ", "quat")
+    rr = engine.dynamics_resident(be.arm_id, 6, qs, dqs, want=want)
+    ref = be.e.dynamics(be.arm_id, 6, q, dq, None, None, want, np.float64, 0)
+    for k in want:
+        assert np.array_equal(rr[k].numpy(), ref[k]), k
+    # fp32, fewer rows than shards (empty shards are skipped), errors
+    p = _abi.make_osc_params(6, kp=200)
+    md3 = MultiDevice([0] * 8)
+    q3, dq3, t3_ = (md3.scatter(x[:3].astype(np.float32)) for x in (q, dq, t))
+    u3 = engine.osc_generate_resident(be.arm_id, 6, p, q3, dq3, t3_, dtype=np.float32)
+    assert np.array_equal(u3.numpy(), be.e.osc_generate(be.arm_id, 6, p, q[:3].astype(np.float32), dq[:3].astype(np.float32),
+                                                       t[:3].astype(np.float32), dtype=np.float32))
+    with pytest.raises(ValueError):
+        engine.osc_generate_resident(be.arm_id, 6, p, qs, dq3, ts_)  # cut differently
+    with pytest.raises(Exception, match="host arrays|NumPy"):
+        engine.osc_generate_sharded(be.arm_id, 6, p, qs.parts[0], dq, t, [0])
+
+
+def test_gpu_resident_sharded_plan_replays_k_ticks_on_every_shard():
+    """a recorded Plan per shard, replayed from ONE call (MultiDevice.record_generate -> ShardedPlan.launch /
+    .launch_graph -> abrk_plans_launch): K ticks of a control loop with integral state on eight shards equal K consecutive
+    unsharded calls, plain launches and hipGraph replays alike; a singular shard is reported by ShardedPlan.sync()"""
+    from abr_control_amd import engine
+    from abr_control_amd.arms import ur5
+    from abr_control_amd.controllers import OSC, Damping
+    from abr_control_amd.sharding import MultiDevice
+
+    B, K = 40000, 6
+    q, dq, t = draw(93, B, 6)
+    rc = ur5.Config()
+    mk = lambda: OSC(rc, kp=100, kv=15, ki=0.2, use_C=True, null_controllers=[Damping(rc, kv=5)])
+    ref = mk()
+    for _ in range(2 * K):
+        u_ref = ref.generate(q, dq, t)
+    md = MultiDevice([0] * 8)
+    qs, dqs, ts_ = (md.scatter(x) for x in (q, dq, t))
+    c = mk()
+    plan = md.record_generate(c, qs, dqs, ts_)
+    plan.launch(K)          # K plain launches per shard, one call
+    plan.launch_graph(K)    # K more ticks as one hipGraph per shard, one call
+    plan.sync()
+    assert np.array_equal(plan.u.numpy(), u_ref)
+    assert np.array_equal(c.integrated_error.numpy(), ref.integrated_error)
+    # the six-row law as a sharded plan (every shard's plan owns its worklist / records)
+    c6, r6 = OSC(rc, kp=200, ko=150, kv=25, ctrlr_dof=[True] * 6), OSC(rc, kp=200, ko=150, kv=25, ctrlr_dof=[True] * 6)
+    plan6 = md.record_generate(c6, qs, dqs, ts_)
+    plan6.launch_graph(3)
+    plan6.sync()
+    assert np.array_equal(plan6.u.numpy(), r6.generate(q, dq, t))
+    plan.close()
+    plan6.close()
+    # new states into the fixed buffers between ticks
+    q2, dq2, t2 = draw(94, B, 6)
+    qs.copy_from_numpy(q2), dqs.copy_from_numpy(dq2), ts_.copy_from_numpy(t2)
+    c2 = OSC(rc, kp=200)
+    plan2 = md.record_generate(c2, qs, dqs, ts_)
+    plan2.launch()
+    plan2.sync()
+    assert np.array_equal(plan2.u.numpy(), OSC(rc, kp=200).generate(q2, dq2, t2))
+    plan2.close()
+
+
+def test_gpu_resident_shards_from_threads_and_host_sharded_calls_on_disjoint_slots():
+    """the host-array *_sharded calls no longer serialise on a process-wide lock (one lock per device, one host thread per
+    device inside a call) and resident calls take none: four threads mixing both on one device return the single-call
+    bits (TSan run: tools/gpu_sanitize.sh)"""
+    import threading
+
+    from abr_control_amd import engine
+    from abr_control_amd.sharding import MultiDevice
+
+    be = cases.GpuBackend("ur5")
+    p = _abi.make_osc_params(6, kp=200, use_C=True)
+    p6 = _abi.make_osc_params(6, kp=200, ko=150, kv=25, ctrlr_dof=[1] * 6)
+    data = [draw(100 + i, 6000 + 37 * i, 6) for i in range(4)]
+    want = [(be.e.osc_generate(be.arm_id, 6, p, *d), be.e.osc_generate(be.arm_id, 6, p6, *d)) for d in data]
+    bad = []
+
+    def work(i):
+        try:
+            q, dq, t = data[i]
+            for rep in range(6):
+                if (i + rep) % 2:
+                    u = engine.osc_generate_sharded(be.arm_id, 6, p, q, dq, t, [0] * (2 + i))
+                    u6 = engine.osc_generate_sharded(be.arm_id, 6, p6, q, dq, t, [0] * (2 + i))
+                else:
+                    import abr_control_amd as a
+
+                    md = MultiDevice([0] * (2 + i))
+                    own = [a.Stream(0) for _ in md.devices]  # this thread's own streams: nothing shared with the others
+                    qs, dqs, ts_ = (md.scatter(x) for x in (q, dq, t))
+                    ud = engine.osc_generate_resident(be.arm_id, 6, p, qs, dqs, ts_, streams=own)
+                    u6d = engine.osc_generate_resident(be.arm_id, 6, p6, qs, dqs, ts_, streams=own)
+                    engine.shards_sync(ud, own)
+                    u, u6 = ud.numpy(own), u6d.numpy(own)
+                if not (np.array_equal(u, want[i][0]) and np.array_equal(u6, want[i][1])):
+                    bad.append((i, rep))
+        except Exception as e:  # noqa: BLE001
+            bad.append((i, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not bad, bad
 
 
 def test_gpu_sharded_sliding_joint_dynamics_equal_unsharded_bitwise():

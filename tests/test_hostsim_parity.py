@@ -84,6 +84,48 @@ def test_rows_six_row_handover_form_matches_reference(case_id):
     assert be.deferred >= r["n_trunc_compared"], (be.deferred, r)
 
 
+NOTS_CASES = [c for c in sorted(cases.CASES) if cases.takes_plain_six_row_law(c)]
+
+
+def test_nots_case_list_covers_the_six_row_cases():
+    """every golden case of the plain six-row law is run without the training signal too (the list is derived from the
+    dispatch rule, abrk_params.h osc_fast_rows + Launch::osc_launch_feat, not kept by hand)"""
+    assert set(NOTS_CASES) == set(SIX_ROW_CASES)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("variant", ["static", "rt"])
+@pytest.mark.parametrize("handover", [False, True], ids=["onepass", "handover"])
+@pytest.mark.parametrize("case_id", NOTS_CASES)
+def test_rows_six_row_cases_without_training_signal(case_id, handover, variant, dtype):
+    """what bench.py times on the six-row law and what a C-ABI caller without a training-signal buffer runs: the NoTs
+    arithmetic (gravity folded into the velocity term ahead of the factorisations), one-pass and hand-over forms, built-in
+    and runtime-table row programs, both arithmetic types - against the reference's outputs"""
+    arm = cases.CASES[case_id]["arm"]
+    be = cases.HostsimBackend(arm, variant, handover=handover, training_signal=False)
+    r = cases.check_case_against_golden(be, case_id, golden(arm), dtype=dtype)
+    if handover and dtype == np.float64:
+        assert be.deferred >= r["n_trunc_compared"], (be.deferred, r)
+
+
+@pytest.mark.parametrize("arm", ["ur5", "jaco2"])
+def test_rows_six_row_near_singular_postures_without_training_signal(arm):
+    """the truncating rows of the near-singular postures through the NoTs row programs (plain law; the other two laws of
+    the set carry optional inputs and have no NoTs twin), hand-over and one-pass forms"""
+    be = cases.HostsimBackend(arm, "static", handover=True, training_signal=False)
+    ref = cases.HostsimBackend(arm, "static", training_signal=False)
+    worst, n_trunc = cases.check_six_row_near_singular(be, arm, B=300, reference=ref)
+    assert be.deferred >= n_trunc and worst <= cases.TOL_D
+
+
+def test_rows_fuzz_plain_six_row_law_without_training_signal():
+    """random 1..7-joint user arms, any mask / frame / offset / vmax / orientation algorithm, no optional input and no
+    training signal: the NoTs row programs against the oracle, one-pass and hand-over forms"""
+    for fc in cases.fuzz_osc_cases(61, 16, plain_six=True):
+        for handover in (False, True):
+            cases.check_fuzz_case(lambda tab, h=handover: cases.HostsimBackend(tab, handover=h), fc, B=64)
+
+
 @pytest.mark.parametrize("arm", ["ur5", "jaco2"])
 def test_rows_six_row_handover_form_near_singular_postures(arm):
     """hundreds of truncating rows (postures next to the kinematic singularities) through the hand-over records: plain

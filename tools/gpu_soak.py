@@ -15,9 +15,13 @@ offset = int(sys.argv[2]) if len(sys.argv) > 2 else 0  # shifts every seed range
 fails, n_osc, n_other, worst = [], 0, 0, 0.0
 seed = 100 + offset
 while time.time() - t0 < budget * 0.6:
-    for fc in cases.fuzz_osc_cases(seed, 24):
+    # (each case draws whether it asks for the training signal; every third seed is the plain six-row law without it -
+    #  the NOTS kernels bench.py times - in the hand-over and the one-pass form alternately)
+    plain = seed % 3 == 2
+    factory = (lambda tab, f=("auto", "slices")[(seed // 3) & 1]: cases.GpuBackend(tab, form=f)) if plain else cases.GpuBackend
+    for fc in cases.fuzz_osc_cases(seed, 24, plain_six=plain):
         try:
-            worst = max(worst, cases.check_fuzz_case(cases.GpuBackend, fc))
+            worst = max(worst, cases.check_fuzz_case(factory, fc))
         except Exception as e:  # noqa: BLE001
             fails.append(("osc", seed, fc.get("kw"), repr(e)[:300]))
         n_osc += 1
@@ -50,7 +54,9 @@ n_def, t4, s4 = 0, time.time(), 9000 + offset
 while time.time() - t4 < min(30.0, budget * 0.15):
     rng = np.random.RandomState(s4)
     n = int(rng.randint(4, 8))
-    be = cases.GpuBackend(make_arm(n, s4, non_orthogonal=bool(rng.randint(2))))
+    # with or without the training signal asked for (drawn per case): without it the plain six-row law below runs its NOTS
+    # instantiations in every pass - what bench.py times
+    be = cases.GpuBackend(make_arm(n, s4, non_orthogonal=bool(rng.randint(2))), training_signal=bool(s4 & 1))
     B = 20000
     q, dq, t = rng.uniform(-3, 3, (B, n)), rng.uniform(-2, 2, (B, n)), rng.uniform(-0.6, 0.6, (B, 6))
     dof = [1] * 6 if n >= 6 else [1, 1, 1, 1, 0, 0]
