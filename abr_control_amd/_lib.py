@@ -192,7 +192,33 @@ class DeviceArray:
         check(lib().abrk_memset(self.device, self.ptr, 0, self.nbytes, getattr(stream, "ptr", stream)))
         return self
 
+    def rows(self, lo, hi):
+        """rows [lo, hi) of this array as a DeviceArray of their own: a VIEW (same memory, no copy; keeps this array
+        alive) - how several control loops share one batch buffer (engine.MergedLoops)"""
+        lo, hi = int(lo), int(hi)
+        if not 0 <= lo <= hi <= self.shape[0]:
+            raise IndexError(f"rows [{lo}, {hi}) outside 0..{self.shape[0]}")
+        v = DeviceArray.__new__(DeviceArray)
+        v.shape, v.dtype, v.device = (hi - lo,) + self.shape[1:], self.dtype, self.device
+        row_bytes = (self.nbytes // self.shape[0]) if self.shape[0] else 0
+        v.nbytes = (hi - lo) * row_bytes
+        v.ptr = (self.ptr or 0) + lo * row_bytes
+        v._base = self  # a view frees nothing
+        return v
+
+    def copy_from_numpy(self, a, stream=None):
+        """overwrite the buffer with a host array of the same shape (synchronous)"""
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.shape != self.shape:
+            raise ValueError(f"expected {self.shape}, got {a.shape}")
+        if self.nbytes:
+            check(lib().abrk_memcpy_h2d(self.device, self.ptr, a.ctypes.data, a.nbytes, getattr(stream, "ptr", stream)))
+        return self
+
     def free(self):
+        if getattr(self, "_base", None) is not None:  # a view (rows()): the memory belongs to its base array
+            self.ptr = None
+            return
         if self.ptr:
             lib().abrk_free(self.device, self.ptr)
             self.ptr = None

@@ -677,6 +677,65 @@ class SlidingPlan(Plan):
             ptr["target_acc"], ptr["u"], ptr["s"], device, _sp(stream)))
 
 
+class MergedLoops:
+    """Several INDEPENDENT control loops that run the same controller on one GPU, evaluated by ONE launch per tick.
+
+    Why: independent loops on streams of their own do not overlap beyond two streams - the runtime maps streams onto a
+    few hardware queues and the command processor serialises the dependent kernel chains that share one (measured,
+    profiles/round6/concurrent_streams.md: 16 streams of 4096-row graph replays reach 3.0 G evaluations/s, while the
+    same 65 536 rows as one launch take 5.4 us: 12.2 G/s; more hardware queues - GPU_MAX_HW_QUEUES=8 / 16 - make it
+    4x WORSE).  A config-sized step occupies 64 of the chip's 1024 SIMDs, so the remedy is to put the loops' rows into
+    one batch: loop i owns rows [lo_i, hi_i) of shared q / dq / target / u buffers (`loop(i)`: DeviceArray VIEWS - each
+    loop writes its states and reads its torques without knowing of the others), and `launch()` / `launch_graph(K)`
+    evaluate every loop's rows together.  The loops share the controller's parameters (one `abrk_osc_params` per
+    launch); loops with different gains need launches of their own.
+
+        loops = engine.MergedLoops(rc.arm_id, rc.N_JOINTS, params, [4096] * 16, device=0)
+        loops.loop(3).q.copy_from_numpy(q3) ...        # every loop feeds its own rows
+        loops.launch(); loops.stream.sync()
+        u3 = loops.loop(3).u.numpy(loops.stream)"""
+
+    def __init__(self, arm_id, n, params, rows_per_loop, dtype=np.float64, device=0, stream=None, target_velocity=False,
+                 training_signal=False):
+        from ._lib import Stream
+
+        self.rows = [int(r) for r in rows_per_loop]
+        if not self.rows or min(self.rows) < 1:
+            raise ValueError("every loop needs at least one row")
+        self.bounds = np.concatenate([[0], np.cumsum(self.rows)]).tolist()
+        B = self.bounds[-1]
+        self.device, self.stream = device, stream if stream is not None else Stream(device)
+        mk = lambda w: DeviceArray((B, w), dtype, device)
+        self.q, self.dq, self.target, self.u = mk(n), mk(n), mk(6), mk(n)
+        self.target_velocity = mk(6).zero_() if target_velocity else None
+        self.integrated_error = mk(6).zero_() if params.ki != 0 else None
+        self.training_signal = mk(n) if training_signal else None
+        with Plan(device, self.stream) as self.plan:
+            osc_generate(arm_id, n, params, self.q, self.dq, self.target, self.target_velocity, self.integrated_error,
+                         None, self.u, self.training_signal if training_signal else False, dtype=dtype, device=device,
+                         stream=self.stream)
+
+    def loop(self, i):
+        """loop i's rows of every buffer, as DeviceArray views: .q .dq .target .u (.target_velocity .integrated_error
+        .training_signal where present)"""
+        import types
+
+        lo, hi = self.bounds[i], self.bounds[i + 1]
+        v = lambda a: None if a is None else a.rows(lo, hi)
+        return types.SimpleNamespace(q=v(self.q), dq=v(self.dq), target=v(self.target), u=v(self.u),
+                                     target_velocity=v(self.target_velocity), integrated_error=v(self.integrated_error),
+                                     training_signal=v(self.training_signal), rows=(lo, hi))
+
+    def launch(self):
+        self.plan.launch()
+
+    def launch_graph(self, repeat):
+        self.plan.launch_graph(repeat)
+
+    def close(self):
+        self.plan.close()
+
+
 def ik_generate_path(arm_id, n, params, position, target, dtype=np.float64, device=0, stream=None,
                      position_path=None, velocity_path=None):
     """InverseKinematics.generate_path for B paths: position [B,n], target [B,6] (xyz + Euler 'sxyz').

@@ -319,9 +319,11 @@ class MultiDevice:
         return ShardedPlan(plans, self.streams, _CutOnly(self.devices), results)
 
     def record_generate(self, ctrlr, q, dq, target, target_velocity=None, ref_frame="EE", xyz_offset=None, u=None,
-                        training_signal=None):
+                        training_signal=True):
         """One tick of `ctrlr.generate` on resident ShardedArrays as a ShardedPlan: plan.launch(K) / plan.launch_graph(K)
-        replay K ticks on every device from one call; the outputs are plan.u (and plan.training_signal), per-row state
+        replay K ticks on every device from one call; the outputs are plan.u and plan.training_signal (= ctrlr.
+        training_signal, as OSC.generate leaves it, osc.py:297; training_signal=False: not computed - the six-row law
+        then runs its NOTS kernels, whose u differs from the class's in the last bits, include/abrk.h), per-row state
         (integrated_error) lives in ctrlr.integrated_error as a ShardedArray."""
         from . import engine
         from .controllers import OSC
@@ -334,6 +336,12 @@ class MultiDevice:
         ie = self._sharded_state(ctrlr, B, rc.dtype)
         u = u if u is not None else ShardedArray.empty((B, n), rc.dtype, self.devices, rows=q.rows)
         ts = training_signal
+        if ts is True:
+            ts = ShardedArray.empty((B, n), rc.dtype, self.devices, rows=q.rows)
+        elif ts is False:
+            ts = None
+        if ts is not None:
+            ctrlr.training_signal = ts
 
         def tick(g, d, st):
             engine.osc_generate(rc.arm_id, n, params, q.parts[g], dq.parts[g], target.parts[g],
