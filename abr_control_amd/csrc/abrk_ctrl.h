@@ -817,16 +817,29 @@ ABRK_INL void pinv_3xN(const T (&J)[N][3], T rcond, T (&P)[N][3]) {
 // and nothing can overflow (a reciprocal square root per step was a sixth of the orientation error's cost).
 // STEPS = 1 where R is a product of exact joint rotations (orthogonal to rounding: the frame rotation of an orthogonal
 // chain inside the fused kernels) - the heaviest column is then already the eigenvector to ~1e-16.
+// (Every sum of products in this section is written as an explicit fma chain under `fp contract(off)`: which multiply the
+//  compiler fuses with which add otherwise depends on the code around the inlined call, and the two kernels that run
+//  the six-row law on a row - first pass and complete row program - must round alike: a row's bits do not depend on the
+//  batch it arrives in, G::test_gpu_six_row_bits_do_not_depend_on_the_batch_size.)
+template <class T>
+ABRK_INL T dot4_fma(T a0, T b0, T a1, T b1, T a2, T b2, T a3, T b3) {
+  return Rm<T>::fma(a3, b3, Rm<T>::fma(a2, b2, Rm<T>::fma(a1, b1, a0 * b0)));
+}
+template <class T>
+ABRK_INL T dot3_fma(T a0, T b0, T a1, T b1, T a2, T b2) {
+  return Rm<T>::fma(a2, b2, Rm<T>::fma(a1, b1, a0 * b0));
+}
 template <class T, int STEPS = 3>
 ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
+#pragma clang fp contract(off)
   const T m00 = R[0], m01 = R[1], m02 = R[2], m10 = R[3], m11 = R[4], m12 = R[5], m20 = R[6], m21 = R[7],
           m22 = R[8];
   const T th = T(1) / T(3);
   T Bm[4][4];
-  Bm[0][0] = (m00 - m11 - m22) * th + th;
-  Bm[1][1] = (m11 - m00 - m22) * th + th;
-  Bm[2][2] = (m22 - m00 - m11) * th + th;
-  Bm[3][3] = (m00 + m11 + m22) * th + th;
+  Bm[0][0] = Rm<T>::fma(m00 - m11 - m22, th, th);
+  Bm[1][1] = Rm<T>::fma(m11 - m00 - m22, th, th);
+  Bm[2][2] = Rm<T>::fma(m22 - m00 - m11, th, th);
+  Bm[3][3] = Rm<T>::fma(m00 + m11 + m22, th, th);
   Bm[1][0] = Bm[0][1] = (m01 + m10) * th;
   Bm[2][0] = Bm[0][2] = (m02 + m20) * th;
   Bm[2][1] = Bm[1][2] = (m12 + m21) * th;
@@ -849,11 +862,11 @@ ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
   sfor<STEPS>([&](auto it) ABRK_LAMBDA {
     T w[4];
     sfor<4>([&](auto i) ABRK_LAMBDA {
-      w[i()] = Bm[i()][0] * v[0] + Bm[i()][1] * v[1] + Bm[i()][2] * v[2] + Bm[i()][3] * v[3];
+      w[i()] = dot4_fma(Bm[i()][0], v[0], Bm[i()][1], v[1], Bm[i()][2], v[2], Bm[i()][3], v[3]);
     });
     sfor<4>([&](auto i) ABRK_LAMBDA { v[i()] = w[i()]; });
   });
-  T nn = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  T nn = dot4_fma(v[0], v[0], v[1], v[1], v[2], v[2], v[3], v[3]);
   T inv = Rm<T>::rsqrt(nn);
   T sg = (v[3] < T(0)) ? -inv : inv;
   qo[0] = v[3] * sg;
@@ -862,24 +875,37 @@ ABRK_INL void quat_from_R(const T (&R)[9], T (&qo)[4]) {
   qo[3] = v[2] * sg;
 }
 
+// sin / cos of three angles: through the calling kernel's LDS table where it keeps one (`tab`; sincos_all_tab: one
+// straight-line block, the library behind one rarely taken branch), else the polynomial / library routine
+template <class T, bool TAB>
+ABRK_INL void sincos3(T a0, T a1, T a2, T (&sv)[3][2], const void* tab) {
+  if constexpr (TAB) {
+    const T x[3] = {a0, a1, a2};
+    sincos_all_tab<3>(x, sv, tab);
+  } else {
+    Rm<T>::sincos(a0, sv[0][0], sv[0][1]);
+    Rm<T>::sincos(a1, sv[1][0], sv[1][1]);
+    Rm<T>::sincos(a2, sv[2][0], sv[2][1]);
+  }
+}
 // quaternion_from_euler(ai, aj, ak, 'rxyz') (transformations.py:1096-1150), then unit_vector
-template <class T>
-ABRK_INL void quat_from_euler_rxyz(T ai, T aj, T ak, T (&q)[4]) {
+template <class T, bool TAB = false>
+ABRK_INL void quat_from_euler_rxyz(T ai, T aj, T ak, T (&q)[4], const void* tab = nullptr) {
+#pragma clang fp contract(off)
   // axes 'rxyz' -> (firstaxis, parity, repetition, frame) = (2, 1, 0, 1): i=3, j=2, k=1
   T t = ai;
   ai = ak;
   ak = t;
   aj = -aj;
-  T si, ci, sj, cj, sk, ck;
-  Rm<T>::sincos(ai / T(2), si, ci);
-  Rm<T>::sincos(aj / T(2), sj, cj);
-  Rm<T>::sincos(ak / T(2), sk, ck);
+  T sv[3][2];
+  sincos3<T, TAB>(ai / T(2), aj / T(2), ak / T(2), sv, tab);
+  const T si = sv[0][0], ci = sv[0][1], sj = sv[1][0], cj = sv[1][1], sk = sv[2][0], ck = sv[2][1];
   T cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
-  q[0] = cj * cc + sj * ss;
-  q[3] = cj * sc - sj * cs;
-  q[2] = -(cj * ss + sj * cc);
-  q[1] = cj * cs - sj * sc;
-  T inv = Rm<T>::rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] = Rm<T>::fma(cj, cc, sj * ss);
+  q[3] = Rm<T>::fma(cj, sc, -(sj * cs));
+  q[2] = -Rm<T>::fma(cj, ss, sj * cc);
+  q[1] = Rm<T>::fma(cj, cs, -(sj * sc));
+  T inv = Rm<T>::rsqrt(dot4_fma(q[0], q[0], q[1], q[1], q[2], q[2], q[3], q[3]));
   sfor<4>([&](auto i) ABRK_LAMBDA { q[i()] *= inv; });
 }
 
@@ -887,39 +913,40 @@ ABRK_INL void quat_from_euler_rxyz(T ai, T aj, T ak, T (&q)[4]) {
 // then unit_vector - the target orientation of inverse_kinematics.py:73-82
 template <class T>
 ABRK_INL void quat_from_euler_sxyz(T ai, T aj, T ak, T (&q)[4]) {
+#pragma clang fp contract(off)
   T si, ci, sj, cj, sk, ck;
   Rm<T>::sincos(ai / T(2), si, ci);
   Rm<T>::sincos(aj / T(2), sj, cj);
   Rm<T>::sincos(ak / T(2), sk, ck);
   T cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
-  q[0] = cj * cc + sj * ss;
-  q[1] = cj * sc - sj * cs;
-  q[2] = cj * ss + sj * cc;
-  q[3] = cj * cs - sj * sc;
-  T inv = Rm<T>::rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  q[0] = Rm<T>::fma(cj, cc, sj * ss);
+  q[1] = Rm<T>::fma(cj, sc, -(sj * cs));
+  q[2] = Rm<T>::fma(cj, ss, sj * cc);
+  q[3] = Rm<T>::fma(cj, cs, -(sj * sc));
+  T inv = Rm<T>::rsqrt(dot4_fma(q[0], q[0], q[1], q[1], q[2], q[2], q[3], q[3]));
   sfor<4>([&](auto i) ABRK_LAMBDA { q[i()] *= inv; });
 }
 
 // euler_matrix(ai, aj, ak, 'rxyz')[:3,:3] (transformations.py:973-1032)
-template <class T>
-ABRK_INL void euler_matrix_rxyz(T ai, T aj, T ak, T (&M)[9]) {
+template <class T, bool TAB = false>
+ABRK_INL void euler_matrix_rxyz(T ai, T aj, T ak, T (&M)[9], const void* tab = nullptr) {
+#pragma clang fp contract(off)
   // (2,1,0,1): i=2, j=1, k=0; swap ai/ak; negate all
   T t = ai;
   ai = -ak;
   ak = -t;
   aj = -aj;
-  T si, ci, sj, cj, sk, ck;
-  Rm<T>::sincos(ai, si, ci);
-  Rm<T>::sincos(aj, sj, cj);
-  Rm<T>::sincos(ak, sk, ck);
+  T sv[3][2];
+  sincos3<T, TAB>(ai, aj, ak, sv, tab);
+  const T si = sv[0][0], ci = sv[0][1], sj = sv[1][0], cj = sv[1][1], sk = sv[2][0], ck = sv[2][1];
   T cc = ci * ck, cs = ci * sk, sc = si * ck, ss = si * sk;
   constexpr int i = 2, j = 1, k = 0;
   M[i * 3 + i] = cj * ck;
-  M[i * 3 + j] = sj * sc - cs;
-  M[i * 3 + k] = sj * cc + ss;
+  M[i * 3 + j] = Rm<T>::fma(sj, sc, -cs);
+  M[i * 3 + k] = Rm<T>::fma(sj, cc, ss);
   M[j * 3 + i] = cj * sk;
-  M[j * 3 + j] = sj * ss + cc;
-  M[j * 3 + k] = sj * cs - sc;
+  M[j * 3 + j] = Rm<T>::fma(sj, ss, cc);
+  M[j * 3 + k] = Rm<T>::fma(sj, cs, -sc);
   M[k * 3 + i] = -sj;
   M[k * 3 + j] = cj * si;
   M[k * 3 + k] = cj * ci;
@@ -928,21 +955,24 @@ ABRK_INL void euler_matrix_rxyz(T ai, T aj, T ak, T (&M)[9]) {
 // quaternion_multiply(q1, q0) (transformations.py:1274-1290)
 template <class T>
 ABRK_INL void quat_mul(const T (&q1)[4], const T (&q0)[4], T (&r)[4]) {
+#pragma clang fp contract(off)
   T w0 = q0[0], x0 = q0[1], y0 = q0[2], z0 = q0[3];
   T w1 = q1[0], x1 = q1[1], y1 = q1[2], z1 = q1[3];
-  r[0] = -x1 * x0 - y1 * y0 - z1 * z0 + w1 * w0;
-  r[1] = x1 * w0 + y1 * z0 - z1 * y0 + w1 * x0;
-  r[2] = -x1 * z0 + y1 * w0 + z1 * x0 + w1 * y0;
-  r[3] = x1 * y0 - y1 * x0 + z1 * w0 + w1 * z0;
+  r[0] = Rm<T>::fma(w1, w0, -dot3_fma(x1, x0, y1, y0, z1, z0));
+  r[1] = Rm<T>::fma(w1, x0, Rm<T>::fma(-z1, y0, Rm<T>::fma(y1, z0, x1 * w0)));
+  r[2] = Rm<T>::fma(w1, y0, Rm<T>::fma(z1, x0, Rm<T>::fma(y1, w0, -(x1 * z0))));
+  r[3] = Rm<T>::fma(w1, z0, Rm<T>::fma(z1, w0, Rm<T>::fma(-y1, x0, x1 * y0)));
 }
 
 // _calc_orientation_forces (osc.py:149-196)
 // QSTEPS: power steps of quat_from_R (1 where Re is orthogonal to rounding)
-template <class T, int QSTEPS = 3>
-ABRK_INL void orientation_forces(int alg, const T (&Re)[9], const T (&abg)[3], T (&uo)[3]) {
+// TAB: sin / cos of the target's Euler angles through the calling kernel's LDS table (`tab`)
+template <class T, int QSTEPS = 3, bool TAB = false>
+ABRK_INL void orientation_forces(int alg, const T (&Re)[9], const T (&abg)[3], T (&uo)[3], const void* tab = nullptr) {
+#pragma clang fp contract(off)
   if (alg == 0) {
     T qd[4], qe[4], qec[4], qr[4];
-    quat_from_euler_rxyz(abg[0], abg[1], abg[2], qd);
+    quat_from_euler_rxyz<T, TAB>(abg[0], abg[1], abg[2], qd, tab);
     quat_from_R<T, QSTEPS>(Re, qe);
     qec[0] = qe[0];
     qec[1] = -qe[1];
@@ -953,16 +983,16 @@ ABRK_INL void orientation_forces(int alg, const T (&Re)[9], const T (&abg)[3], T
     sfor<3>([&](auto r) ABRK_LAMBDA { uo[r()] = -qr[1 + r()] * sg; });
   } else {
     T Rd[9], Red[9], qed[4];
-    euler_matrix_rxyz(abg[0], abg[1], abg[2], Rd);
+    euler_matrix_rxyz<T, TAB>(abg[0], abg[1], abg[2], Rd, tab);
     sfor<3>([&](auto r) ABRK_LAMBDA {
       sfor<3>([&](auto c) ABRK_LAMBDA {
-        Red[r() * 3 + c()] = Re[0 * 3 + r()] * Rd[0 * 3 + c()] + Re[1 * 3 + r()] * Rd[1 * 3 + c()] +
-                             Re[2 * 3 + r()] * Rd[2 * 3 + c()];
+        Red[r() * 3 + c()] = dot3_fma(Re[0 * 3 + r()], Rd[0 * 3 + c()], Re[1 * 3 + r()], Rd[1 * 3 + c()],
+                                      Re[2 * 3 + r()], Rd[2 * 3 + c()]);
       });
     });
     quat_from_R<T, QSTEPS>(Red, qed);
     sfor<3>([&](auto r) ABRK_LAMBDA {
-      uo[r()] = -(Re[r() * 3 + 0] * qed[1] + Re[r() * 3 + 1] * qed[2] + Re[r() * 3 + 2] * qed[3]);
+      uo[r()] = -dot3_fma(Re[r() * 3 + 0], qed[1], Re[r() * 3 + 1], qed[2], Re[r() * 3 + 2], qed[3]);
     });
   }
 }
@@ -1425,7 +1455,10 @@ ABRK_INL void osc_law6(const OscP<T>& P, const T (&Ms)[N * (N + 1) / 2], const T
   if (P.pos_on) sfor<3>([&](auto r) ABRK_LAMBDA { ut[r()] = p[r()] - tgt[r()]; });
   if (P.ori_on) {
     T abg[3] = {tgt[3], tgt[4], tgt[5]}, uo[3];
-    orientation_forces<T, QSTEPS>(P.alg, RF, abg, uo);
+    // (the target's Euler angles: through the kernel's sin / cos table in LDS where there is one - 16 + 3 instructions
+    //  per angle against 25 + 10 of the polynomial routine)
+    if constexpr (Rows::kHasTab) orientation_forces<T, QSTEPS, true>(P.alg, RF, abg, uo, js.sctab);
+    else orientation_forces<T, QSTEPS>(P.alg, RF, abg, uo);
     sfor<3>([&](auto r) ABRK_LAMBDA { ut[3 + r()] = uo[r()]; });
   }
   // integral term (osc.py:262-264).  (A deferred row returns below without its state being stored.)
@@ -1833,6 +1866,17 @@ ABRK_INL void osc_row(const A& arm, const OscP<T>& P, const T (&q)[A::N], const 
     } else {
       mulBE_pt<A, T>(arm, XR, xo, p);
     }
+  } else if constexpr (std::decay<Scr>::type::kEeFrame) {
+    // the end effector's frame, known at compile time: no capture in the chain (ScratchBase::kEeFrame); the same
+    // expressions as the capture path below, so the same bits
+    NoCap nc;
+    dynamics_pass(nc);
+    T oe[3];
+    mulBE<A, T>(arm, XR, xo, RF, oe);
+    sfor<3>([&](auto r) ABRK_LAMBDA {
+      p[r()] = oe[r()] + RF[r() * 3] * P.off[0] + RF[r() * 3 + 1] * P.off[1] + RF[r() * 3 + 2] * P.off[2];
+    });
+    m = N;
   } else {
     FrameCap<T> cap;
     cap.frame = P.ref_frame;

@@ -942,6 +942,11 @@ struct ScratchBase {
   // its velocity term BEFORE the factorisations - six values fewer to carry through them, which is what the first
   // pass's 256-register budget was short of (it spilled them: 86 B per row of scratch writes, PMC)
   static constexpr bool kNoTs = false;
+  // true where the launch's reference frame is known to be the end effector when the kernel is compiled (EeFrame below;
+  // the first pass of the plain six-row law - the reference benchmark's setting - is instantiated that way too): the
+  // forward kinematics then carries no frame capture (14 uniform compares, 24 captured registers live down the chain)
+  // and ends in the same mulBE the capture would have run - the same bits
+  static constexpr bool kEeFrame = false;
   bool allow_defer = false, deferred = false;
   bool singular = false;  // the row's M has a non-positive pivot (the law's verdict; the flag is stored after the outputs)
 #if defined(ABRK_TIMELINE)
@@ -1032,6 +1037,10 @@ struct DeferOnly : Scr {
 template <class Scr>
 struct NoTs : Scr {
   static constexpr bool kNoTs = true;
+};
+template <class Scr>
+struct EeFrame : Scr {
+  static constexpr bool kEeFrame = true;
 };
 
 // a + al x d + w (w . d) - w2 d : acceleration of a point at offset d from a point of the same body whose

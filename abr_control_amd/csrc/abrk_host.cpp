@@ -773,6 +773,28 @@ void wl_forget_stream(int device, hipStream_t stream) {
   }
   if (mine) wl_retire(mine, true);  // (a caller that found the slot just before may still be enqueueing: s->mu)
 }
+// Beyond kHandoverRows and up to here the hand-over form continues with the DENSE finish kernel (abrk_law.hip
+// osc6_finish_dense_kernel, round 6: 64 chunks' records numbered through, one record per lane) instead of the recompute
+// pass.  Same box, UR5 six rows, us per step recompute / dense: 131 072 rows 36.9 / 29.5, 1 M rows 98.9 / 98.0, 8 M rows
+// 708 / 758 (profiles/round6/dense_finish_ab.txt): while the records (656 B per deferred row, written 16 bytes at a time
+// by ~3 lanes of a wavefront) stay in the caches they beat re-running the 1800-instruction kinematics; from HBM their
+// traffic - 2 x 253 MB at 8 M rows - costs more than the recomputation.
+constexpr int64_t kDenseFinishRows = 1 << 20;
+int64_t dense_finish_max() {
+  static const int64_t v = [] {  // measurement switch (0: recompute form beyond kHandoverRows, as until round 5)
+    const char* e = measurement_env("ABRK_DENSE_MAX");
+    return e ? (int64_t)atoll(e) : kDenseFinishRows;
+  }();
+  return v;
+}
+int64_t handover_max() {  // the largest batch whose records go to the per-chunk / grouped finish kernels
+  static const int64_t v = [] {  // measurement switch
+    const char* e = measurement_env("ABRK_HANDOVER_MAX");
+    const int64_t x = e ? atoll(e) : kHandoverRows;
+    return x < kHandoverMaxRows ? x : (int64_t)kHandoverMaxRows;
+  }();
+  return v;
+}
 bool handover_enabled() {
   static const bool off = measurement_env("ABRK_NO_HANDOVER") != nullptr;  // measurement switch: the round-3 scheme
   return !off;
@@ -805,14 +827,10 @@ int worklist_for(int device, hipStream_t stream, int64_t B, int n, int dtype, in
   static const bool off = measurement_env("ABRK_NO_DEFER") != nullptr;  // measurement switch: sweeps inline, as before round 2
   // (row indices are parked as 32-bit ints: batches beyond 2^31 rows - they fit the 288 GB for fp32 arms - run inline)
   if (off || B > 0x7fffffffLL) return 0;
-  static const int64_t ho_max = [] {  // measurement switch: the largest batch that takes the hand-over form
-    const char* e = measurement_env("ABRK_HANDOVER_MAX");
-    const int64_t v = e ? atoll(e) : kHandoverRows;
-    return v < kHandoverMaxRows ? v : (int64_t)kHandoverMaxRows;
-  }();
+  const int64_t ho_max = handover_max();
   // below one wavefront of rows the second launch costs more than the eigen-decomposition it takes off the critical path
   // (a single state truncates in 4.6 % of the calls: 0.7 us expected, against ~4 us of launch + the finish kernel's scan)
-  const bool handover = handover_enabled() && B <= ho_max && B >= 64;
+  const bool handover = handover_enabled() && B >= 64 && (B <= ho_max || B <= dense_finish_max());
   // the recompute form below ~16 k rows: the second launch costs more than the divergence it removes (round 2)
   if (!handover && B < 16384) return 0;
   const size_t need = (size_t)wl_ints(B) * sizeof(int);
@@ -922,6 +940,7 @@ int finish_slots_for(int64_t B) {
 // chunks per group of the grouped finish kernel (abrk_law.hip osc6_finish_group_kernel), 0 = the per-chunk kernel: the
 // 16384-row band, where the per-chunk grid doubles working wavefronts up on SIMDs
 int finish_group_for(int64_t B) {
+  if (B > handover_max()) return -1;  // (beyond that the hand-over form only exists with the dense finish kernel: worklist_for)
   static const int forced = env_int("ABRK_FINISH_GROUP", -1);  // measurement switch: 0 = never grouped, 1..16 = always
   if (forced >= 0 && forced <= 16) return forced;
   const int64_t nchunk = (B + kBlock - 1) / kBlock;

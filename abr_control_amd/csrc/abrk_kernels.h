@@ -202,7 +202,9 @@ template <class A, class T, int KM, bool USE_C>
 constexpr bool osc_uses_slab() {
   return (USE_C && A::kOrtho) || KM == 6;
 }
-template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOTS = false>
+// EEF (the plain six-row law of arms with a two-wave first pass): the launch's ref_frame is the end effector -
+// ScratchBase::kEeFrame.
+template <class A, class T, int KM, bool USE_C, int FEAT, int PASS = 0, bool NOTS = false, bool EEF = false>
 __global__ void __launch_bounds__(kBlock, osc_min_waves(KM, USE_C, FEAT, A::kOrtho, PASS, A::kStatic))
 osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restrict__ dqg,
            const T* __restrict__ tg, const T* __restrict__ tvg, T* __restrict__ ierrg,
@@ -278,24 +280,19 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
 #endif
       return scr.deferred;
     };
-    if constexpr (kLds && NOTS) {
-      static_assert(KM == 6 && FEAT == 0, "NOTS is instantiated for the plain six-row law");
-      NoTs<std::conditional_t<PASS == 1, DeferOnly<LdsScratch<T, A::N>>, LdsScratch<T, A::N>>> scr;
+    static_assert(!NOTS || (KM == 6 && FEAT == 0), "NOTS is instantiated for the plain six-row law");
+    static_assert(!EEF || (KM == 6 && FEAT == 0 && km6_first_pass_plain(KM, USE_C, FEAT, A::kOrtho, 1, A::kStatic)),
+                  "EEF is instantiated for the plain six-row law of arms with a two-wave first pass");
+    using S0 = std::conditional_t<kLds, LdsScratch<T, A::N>, TabScratch<T, A::N>>;
+    using S1 = std::conditional_t<PASS == 1, DeferOnly<S0>, S0>;
+    using S2 = std::conditional_t<NOTS, NoTs<S1>, S1>;
+    std::conditional_t<EEF, EeFrame<S2>, S2> scr;
+    if constexpr (kLds) {
       scr.slab = slab;
       scr.lane = lane;
-      scr.sctab = sctab;
-      return go(scr);
-    } else if constexpr (kLds) {
-      std::conditional_t<PASS == 1, DeferOnly<LdsScratch<T, A::N>>, LdsScratch<T, A::N>> scr;
-      scr.slab = slab;
-      scr.lane = lane;
-      scr.sctab = sctab;
-      return go(scr);
-    } else {
-      std::conditional_t<PASS == 1, DeferOnly<TabScratch<T, A::N>>, TabScratch<T, A::N>> scr;
-      scr.sctab = sctab;
-      return go(scr);
     }
+    scr.sctab = sctab;
+    return go(scr);
   };
   // hand-over mode: which rows of a 64-row chunk deferred, as one mask per chunk (every chunk writes its mask, so the
   // array needs no clearing between calls); the finish kernel compacts the masks
@@ -815,19 +812,39 @@ struct Launch {
   }
   template <int KM, bool UC, int FEAT>
   static hipError_t osc_launch(const LaunchArgs& la, const OscArgs& a) {
+    // the first pass of the plain six-row law has an instantiation for "ref_frame is the end effector" (EEF: no frame
+    // capture in the forward kinematics; the same bits) - the reference benchmark's setting
+    // Built for the arms whose first pass holds two waves per SIMD (orthogonal built-in / compiled chains: where it was
+    // measured, UR5 8 M rows -1.6 %); the one-wave persistent-loop first pass of general chains keeps the capture.  EVERY
+    // pass of such a launch takes the EEF form (first pass, recompute pass, one-pass): the capture changes the basic-block
+    // structure of the forward kinematics, and with it which multiply the compiler fuses with which add in its
+    // `c a0 + s a1` shapes - a row's bits must not depend on the pass that evaluates it.
+    constexpr bool kEefBuilt = km6_first_pass_plain(KM, UC, FEAT, A::kOrtho, 1, A::kStatic);
+    const bool eef = kEefBuilt && static_cast<const OscP<T>*>(a.P)->ref_frame == 2 * A::N + 1;
+    auto launch = [&](auto pass, auto nots_, auto eef_, dim3 grid, int mode) {
+      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass(), nots_(), eef_()>), grid, dim3(kBlock), 0, la.stream,
+                         arm_of(la), *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq,
+                         (const T*)a.target, (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u,
+                         nots_() ? (T*)nullptr : (T*)a.ts, mode, a.wl, (T*)a.rec);
+    };
+    using std::false_type;
+    using std::true_type;
     auto go = [&](auto pass, dim3 grid, int mode) {
-      hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass()>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
-                         *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
-                         (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)a.ts, mode, a.wl, (T*)a.rec);
+      if constexpr (kEefBuilt && FEAT == 0) {
+        if (eef) return launch(pass, false_type{}, true_type{}, grid, mode);
+      }
+      launch(pass, false_type{}, false_type{}, grid, mode);
     };
     // the plain six-row law when no training signal is asked for (NOTS: gravity joins the velocity term before the
     // factorisations).  EVERY form of the law then runs that arithmetic - first pass, recompute pass, one-pass - so
     // that a row's bits do not depend on the batch it arrives in.
     auto go_nots = [&](auto pass, dim3 grid, int mode) {
-      if constexpr (KM == 6 && FEAT == 0)
-        hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass(), true>), grid, dim3(kBlock), 0, la.stream, arm_of(la),
-                           *static_cast<const OscP<T>*>(a.P), la.B, (const T*)a.q, (const T*)a.dq, (const T*)a.target,
-                           (const T*)a.tv, (T*)a.ierr, (const T*)a.une, (T*)a.u, (T*)nullptr, mode, a.wl, (T*)a.rec);
+      if constexpr (KM == 6 && FEAT == 0) {
+        if constexpr (kEefBuilt) {
+          if (eef) return launch(pass, true_type{}, true_type{}, grid, mode);
+        }
+        launch(pass, true_type{}, false_type{}, grid, mode);
+      }
     };
     const bool nots = KM == 6 && FEAT == 0 && !a.ts;
     if constexpr (KM == 6) {

@@ -95,9 +95,61 @@ osc6_finish_group_kernel(const unsigned long long* __restrict__ masks, const T* 
     }
   }
 }
+// ---- finish kernel, dense form (round 6): batches beyond 65 536 rows, where the deferred rows are many enough to fill
+// wavefronts ONE RECORD PER LANE.  Until round 5 such batches took the recompute form - a second pass of the complete
+// row program over a worklist (kinematics, dynamics, Jacobian, the whole law again for 4.6 % of the rows: ~7000
+// instructions per row, 124 us of an 8 M-row step's 752).  Here a group of 64 consecutive chunks (4096 rows; 188 +- 13
+// records for random UR5 states) is numbered through from its 64 masks - lane l holds chunk l's mask, one wave scan, no
+// atomics - and wavefront w takes records 64 w .. 64 w + 63 of that numbering, each lane finding its record's chunk by a
+// binary search over the scan (six __shfl) and finishing it from the record alone (osc6_finish_row: the lane form,
+// ~5200 instructions).  Lanes are 98 % occupied (the recompute pass packs 100 %, but runs the 1800-instruction
+// kinematics on top).  Grid: groups x 4 wavefronts, a wavefront loops while the group has more records (> 256 of 4096
+// rows deferring: dense fuzz arms, near-singular sets).  Same arithmetic, same bits as every other form.
+template <int N, class T>
+__global__ void __launch_bounds__(kBlock)
+osc6_finish_dense_kernel(const unsigned long long* __restrict__ masks, const T* __restrict__ recs, int nulls,
+                         long nchunk, long B, T* __restrict__ ug, T* __restrict__ tsg) {
+  const int lane = (int)threadIdx.x;
+  const long c0 = (long)blockIdx.x * kBlock;
+  unsigned long long m = 0ull;
+  if (c0 + lane < nchunk) m = masks[c0 + lane];
+  const int cnt = __popcll(m);
+  int incl = cnt;
+  for (int d = 1; d < kBlock; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if (lane >= d) incl += v;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, kBlock - 1);
+  for (int w = (int)blockIdx.y; w * kBlock < total; w += (int)gridDim.y) {
+    const int r = w * kBlock + lane;
+    const int rr = r < total ? r : total - 1;  // (idle lanes of the last block shadow its last record: the shuffles stay uniform)
+    int ch = 0;  // the chunk that holds record rr: the first lane whose inclusive count passes it
+    for (int step = kBlock / 2; step >= 1; step >>= 1) {
+      const int v = __shfl(incl, ch + step - 1);
+      if (v <= rr) ch += step;
+    }
+    const int k = rr - (__shfl(incl, ch) - __shfl(cnt, ch));
+    if (r < total) {
+      const T* rec = recs + ((c0 + ch) * kBlock + k) * rec_len(N);
+      const T rix = rec[21];
+      if (rix >= T(0) && rix < T(B)) {  // (a record's row index is data: nothing is stored outside [0, B))
+        T u[N], ts[N];
+        osc6_finish_row<N, T>(rec, nulls != 0, u, ts);
+        store_row<N>(ug, (long)rix, u);
+        if (tsg) store_row<N>(tsg, (long)rix, ts);
+      }
+    }
+  }
+}
 template <int N, class T>
 static hipError_t finish_launch(const LaunchArgs& la, const FinishArgs& a) {
   const unsigned nchunk = (unsigned)((la.B + kBlock - 1) / kBlock);
+  if (a.group < 0) {  // (FinishArgs::group == -1: the dense form)
+    hipLaunchKernelGGL((osc6_finish_dense_kernel<N, T>), dim3((nchunk + kBlock - 1) / kBlock, 4u), dim3(kBlock), 0,
+                       la.stream, (const unsigned long long*)a.masks, (const T*)a.rec, a.nulls, (long)nchunk, la.B,
+                       (T*)a.u, (T*)a.ts);
+    return hipGetLastError();
+  }
   if (a.group > 0) {
     // grouped form: four wavefronts per chunk; a group with more than coop_rounds x its wavefronts goes one record per lane
     const int gc = a.group, wg = 4 * gc;
@@ -112,7 +164,8 @@ static hipError_t finish_launch(const LaunchArgs& la, const FinishArgs& a) {
 }
 hipError_t launch_osc6_finish(int n, int dtype, const LaunchArgs& la, const FinishArgs& a) {
   // (group: at most 16 chunks - four wavefronts per chunk - so that one lane per chunk holds the group's masks)
-  if (a.slots < 1 || a.slots > kBlock || a.group < 0 || a.group > 16 || la.B < 1 || la.B > kHandoverMaxRows) return hipErrorInvalidValue;
+  if (a.slots < 1 || a.slots > kBlock || a.group < -1 || a.group > 16 || la.B < 1 || (a.group >= 0 && la.B > kHandoverMaxRows))
+    return hipErrorInvalidValue;
 #define ABRK_CASE(NN) \
   case NN:            \
     return dtype == 0 ? finish_launch<NN, double>(la, a) : finish_launch<NN, float>(la, a);

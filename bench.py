@@ -42,9 +42,9 @@ FP64_VALU_PEAK_TF = 78.6   # = 1/2 of the 157.3 TF fp32 vector peak
 ISSUE_PEAK_NOMINAL = {"f64": 1024 * 16 * 2.4e9, "f32": 1024 * 32 * 2.4e9}
 # committed rocprofv3 evidence.  (Earlier rounds are not consulted: kernel names changed - a template parameter was added -
 # and round 2's traffic.json keyed the grid-stride kernels by grid threads instead of rows.)
-PROFILE_DIRS = ("round5", "round4", "round3")
+PROFILE_DIRS = ("round6", "round5", "round4", "round3")
 # the reference's own Cython path timed on a GPU box's host (cpu_baseline fallback where no staged reference travels)
-BASELINE_DIRS = ("round5", "round4", "round3", "round2")
+BASELINE_DIRS = ("round6", "round5", "round4", "round3", "round2")
 
 WORKLOADS = {
     # name: (arm, batch per GPU, dtype, kind, params kwargs, algorithmic flops per eval)
@@ -233,8 +233,12 @@ class Runner:
             km = 3 if fast else (2 if dof == [1, 1, 0, 0, 0, 0] and self.n <= 3 and p.ref_frame == 2 * self.n + 1 else 6)
             # ... and, the bench never asking for the training signal, the plain law's first pass is the NOTS variant
             nots = six_two_pass and not p.n_null and not os.environ.get("ABRK_BENCH_TS")
+            # ... and, the reference frame being the end effector, the first pass of the plain law is the EEF instantiation
+            # (round 6: no frame capture in the forward kinematics)
+            eef = (six_two_pass and not p.n_null and p.ref_frame == 2 * self.n + 1
+                   and self.arm in ("ur5", "threejoint", "twojoint", "onejoint"))  # orthogonal chains: abrk_kernels.h kEefBuilt
             return (f"osc_kernel<{arm}, {t}, {km}, {b(p.use_C)}, {1 if p.n_null else 0}, {1 if six_two_pass else 0}, "
-                    f"{b(nots)}>")
+                    f"{b(nots)}, {b(eef)}>")
         if k == "dyn":
             return f"dyn_kernel<{arm}, {t}, {'true' if ('C' in self.want or 'dJ' in self.want) else 'false'}>"
         if k == "osc_full":
@@ -344,7 +348,7 @@ class Runner:
         if self.plan is not None and 8 <= steps < self.graph_steps:
             self.graph_steps = steps  # a short run is one graph of exactly K nodes
         graph = self.used_graph = self.plan is not None and self.graph_steps > 1 and steps >= self.graph_steps
-        # measurement switch (tools/gpu_latency_r3.sh): a short run as `head` plain launches followed by ONE graph of the
+        # measurement switch (tools/history/gpu_latency_r3.sh): a short run as `head` plain launches followed by ONE graph of the
         # remaining K - head nodes - does the GPU-side lead-in of a graph launch hide behind kernels already running?
         head = int(os.environ.get("ABRK_BENCH_HEAD", "0")) if graph and steps == self.graph_steps else 0
         head = min(head, max(steps - 2, 0))
@@ -441,7 +445,7 @@ def _profiled(fname, kernel, batch):
 
 
 def profiled_traffic(kernel, batch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/gpu_profiles.sh ->
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (tools/gpu_profiles_r6.sh ->
     profiles/<round>/traffic.json): NOT a measurement of the run that prints it - the profile's commit is stamped"""
     t, src, commit = _profiled("traffic.json", kernel, batch)
     if t is None:

@@ -1783,7 +1783,7 @@ def test_gpu_osc_generate_return_dynamics_python_api():
 def test_gpu_fp32_runtime_table_sliding_is_as_accurate_as_the_builtin():
     """at 8 M rows the fp32 Sliding result of the threejoint arm on the runtime-table kernels differed
     from the built-in kernels by up to 2.6e-3 relative (profiles/round2/rt_ab.md).  Measured against the fp64 kernels on
-    the same float32 inputs (tools/gpu_rt_fp32_check.py, profiles/round3/rt_fp32.txt) BOTH fp32 programs are that far
+    the same float32 inputs (tools/history/gpu_rt_fp32_check.py, profiles/round3/rt_fp32.txt) BOTH fp32 programs are that far
     from fp64 on the same handful of rows - the planar arm folded onto itself (q1 ~ pi, q2 ~ 0), where J[:2] loses rank
     and pinv amplifies rounding - the built-in (6.9e-3) more than the runtime table (4.3e-3).  Pinned here: the
     runtime-table kernels are no further from fp64 than the built-in ones anywhere in the distribution, and wherever the

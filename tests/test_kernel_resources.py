@@ -19,15 +19,19 @@ TOOL = os.path.join(REPO, "tools", "kernel_resources.py")
 # (object, kernel as tools/kernel_resources.py prints it): two waves per SIMD, no scratch
 TWO_WAVES = [
     # BASELINE config 2 (the headline), config 4 (+ Coriolis), config 3 (Jaco2 + Damping), config 5 (fp32 Sliding)
-    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 3, false, 0, 0, false>"),
-    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 3, true, 0, 0, false>"),
-    ("abrk_arm_jaco2.o", "osc_kernel<abrk::StaticArm<abrk::Tab_jaco2>, double, 3, false, 1, 0, false>"),
-    ("abrk_arm_jaco2.o", "osc_kernel<abrk::StaticArm<abrk::Tab_jaco2>, double, 3, false, 0, 0, false>"),
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 3, false, 0, 0, false, false>"),
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 3, true, 0, 0, false, false>"),
+    ("abrk_arm_jaco2.o", "osc_kernel<abrk::StaticArm<abrk::Tab_jaco2>, double, 3, false, 1, 0, false, false>"),
+    ("abrk_arm_jaco2.o", "osc_kernel<abrk::StaticArm<abrk::Tab_jaco2>, double, 3, false, 0, 0, false, false>"),
     ("abrk_arm_threejoint.o", "sliding_kernel<abrk::StaticArm<abrk::Tab_threejoint>, float>"),
     # the reference benchmark's UR5 setting (all six task rows): first pass with / without a training signal, with use_C
-    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, false, 0, 1, true>"),
-    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, false, 0, 1, false>"),
-    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, true, 0, 1, false>"),
+    # (round 6: ... each in two forms - ref_frame = EE known at compile time (what the benchmark runs), any frame)
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, false, 0, 1, true, true>"),
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, false, 0, 1, true, false>"),
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, false, 0, 1, false, true>"),
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, false, 0, 1, false, false>"),
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, true, 0, 1, false, true>"),
+    ("abrk_arm_ur5.o", "osc_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 6, true, 0, 1, false, false>"),
     # u + Tx, J, M, g from one launch (the HBM-bound mode)
     ("abrk_arm_ur5.o", "osc_full_kernel<abrk::StaticArm<abrk::Tab_ur5>, double, 3, false, 0, false>"),
 ]

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs the host-layer stress tests of the GPU suite on the sanitizer builds of libabrk.so (csrc/Makefile: make asan tsan
 # ubsan - host code only, the kernels are the product's).  On the GPU box:  bash tools/gpu_sanitize.sh [outdir]
-# Logs: <outdir>/{asan,tsan,ubsan}.log + summary.txt (copied to profiles/round4/sanitizers/ when clean).
+# Logs: <outdir>/{asan,tsan,ubsan}.log + summary.txt (copied to profiles/round6/sanitizers/ when clean).
 set -u
 cd "$(dirname "$0")/.."
 OUT=${1:-gpurun_out/sanitizers}
@@ -10,7 +10,10 @@ RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux
 TESTS="test_gpu_concurrent_host_calls_from_threads or test_gpu_six_row_from_threads_on_default_stream or \
 test_gpu_concurrent_threads_own_streams or test_gpu_plan_slots_are_recycled_and_stale_ids_rejected or \
 test_gpu_six_row_many_short_lived_streams or test_gpu_sharded_call_equals_unsharded_bitwise or \
-test_gpu_sharded_sliding_joint_dynamics_equal_unsharded_bitwise or test_gpu_recorded_plans_equal_direct_calls"
+test_gpu_sharded_sliding_joint_dynamics_equal_unsharded_bitwise or test_gpu_recorded_plans_equal_direct_calls or \
+test_gpu_singular_flag_is_per_stream or test_gpu_resident_shards_equal_unsharded_bitwise or \
+test_gpu_resident_sharded_plan_replays_k_ticks_on_every_shard or \
+test_gpu_resident_shards_from_threads_and_host_sharded_calls_on_disjoint_slots or test_gpu_merged_loops_equal_separate_loops"
 : > "$OUT/summary.txt"
 run() {  # name, runtime .so, environment
   local name=$1 rt=$2; shift 2

@@ -51,6 +51,19 @@ for f in sorted(os.listdir(src)):
             ROWS[(norm(leg["kernel"]), int(leg["grid_threads"]))] = int(leg["batch"])
 
 
+def osc_args(kn):
+    """(arm + type prefix, [KM, USE_C, FEAT, PASS, NOTS, EEF]) of a normalised osc_kernel name, or None"""
+    if not kn.startswith("osc_kernel<") or not kn.endswith(">"):
+        return None
+    parts = kn[:-1].split(",")
+    if len(parts) < 7:
+        return None
+    tail = parts[-6:]
+    if tail[-1] not in ("true", "false") or tail[-2] not in ("true", "false") or not tail[-3].isdigit():
+        return None  # a name of an earlier round (no EEF argument)
+    return ",".join(parts[:-6]), tail
+
+
 def rows_for(kernel, grid):
     """rows a launch of `kernel` with `grid` threads processed (the grid itself for one-lane-per-row kernels)"""
     kn = norm(kernel)
@@ -59,14 +72,16 @@ def rows_for(kernel, grid):
     # the six-row law's second pass (PASS = 0 at a fixed 2048-block grid) belongs to the leg of its first pass
     # (PASS = 1, with or without the training-signal output)
     # (since round 5 the second pass carries the first pass's NOTS flag: <.., 1, true> goes with <.., 0, true>)
-    if kn.startswith("osc_kernel<") and kn.endswith((",0,false>", ",0,true>")) and int(grid) == 8 * 256 * 64:
-        stem = kn[: kn.rindex(",0,")]
-        big = [b for (k, g), b in ROWS.items() if k in (stem + ",1,true>", stem + ",1,false>")]
+    # (round 6: osc_kernel<arm, T, KM, USE_C, FEAT, PASS, NOTS, EEF> - the first pass may be the EEF instantiation)
+    a = osc_args(kn)
+    if a and a[1][-3] == "0" and int(grid) == 8 * 256 * 64:
+        big = [b for (k, g), b in ROWS.items() if osc_args(k) and osc_args(k)[0] == a[0] and osc_args(k)[1][:-3] == a[1][:-3]
+               and osc_args(k)[1][-3] == "1"]
         if big:
             return max(big)
     return int(grid)
 lines = ["# rocprofv3 evidence (MI355X, ROCm 7.2)", "",
-         f"Commands: `{os.environ.get('ABRK_PROFILE_SCRIPT', 'tools/gpu_profiles_r5.sh')}` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
+         f"Commands: `{os.environ.get('ABRK_PROFILE_SCRIPT', 'tools/gpu_profiles_r6.sh')}` (bench.py under `rocprofv3 --kernel-trace --stats`, then separate "
          "`--pmc` passes as MI355X_MICROARCH.md prescribes).  `FETCH_SIZE`/`WRITE_SIZE` are in KiB; on gfx950 "
          "FETCH_SIZE counts 64 B per 128-B request, so read bytes = FETCH_SIZE x 1024 x 2.", ""]
 for f in ("pytest_gpu.log", "smoke.log", "coop_ab.md", "rt_ab.md", "valu_rates.txt", "host.txt", "osc6_step_trace.txt"):
@@ -115,10 +130,10 @@ if os.path.exists(ks):
             leg = ll[0][1]
             mean_us = sel["dur"].mean() / 1e3
             extra = 0.0
-            if kn.startswith("osc_kernel<") and kn.endswith((",1,true>", ",1,false>")):  # + the dense second pass of the same calls
-                stem, tail = kn[: kn.rindex(",1,")], kn[kn.rindex(",1,") + 3:]  # tail: "true>" / "false>" (NOTS)
-                s2 = kt[(kt["kernel"].str.replace(" ", "").isin([(stem + ",0," + tail)[:90], (stem + ",0,false>")[:90]]))
-                        & (kt["Grid_Size_X"] == 8 * 256 * 64)]
+            oa = osc_args(kn)
+            if oa and oa[1][-3] == "1":  # + the dense second pass of the same calls (PASS = 0, same NOTS, same EEF)
+                second = ",".join([oa[0]] + oa[1][:3] + ["0", oa[1][4], oa[1][5]]) + ">"
+                s2 = kt[(kt["kernel"].str.replace(" ", "") == second[:90]) & (kt["Grid_Size_X"] == 8 * 256 * 64)]
                 if not s2.empty:
                     extra = s2["dur"].mean() / 1e3
             frac = leg["batch"] * leg["bytes_per_eval"] / ((mean_us + extra) * 1e-6) / 8e12
@@ -192,7 +207,10 @@ if rows:
         e = {"valu_per_row": float(r["SQ_INSTS_VALU"] / w), "salu_per_row": float(r["SQ_INSTS_SALU"] / w),
              "wave_cycles_per_wave": float(4 * r["SQ_WAVE_CYCLES"] / w),
              "busy_cycles": float(r["SQ_BUSY_CYCLES"]) if "SQ_BUSY_CYCLES" in r else None}
-        if "GRBM_GUI_ACTIVE" in r and r["GRBM_GUI_ACTIVE"] == r["GRBM_GUI_ACTIVE"] and (k, grid0) in durs:
+        # (legs under 50 us are launch-bound: GRBM_GUI_ACTIVE counts the lead-in of a cold dispatch too, and divided by
+        #  the kernel's own duration it printed 4 - 5.5 "GHz" in rounds 4 and 5 - no clock / utilisation for them)
+        if ("GRBM_GUI_ACTIVE" in r and r["GRBM_GUI_ACTIVE"] == r["GRBM_GUI_ACTIVE"] and (k, grid0) in durs
+                and durs[(k, grid0)] >= 50e3):
             # GRBM_GUI_ACTIVE is summed over the 8 XCDs: shader clock = counter / 8 / kernel duration (of these short
             # PMC passes - the first launches after idle run above the sustained clock)
             gui = float(r["GRBM_GUI_ACTIVE"]) / 8.0
