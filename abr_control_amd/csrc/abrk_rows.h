@@ -171,7 +171,12 @@ ABRK_INL void osc_body(long b, const A& arm, const OscP<T>& P, long B, const T* 
   // (the six-row FIRST pass of orthogonal chains asks early too since round 4: its law was restructured to 224 - 246
   //  registers, and at two waves per SIMD one memory round trip fewer per wavefront is worth 2.7 % at 8 M rows - 740 / 746 /
   //  744 us against 760 / 765 / 767 us, same box; the one-wave six-row kernels keep asking late)
-  constexpr bool EARLY = FEAT < 2 && (KM <= 3 || (std::remove_reference<Scr>::type::kDeferOnly && A::kOrtho && A::kStatic));
+  // (round 6: ... and so does the one-wave first pass of built-in / compiled GENERAL chains - 304 + 48 registers on Jaco2,
+  //  room for the 36 more: same box, Jaco2 five task rows at 8 M rows 925.6 -> 877.2 us, 1 M rows 139.7 -> 137.8 us, the
+  //  4096-row step unchanged, same bits (profiles/round6/ab/jaco2_inputs_early/).  Requesting the NEXT row's inputs at the
+  //  law's tail on top of that - software pipelining of the persistent loop - was built and measured too: 360 + 104
+  //  registers, 928 us: the accumulator-register traffic eats what the hidden round trip returns.)
+  constexpr bool EARLY = FEAT < 2 && (KM <= 3 || (std::remove_reference<Scr>::type::kDeferOnly && A::kStatic));
   // (requesting the target after the kinematics in the use_C kernels was measured unnecessary once the link wrenches
   //  of the Coriolis recursion live in LDS: 240 VGPRs either way, one memory round trip fewer)
   constexpr bool EARLY_T = EARLY;

@@ -30,6 +30,18 @@ for w in cfg3 cfg4 cfg5 osc6 osc5_j2 sliding_j2 oscF oscFC; do python bench.py -
 ABRK_BENCH_TS=1 python bench.py --workload osc6 --steps 500 --warmup 50 --no-cpu-baseline --no-strong-leg > $O/bench_osc6_ts.json 2> $O/bench_osc6_ts.err
 for w in cfg3 cfg4 cfg5; do python bench.py --workload $w --steps 500 --warmup 50 --no-strong-leg --no-roofline-leg > $O/bench_${w}_cpu.json 2> $O/bench_${w}_cpu.err; done
 for w in limits floating joint obstacles rollout ik dynF dynC; do python bench.py --workload $w --steps 200 --warmup 20 --roofline-batch 4194304 --no-cpu-baseline --no-strong-leg > $O/bench_$w.json 2> $O/bench_$w.err; done
+python bench.py --gpus 8 --single-process --allow-shared-device --steps 20 --warmup 5 > $O/bench_single_process_8shards.json 2> $O/bench_single_process_8shards.err
+python tools/concurrent_streams_probe.py > $O/concurrent_streams.jsonl 2> $O/concurrent_streams.err
+S="--steps 400 --warmup 50 --no-roofline-leg --no-strong-leg --no-cpu-baseline --no-streams-leg --no-extras"
+: > $O/osc6_sizes.txt
+for b in 4096 16384 65536 131072 262144 524288 1048576 2097152; do
+  for mode in shipped recompute; do
+    E="A=1"; [ $mode = recompute ] && E="ABRK_MEASUREMENT=1 ABRK_DENSE_MAX=0"
+    [ $mode = recompute ] && [ $b -le 65536 ] && continue
+    env $E python bench.py --workload osc6 --batch $b $S 2> /dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('osc6 B=$b $mode', d['roofline_config']['us_per_launch'], 'us/step')" >> $O/osc6_sizes.txt
+  done
+done
 # 3. the kernel trace of the bench command itself
 cd /tmp && export TMPDIR=/tmp
 # (every leg runs its full sustained protocol, so the trace mean of a
