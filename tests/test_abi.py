@@ -37,10 +37,11 @@ def test_struct_layouts_match_header():
     src = r'''
 #include <stdio.h>
 #include "abrk.h"
-int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(abrk_arm_desc), sizeof(abrk_dyn_out),
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(abrk_arm_desc), sizeof(abrk_dyn_out),
   sizeof(abrk_null_ctrl), sizeof(abrk_osc_params), sizeof(abrk_sliding_params), offsetof(abrk_osc_params, null_ctrl),
   sizeof(abrk_limits_params), sizeof(abrk_obstacles_params), offsetof(abrk_obstacles_params, obstacles),
-  sizeof(abrk_scratch_info), offsetof(abrk_scratch_info, device_free_bytes));return 0;}'''
+  sizeof(abrk_scratch_info), offsetof(abrk_scratch_info, device_free_bytes), sizeof(abrk_shard_cut),
+  offsetof(abrk_shard_cut, rows), offsetof(abrk_shard_cut, streams));return 0;}'''
     exe = "/tmp/abrk_layout_probe"
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(REPO, "include"), "-o", exe], input=src.encode(),
                    check=True)
@@ -48,7 +49,43 @@ int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(abrk_a
     assert sizes == [C.sizeof(_abi.ArmDesc), C.sizeof(_abi.DynOut), C.sizeof(_abi.NullCtrl),
                      C.sizeof(_abi.OSCParams), C.sizeof(_abi.SlidingParams), _abi.OSCParams.null_ctrl.offset,
                      C.sizeof(_abi.LimitsParams), C.sizeof(_abi.ObstaclesParams), _abi.ObstaclesParams.obstacles.offset,
-                     C.sizeof(_abi.ScratchInfo), _abi.ScratchInfo.device_free_bytes.offset]
+                     C.sizeof(_abi.ScratchInfo), _abi.ScratchInfo.device_free_bytes.offset, C.sizeof(_abi.ShardCut),
+                     _abi.ShardCut.rows.offset, _abi.ShardCut.streams.offset]
+
+
+def test_resident_entry_points_validate_and_fail_loudly_without_a_device(L):
+    """abrk_*_resident / abrk_shards_sync / abrk_plans_launch (round 6): argument checks that need no device, and
+    ABRK_ENODEV - never a CPU path - where one is needed"""
+    import abr_control_amd as a
+
+    p = _abi.make_osc_params(6, kp=200)
+    ur5 = L.abrk_arm_builtin(b"ur5")
+    dev = (C.c_int32 * 2)(0, 0)
+    rows = (C.c_int64 * 2)(4, 4)
+    cut = _abi.ShardCut(2, dev, rows, None)
+    tab = (C.c_void_p * 2)(None, None)
+    assert L.abrk_osc_generate_resident(ur5, _abi.F64, C.byref(p), None, tab, tab, tab, None, None, None, tab, None) == -1
+    bad = _abi.ShardCut(0, dev, rows, None)
+    assert L.abrk_osc_generate_resident(ur5, _abi.F64, C.byref(p), C.byref(bad), tab, tab, tab, None, None, None, tab, None) < 0
+    assert L.abrk_shards_sync(None) < 0
+    assert L.abrk_plans_launch(None, 0, 1, 0) < 0
+    ids = (C.c_int * 1)(12345)
+    assert L.abrk_plans_launch(ids, 1, 1, 7) < 0 and L.abrk_plans_launch(ids, 1, 1, 0) < 0  # bad mode; unknown plan
+    if a.device_count() == 0:
+        rc = L.abrk_osc_generate_resident(ur5, _abi.F64, C.byref(p), C.byref(cut), tab, tab, tab, None, None, None, tab, None)
+        assert rc == -2 and b"no HIP device" in L.abrk_last_error()  # ABRK_ENODEV
+        assert L.abrk_shards_sync(C.byref(cut)) == -2
+        assert not L.abrk_shard_stream(0, 0)
+
+
+def test_sharded_array_cut_matches_shard_range():
+    from abr_control_amd.sharding import ShardedArray, shard_range
+
+    for B in (0, 1, 7, 8, 9, 4096, 10007):
+        for G in (1, 2, 3, 8, 13):
+            rows = ShardedArray.cut(B, G)
+            assert sum(rows) == B and max(rows) - min(rows) <= 1
+            assert rows == [shard_range(B, g, G)[1] - shard_range(B, g, G)[0] for g in range(G)]
 
 
 def test_builtin_arm_registry_matches_tables(L):
