@@ -340,13 +340,17 @@ def test_gpu_singular_flag_is_per_stream():
     def host_call():
         good.osc(p, q[:8], dq[:8], t[:8])
 
+    before = _abi.ScratchInfo()
+    check(lib().abrk_scratch_stats(0, before))
     for _ in range(200):
         th = threading.Thread(target=host_call)
         th.start()
         th.join()
     info = _abi.ScratchInfo()
     check(lib().abrk_scratch_stats(0, info))
-    assert info.status_words_out <= 8 and info.status_blocks <= 2, (info.status_words_out, info.status_blocks)
+    # (relative to what the process held before: other tests' live streams and threads keep their words)
+    assert info.status_words_out <= before.status_words_out + 1, (before.status_words_out, info.status_words_out)
+    assert info.status_blocks <= before.status_blocks + 1, (before.status_blocks, info.status_blocks)
 
 
 def test_gpu_python_api_drop_in():
