@@ -144,7 +144,10 @@ struct LdsScratch : ScratchBase {
   template <int R>
   __device__ __forceinline__ void get_row(ic<R>, T (&row)[N]) const {
     __builtin_amdgcn_sched_barrier(0);
-    const V2* vs = slab + lane;
+    // (an LDS-typed pointer: the reads stay ds_read_b128 - through the generic pointer they were flat loads, which take
+    //  the slower flat path into LDS and tie their wait to the vector-memory counter as well)
+    typedef __attribute__((address_space(3))) const V2 LV2;
+    LV2* vs = (LV2*)(slab + lane);
     asm volatile("" : "+v"(vs));
     sfor<NP>([&](auto k) ABRK_LAMBDA {
       constexpr int i0 = 2 * k(), i1 = 2 * k() + 1;
