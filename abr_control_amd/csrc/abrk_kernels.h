@@ -88,7 +88,13 @@ constexpr int osc_min_waves(int km, bool use_c, int feat, bool ortho, int pass =
   // six-row law: the first pass of orthogonal chains fits 256 registers (UR5: 100-216 B of scratch, all of it in cold
   // branches); general chains carry a 3 x 3 W per joint through the kinematics and would spill 250-650 B in the hot
   // path (measured in round 3: forcing them under 256 registers loses)
-  if (km == 6) return (pass == 1 && ortho && feat <= 1) ? 2 : kMinWaves;
+  // (round 6: the plain first pass of built-in / compiled GENERAL chains is asked to fit two waves as well - without the
+  //  persistent loop, whose hoisted literals and parameters overflow the scalar registers (190 v_readlane per row), it needs
+  //  272 + 16 registers, and capped at 256 it spills 68 B per lane: Jaco2, five task rows, same box, loop form at one wave /
+  //  one row per lane at one wave / at two waves: 8 M rows 852 / 815 / 756 us, 1 M rows 133 / 127 / 107, 65 536 rows 17.3 /
+  //  15.8 / 17.4, 4096-row step 9.56 / 8.44 / 9.08 us (profiles/round6/ab/jaco2_two_waves/).  With the Coriolis vector the
+  //  same cap costs 370 - 430 B of scratch: those kernels keep the loop.)
+  if (km == 6) return (pass == 1 && feat <= 1 && (ortho || (is_static && feat == 0 && !use_c))) ? 2 : kMinWaves;
   return ((!use_c || ortho) && feat <= 1) ? 2 : kMinWaves;
 }
 
@@ -284,7 +290,7 @@ osc_kernel(A arm, OscP<T> P, long B, const T* __restrict__ qg, const T* __restri
       return scr.deferred;
     };
     static_assert(!NOTS || (KM == 6 && FEAT == 0), "NOTS is instantiated for the plain six-row law");
-    static_assert(!EEF || (KM == 6 && FEAT == 0 && km6_first_pass_plain(KM, USE_C, FEAT, A::kOrtho, 1, A::kStatic)),
+    static_assert(!EEF || (A::kOrtho && KM == 6 && FEAT == 0 && km6_first_pass_plain(KM, USE_C, FEAT, A::kOrtho, 1, A::kStatic)),
                   "EEF is instantiated for the plain six-row law of arms with a two-wave first pass");
     using S0 = std::conditional_t<kLds, LdsScratch<T, A::N>, TabScratch<T, A::N>>;
     using S1 = std::conditional_t<PASS == 1, DeferOnly<S0>, S0>;
@@ -817,12 +823,12 @@ struct Launch {
   static hipError_t osc_launch(const LaunchArgs& la, const OscArgs& a) {
     // the first pass of the plain six-row law has an instantiation for "ref_frame is the end effector" (EEF: no frame
     // capture in the forward kinematics; the same bits) - the reference benchmark's setting
-    // Built for the arms whose first pass holds two waves per SIMD (orthogonal built-in / compiled chains: where it was
-    // measured, UR5 8 M rows -1.6 %); the one-wave persistent-loop first pass of general chains keeps the capture.  EVERY
+    // Built for orthogonal built-in / compiled chains (where it was measured, UR5 8 M rows -1.6 %); general chains keep the
+    // capture (their EEF first pass faulted on the four-joint test arm: profiles/round6/NOTES.md section 2).  EVERY
     // pass of such a launch takes the EEF form (first pass, recompute pass, one-pass): the capture changes the basic-block
     // structure of the forward kinematics, and with it which multiply the compiler fuses with which add in its
     // `c a0 + s a1` shapes - a row's bits must not depend on the pass that evaluates it.
-    constexpr bool kEefBuilt = km6_first_pass_plain(KM, UC, FEAT, A::kOrtho, 1, A::kStatic);
+    constexpr bool kEefBuilt = A::kOrtho && km6_first_pass_plain(KM, UC, FEAT, A::kOrtho, 1, A::kStatic);
     const bool eef = kEefBuilt && static_cast<const OscP<T>*>(a.P)->ref_frame == 2 * A::N + 1;
     auto launch = [&](auto pass, auto nots_, auto eef_, dim3 grid, int mode) {
       hipLaunchKernelGGL((osc_kernel<A, T, KM, UC, FEAT, pass(), nots_(), eef_()>), grid, dim3(kBlock), 0, la.stream,

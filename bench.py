@@ -263,8 +263,10 @@ class Runner:
             blocks = min(blocks, 256 * 32 * 4)
         elif self.kind == "obstacles":
             blocks = min(blocks, 4096)
-        elif self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name() and self.arm == "jaco2":
-            # the six-row first pass of a general chain (Jaco2: one wave per SIMD) is a persistent grid
+        elif (self.kind in ("osc", "osc_damp") and ", 6, " in self.kernel_name() and self.arm == "jaco2"
+              and (self.params.use_C or self.params.n_null)):
+            # the six-row first pass of a general chain with the Coriolis vector or fused null controllers (one wave per
+            # SIMD) is a persistent grid; the plain law's runs one row per lane since round 6 (two waves per SIMD)
             blocks = min(blocks, 4096)
         return blocks * 64
 
