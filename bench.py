@@ -426,6 +426,22 @@ def concurrent_streams_rate(workload, B, device, n_streams, steps, graph_steps=1
             "us_per_step_per_stream": round(wall / total_steps * 1e6, 3)}
 
 
+def kernel_sources_hash():
+    """md5 over the kernel and host sources (abr_control_amd/csrc/*.{h,hip,cpp}, include/*.h): the profile summaries carry
+    the hash of the tree they were taken on (`_sources`), the bench line the hash of the tree it runs on - equal hashes
+    mean the profiled kernels ARE this tree's kernels, whatever documents were committed in between"""
+    import glob
+    import hashlib
+
+    h = hashlib.md5()
+    files = sorted(glob.glob(os.path.join(REPO, "abr_control_amd", "csrc", "*.h")) + glob.glob(os.path.join(REPO, "abr_control_amd", "csrc", "*.hip"))
+                   + glob.glob(os.path.join(REPO, "abr_control_amd", "csrc", "*.cpp")) + glob.glob(os.path.join(REPO, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _profiled(fname, kernel, batch):
     """(entry, "profiles/<round>/<fname>", commit the profile was taken at) of the committed rocprofv3 evidence for this
     (kernel, rows per launch) - or (None, None, None)"""
@@ -438,12 +454,21 @@ def _profiled(fname, kernel, batch):
         except (OSError, ValueError):
             continue
         if key in d:
-            return dict(d[key], rows=batch), f"profiles/{rnd}/{fname}", d.get("_commit")
+            return dict(d[key], rows=batch), f"profiles/{rnd}/{fname}", _stamp(d)
         # the same kernel profiled at another HBM-sized batch: per-row figures carry over (the caller rescales)
         same = sorted(((int(k.rsplit(":", 1)[1]), k) for k in d if k.startswith(kn + ":")), reverse=True)
         if same and same[0][0] >= (1 << 20) and batch >= (1 << 20):
-            return dict(d[same[0][1]], rows=same[0][0]), f"profiles/{rnd}/{fname} (profiled at {same[0][0]} rows)", d.get("_commit")
+            return dict(d[same[0][1]], rows=same[0][0]), f"profiles/{rnd}/{fname} (profiled at {same[0][0]} rows)", _stamp(d)
     return None, None, None
+
+
+def _stamp(d):
+    """commit of a profile summary + whether its kernel sources are this tree's"""
+    src = d.get("_sources")
+    if not src:
+        return d.get("_commit")
+    same = src == kernel_sources_hash()
+    return f"{d.get('_commit')} (kernel sources {src}: {'identical to' if same else 'DIFFERENT from'} this tree's)"
 
 
 def profiled_traffic(kernel, batch):

@@ -70,7 +70,11 @@ def test_summarize_profiles_keys_grid_stride_kernels_by_rows(tmp_path):
         json.dump(t, open(os.path.join(REPO, "profiles", "_test_tmp", "traffic.json"), "w"))
         bench.PROFILE_DIRS = ("_test_tmp",)
         traffic, _, commit = bench.profiled_traffic(leg["kernel"], rows)
-        assert commit == "test" and np.isclose(traffic, 48 * rows)
+        # (the stamp: the profile's commit + whether its kernel sources are this tree's - round 6)
+        assert commit.startswith("test") and "identical to this tree's" in commit and np.isclose(traffic, 48 * rows)
+        t["_sources"] = "0" * 16
+        json.dump(t, open(os.path.join(REPO, "profiles", "_test_tmp", "traffic.json"), "w"))
+        assert "DIFFERENT from this tree's" in bench.profiled_traffic(leg["kernel"], rows)[2]
     finally:
         bench.PROFILE_DIRS = old
         import shutil

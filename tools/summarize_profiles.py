@@ -179,6 +179,15 @@ if rows:
                 "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (gfx950)"}
     commit = os.environ.get("ABRK_PROFILE_COMMIT", "unknown")
     traffic["_commit"] = commit
+    try:  # the hash of the kernel / host sources of the tree the profile was taken on (bench.py kernel_sources_hash)
+        import importlib.util as _iu
+
+        _sp = _iu.spec_from_file_location("abrk_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+        _b = _iu.module_from_spec(_sp)
+        _sp.loader.exec_module(_b)
+        traffic["_sources"] = _b.kernel_sources_hash()
+    except Exception:  # noqa: BLE001
+        pass
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     # executed instructions per row, issue utilisation and effective clock per (kernel, rows): what bench.py's
     # `roofline.valu` block is computed from
@@ -194,7 +203,7 @@ if rows:
         kt2["kernel"] = kt2["Kernel_Name"].str.split("(").str[0].str.replace("void abrk::", "").str[:90]
         for (k, gsz), grp in kt2.groupby(["kernel", "Grid_Size_X"]):
             durs[(k, int(gsz))] = float(grp["dur"].mean())
-    counters = {"_commit": commit}
+    counters = {"_commit": commit, "_sources": traffic.get("_sources")}
     for (k, gsz), r in piv.iterrows():
         if "SQ_WAVES" not in r or r["SQ_WAVES"] != r["SQ_WAVES"] or gsz < 4096:
             continue
